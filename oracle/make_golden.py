@@ -1,0 +1,195 @@
+"""Generate golden vectors by running the UNMODIFIED reference (torch CPU fp32) on
+seeded inputs.  Build-container only (needs /root/reference); the committed outputs
+under tests/golden/ are what travels.     python oracle/make_golden.py
+
+Reference entry points driven (all imported from /root/reference/src/modules.py):
+  sample :287-288, norm :275-276, tensor_correlation :283-284, super_perm :291-295,
+  ContrastiveCorrelationLoss.helper :325-347 and .forward :349-398.
+The reference draws coords1/coords2/perm from the torch global RNG inside forward();
+to hand identical draws to a GPU path we (a) replay the same draw order after
+torch.manual_seed(seed) and (b) assert that composing the reference's own
+sample()/helper() with those explicit draws reproduces reference forward() bitwise.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim                       # noqa: E402
+from oracle.corr_oracle import synth_inputs       # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+class Cfg:
+    def __init__(self, **kw):
+        self.pointwise = True; self.zero_clamp = True; self.stabalize = False
+        self.use_salience = False; self.feature_samples = 11; self.neg_samples = 5
+        self.pos_intra_shift = .18; self.pos_inter_shift = .12; self.neg_inter_shift = .46
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def ref_forward_explicit(M, cfg, f, fp, c, cp, coords1, coords2, perms):
+    """Reference forward() recomposed from the reference's own sample()/helper()
+    with explicit RNG draws (modules.py:369-398)."""
+    L = M.ContrastiveCorrelationLoss(cfg)
+    feats = M.sample(f, coords1); code = M.sample(c, coords1)
+    feats_pos = M.sample(fp, coords2); code_pos = M.sample(cp, coords2)
+    il, icd = L.helper(feats, feats, code, code, cfg.pos_intra_shift)
+    el, ecd = L.helper(feats, feats_pos, code, code_pos, cfg.pos_inter_shift)
+    nls, ncds = [], []
+    for perm in perms:
+        fn = M.sample(f[perm], coords2); cn = M.sample(c[perm], coords2)
+        nl, ncd = L.helper(feats, fn, code, cn, cfg.neg_inter_shift)
+        nls.append(nl); ncds.append(ncd)
+    S = cfg.feature_samples
+    if nls:
+        nl = torch.cat(nls, 0); ncd = torch.cat(ncds, 0)
+    else:
+        nl = torch.zeros(0, S, S, S, S); ncd = torch.zeros(0, S, S, S, S)
+    return il.mean(), icd, el.mean(), ecd, nl, ncd
+
+
+def run_case(M, name, B, C, H, W, K, S, n_neg, seed, cfg_kw=None, dino_like=False,
+             store_inputs=True, subsample=1, channels_last=False):
+    cfg = Cfg(feature_samples=S, neg_samples=n_neg, **(cfg_kw or {}))
+    d = synth_inputs(B, C, H, W, K, S, n_neg, seed, dino_like=dino_like)
+    t = {k: torch.from_numpy(v) for k, v in d.items()}
+    f, fp = t["feats"], t["feats_pos"]
+    if channels_last:   # same values, channels-last strides as DinoFeaturizer produces (modules.py:97)
+        f = f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        fp = fp.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    c = t["code"].clone().requires_grad_(True)
+    cp = t["code_pos"].clone().requires_grad_(True)
+    perms = [t["perms"][i] for i in range(n_neg)]
+    out = ref_forward_explicit(M, cfg, f, fp, c, cp, t["coords1"], t["coords2"], perms)
+    # upstream weights as train_segmentation.py:179-181 applies them, plus a random
+    # upstream on every tensor output so the general backward is pinned too
+    g = torch.Generator().manual_seed(seed + 77)
+    u_nl = torch.randn(out[4].shape, generator=g) / max(out[4].numel(), 1)
+    u_cd = [torch.randn(o.shape, generator=g) / max(o.numel(), 1) for o in (out[1], out[3], out[5])]
+    loss_train = .67 * out[0] + .25 * out[2] + (.63 * out[4].mean() if n_neg else 0.)
+    gc_train = torch.autograd.grad(loss_train, [c, cp], retain_graph=True, allow_unused=True)
+    loss_gen = 1.3 * out[0] - .7 * out[2] + (out[4] * u_nl).sum() + \
+        sum((o * u).sum() for o, u in zip((out[1], out[3], out[5]), u_cd))
+    gc_gen = torch.autograd.grad(loss_gen, [c, cp], allow_unused=True)
+
+    def npy(x):
+        return x.detach().numpy()
+
+    def sub(x):
+        x = npy(x).reshape(-1)
+        return x[::subsample].copy()
+
+    rec = dict(
+        meta=np.array([B, C, H, W, K, S, n_neg, seed, int(dino_like), subsample], dtype=np.int64),
+        cfg_flags=np.array([cfg.pointwise, cfg.zero_clamp, cfg.stabalize], dtype=np.int64),
+        shifts=np.array([cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift], dtype=np.float64),
+        pos_intra_loss=npy(out[0]), pos_inter_loss=npy(out[2]),
+        pos_intra_cd=sub(out[1]), pos_inter_cd=sub(out[3]),
+        neg_inter_loss=sub(out[4]), neg_inter_cd=sub(out[5]),
+        neg_loss_mean=np.float32(out[4].mean().item() if n_neg else 0.0),
+        cd_means=np.array([out[1].mean().item(), out[3].mean().item(),
+                           out[5].mean().item() if n_neg else 0.0]),
+        d_code_train=sub(gc_train[0]), d_code_pos_train=sub(gc_train[1]),
+        d_code_gen=sub(gc_gen[0]), d_code_pos_gen=sub(gc_gen[1]),
+        d_code_train_norm=np.float64(gc_train[0].double().norm().item()),
+        d_code_pos_train_norm=np.float64(gc_train[1].double().norm().item()),
+        u_neg_loss=sub(u_nl) if subsample == 1 else np.zeros(0, np.float32),
+        u_intra_cd=sub(u_cd[0]) if subsample == 1 else np.zeros(0, np.float32),
+        u_inter_cd=sub(u_cd[1]) if subsample == 1 else np.zeros(0, np.float32),
+        u_neg_cd=sub(u_cd[2]) if subsample == 1 else np.zeros(0, np.float32),
+        input_checksum=np.array([float(np.abs(v.astype(np.float64)).sum()) for v in
+                                 (d["feats"], d["feats_pos"], d["code"], d["code_pos"],
+                                  d["coords1"], d["coords2"])]),
+        perms=d["perms"],
+    )
+    if store_inputs:
+        for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2"):
+            rec["in_" + k] = d[k]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name, "intra=%.8f inter=%.8f neg=%.8f" %
+          (out[0].item(), out[2].item(), out[4].mean().item() if n_neg else 0.0))
+
+
+def seeded_e2e_case(M):
+    """Reference forward() under torch.manual_seed, with the RNG draws captured by
+    replaying the same draw order (modules.py:366,367,383) - proves the explicit-draw
+    recomposition used above is the reference's forward."""
+    cfg = Cfg(feature_samples=5, neg_samples=3)
+    B, C, H, W, K = 4, 16, 9, 9, 7
+    d = synth_inputs(B, C, H, W, K, 5, 0, seed=5)
+    f, fp, c, cp = (torch.from_numpy(d[k]) for k in ("feats", "feats_pos", "code", "code_pos"))
+    torch.manual_seed(123)
+    ref = M.ContrastiveCorrelationLoss(cfg)(f, fp, None, None, c, cp)
+    torch.manual_seed(123)
+    coords1 = torch.rand(B, 5, 5, 2) * 2 - 1
+    coords2 = torch.rand(B, 5, 5, 2) * 2 - 1
+    perms = [M.super_perm(B, f.device) for _ in range(3)]
+    mine = ref_forward_explicit(M, cfg, f, fp, c, cp, coords1, coords2, perms)
+    for a, b in zip(ref, mine):
+        assert torch.equal(a, b), "explicit-draw recomposition differs from reference forward()"
+    np.savez_compressed(
+        os.path.join(OUT, "seeded_e2e.npz"),
+        in_feats=d["feats"], in_feats_pos=d["feats_pos"], in_code=d["code"], in_code_pos=d["code_pos"],
+        coords1=coords1.numpy(), coords2=coords2.numpy(),
+        perms=torch.stack(perms).numpy(),
+        pos_intra_loss=ref[0].numpy(), pos_intra_cd=ref[1].numpy(), pos_inter_loss=ref[2].numpy(),
+        pos_inter_cd=ref[3].numpy(), neg_inter_loss=ref[4].numpy(), neg_inter_cd=ref[5].numpy())
+    print("wrote seeded_e2e (recomposition == reference forward, bitwise)")
+
+
+def primitives_case(M):
+    g = torch.Generator().manual_seed(9)
+    t = torch.randn(2, 5, 6, 7, generator=g)
+    coords = torch.rand(2, 3, 4, 2, generator=g) * 2.4 - 1.2     # includes out-of-range -> border clip
+    a = torch.randn(2, 5, 3, 4, generator=g)
+    b = torch.randn(2, 5, 2, 3, generator=g)
+    nin = torch.cat([a[:1], torch.zeros(1, 5, 3, 4)])             # zero vectors -> eps branch of norm
+    sp = []
+    for s in range(8):
+        torch.manual_seed(s)
+        rp = torch.randperm(8)
+        torch.manual_seed(s)
+        sp.append(np.stack([rp.numpy(), M.super_perm(8, torch.device("cpu")).numpy()]))
+    np.savez_compressed(
+        os.path.join(OUT, "primitives.npz"),
+        t=t.numpy(), coords=coords.numpy(), sample=M.sample(t, coords).numpy(),
+        norm_in=nin.numpy(), norm_out=M.norm(nin).numpy(),
+        a=a.numpy(), b=b.numpy(), corr=M.tensor_correlation(a, b).numpy(),
+        super_perm=np.stack(sp))
+    print("wrote primitives")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    M = ref_shim.load_reference_modules()
+    primitives_case(M)
+    seeded_e2e_case(M)
+    # small full-tensor cases (inputs stored); H != W catches x/y swaps, odd K/C catch padding bugs
+    run_case(M, "small_default", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=1)
+    run_case(M, "small_nopointwise", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=2, cfg_kw=dict(pointwise=False))
+    run_case(M, "small_noclamp_stab", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=3,
+             cfg_kw=dict(zero_clamp=False, stabalize=True))
+    run_case(M, "small_stab", B=2, C=33, H=8, W=5, K=9, S=3, n_neg=1, seed=4, cfg_kw=dict(stabalize=True),
+             dino_like=False)
+    run_case(M, "small_dinolike_S11", B=1, C=64, H=12, W=12, K=70, S=11, n_neg=1, seed=6, dino_like=True,
+             channels_last=True)
+    run_case(M, "small_noneg", B=2, C=8, H=5, W=5, K=4, S=3, n_neg=0, seed=8)
+    # BASELINE config-1 shape (B=4, ViT-S/8 224^2): inputs regenerated from the seed, outputs subsampled
+    run_case(M, "cfg1_B4_vits8", B=4, C=384, H=28, W=28, K=70, S=11, n_neg=5, seed=11,
+             store_inputs=False, subsample=61)
+    run_case(M, "cfg1_B4_vits8_dinolike", B=4, C=384, H=28, W=28, K=70, S=11, n_neg=5, seed=12,
+             store_inputs=False, subsample=61, dino_like=True, channels_last=True)
+    # BASELINE config-4 shape (ViT-B/8 320^2 -> 768 x 40 x 40), B=2 to stay small
+    run_case(M, "cfg4_B2_vitb8", B=2, C=768, H=40, W=40, K=70, S=11, n_neg=5, seed=13,
+             store_inputs=False, subsample=61)
+
+
+if __name__ == "__main__":
+    main()
