@@ -1,0 +1,303 @@
+#!/usr/bin/env python
+"""Benchmark of the correspondence-loss hot path on MI355X.
+
+Metric (BASELINE.json): image-pairs/sec through the correspondence loss, B=32 per GPU,
+224^2 crops, ViT-S/8 (C=384, 28x28 feature map, K=70 code channels, S=11, 5 negatives).
+One "step" = forward + backward of the fused loss over one batch (per rank), through the
+C ABI of libstego_corr.so; at N>1 each step is followed by the DDP collective of the
+reference's training loop (one flat RCCL all-reduce of the segmentation-head gradients,
+~0.82 MB for ViT-S).  Inputs are synthetic, resident in HBM before the timed region; a ring
+of input sets larger than the 256 MB Infinity Cache is rotated so steps read from HBM.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level table
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-input MFMA (same table)
+MFMA_BF16_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA
+
+
+class Cfg:
+    """Shipped defaults of the reference (configs/train_config.yml:41-64)."""
+    pointwise = True
+    zero_clamp = True
+    stabalize = False
+    use_salience = False
+    feature_samples = 11
+    neg_samples = 5
+    pos_intra_shift = 0.18
+    pos_inter_shift = 0.12
+    neg_inter_shift = 0.46
+    pos_intra_weight = 0.67
+    pos_inter_weight = 0.25
+    neg_inter_weight = 0.63
+    corr_precision = "f32"
+
+
+WORKLOADS = {
+    # name: (C, H, W, K)   (BASELINE.json configs[1] and configs[3])
+    "vits8_224": (384, 28, 28, 70),
+    "vitb8_320": (768, 40, 40, 70),
+}
+
+
+def algorithmic_bytes_fwd(B, C, H, W, K, S, n_neg):
+    """every distinct tensor once, fp32."""
+    P = 2 + n_neg
+    return 4 * (2 * B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B + \
+        4 * (P * B * S ** 4 + n_neg * B * S ** 4) + 12
+
+
+def algorithmic_flops_fwd(B, C, K, S, n_neg):
+    return 2 * (2 + n_neg) * B * S ** 4 * (C + K)
+
+
+def head_grad_numel(C, K, n_classes=27):
+    """Trainable parameters whose gradients DDP all-reduces:
+    cluster1 (C*K+K), cluster2 (C*C+C + C*K+K), linear_probe (K*n+n), cluster_probe (n*K)."""
+    return (C * K + K) + (C * C + C + C * K + K) + (K * n_classes + n_classes) + n_classes * K
+
+
+def make_inputs(B, C, H, W, K, S, n_neg, seed, dev):
+    """DINO-like synthetic features (SURVEY.md 8(d) distribution ii), channels-last strided views
+    exactly as DinoFeaturizer hands them over (modules.py:97), plus the RNG draws of one step."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    R = 8
+    proto = torch.randn(R, C, device=dev, generator=g)
+    head = torch.randn(K, C, device=dev, generator=g) / C ** 0.5
+
+    def feat():
+        z = torch.randn(B, H // 4 + 2, W // 4 + 2, R, device=dev, generator=g)
+        z = z.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W]
+        x = z @ proto + 0.3 * torch.randn(B, H, W, C, device=dev, generator=g)
+        keep = (torch.rand(B, 1, 1, C, device=dev, generator=g) > 0.1).float() / 0.9
+        return (x * keep).contiguous()            # [B,H,W,C] memory
+
+    f, fp = feat(), feat()
+    c = (f @ head.t()).contiguous()
+    cp = (fp @ head.t()).contiguous()
+    coords1 = torch.rand(B, S, S, 2, device=dev, generator=g) * 2 - 1
+    coords2 = torch.rand(B, S, S, 2, device=dev, generator=g) * 2 - 1
+    perms = []
+    for _ in range(n_neg):
+        p = torch.randperm(B, device=dev, generator=g)
+        p = torch.where(p == torch.arange(B, device=dev), p + 1, p) % B
+        perms.append(p)
+    perms = torch.stack(perms) if perms else torch.zeros(0, B, dtype=torch.long, device=dev)
+    return dict(feats=f.permute(0, 3, 1, 2), feats_pos=fp.permute(0, 3, 1, 2),
+                code=c.permute(0, 3, 1, 2), code_pos=cp.permute(0, 3, 1, 2),
+                coords1=coords1, coords2=coords2, perms=perms)
+
+
+def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
+    """The reference's CPU path (torch CPU port of modules.py:349-398, oracle/torch_cpu_port.py),
+    forward+backward, on the host cores of this box.  Bounded sample."""
+    from oracle.torch_cpu_port import corr_loss_torch_cpu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    d = make_inputs(B, C, H, W, K, S, n_neg, 4321, torch.device("cpu"))
+    code = d["code"].clone().requires_grad_(True)
+    code_pos = d["code_pos"].clone().requires_grad_(True)
+
+    def step():
+        code.grad = None
+        code_pos.grad = None
+        out = corr_loss_torch_cpu(d["feats"], d["feats_pos"], code, code_pos, d["coords1"], d["coords2"],
+                                  list(d["perms"]), cfg)
+        (cfg.pos_intra_weight * out[0] + cfg.pos_inter_weight * out[2] + cfg.neg_inter_weight * out[4].mean()).backward()
+
+    step(); step()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 12 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=B / med, unit="image-pairs/s", cores=cores, kind="port",
+                sample="%d fwd+bwd steps of the same B=%d workload (median %.1f ms), torch %s CPU, %d threads; "
+                       "port = oracle/torch_cpu_port.py (ATen CPU kernels the reference calls)"
+                       % (len(times), B, med * 1e3, torch.__version__, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (B)")
+    ap.add_argument("--workload", default="vits8_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--sets", type=int, default=4, help="input sets rotated (4 x 91 MB > 256 MB Infinity Cache)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="time the forward alone (reported in config)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
+
+    from stego_amd import capi
+    cfg = Cfg()
+    cfg.corr_precision = args.precision
+    C, H, W, K = WORKLOADS[args.workload]
+    B, S, n_neg = args.batch, cfg.feature_samples, cfg.neg_samples
+    prec = capi.PREC_F32 if args.precision == "f32" else capi.PREC_BF16X3
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
+                          prec)
+    sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev) for i in range(args.sets)]
+    # upstream gradients exactly as train_segmentation.py:169-181 produces them
+    g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
+    g_inter = torch.tensor(cfg.pos_inter_weight, device=dev)
+    g_neg = torch.full((1,), cfg.neg_inter_weight / (n_neg * B * S ** 4), device=dev).expand(n_neg * B, S, S, S, S)
+    grad_buf = torch.zeros(head_grad_numel(C, K), device=dev)     # flat head-gradient bucket (DDP)
+    keep = [None] * args.sets
+
+    def step_compute(i):
+        d = sets[i]
+        need_grad = not args.fwd_only
+        out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"],
+                            d["perms"], need_grad)
+        if need_grad:
+            lm, icd, ecd, nl, ncd, sw, sm = out
+            grads = capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], sw, sm,
+                                  icd, ecd, ncd, g_intra, g_inter, g_neg, None, None, None)
+            keep[i] = (out, grads)
+        else:
+            keep[i] = (out,)
+
+    for i in range(args.sets):          # eager warm-up (also sets kernel attributes before any capture)
+        step_compute(i)
+    torch.cuda.synchronize()
+
+    graphs = None
+    launch = "eager"
+    if not args.no_graph:
+        try:
+            graphs = []
+            for i in range(args.sets):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    step_compute(i)
+                graphs.append(gr)
+            launch = "hipgraph"
+        except Exception as e:      # noqa: BLE001 - fall back to eager launches, say so in the output
+            graphs = None
+            launch = "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
+
+    def step(k):
+        i = k % args.sets
+        if graphs is not None:
+            graphs[i].replay()
+        else:
+            step_compute(i)
+        if dist is not None:
+            dist.all_reduce(grad_buf)               # gradients of the segmentation head only (backbone frozen)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
+    roof = roof_mfma = None
+    fin_us = None
+    if rank == 0:
+        ms_main = ms_fin = 0.0
+        rounds = 5
+        for r in range(rounds + 1):
+            a = b = 0.0
+            for i in range(args.sets):
+                d = sets[i]
+                m, f = capi.corr_fwd_profile(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"],
+                                             d["coords2"], d["perms"], not args.fwd_only, 1)
+                a += m
+                b += f
+            if r > 0:
+                ms_main += a / args.sets
+                ms_fin += b / args.sets
+        ms_main /= rounds
+        ms_fin /= rounds
+        fin_us = ms_fin * 1e3
+        ab = algorithmic_bytes_fwd(B, C, H, W, K, S, n_neg)
+        fl = algorithmic_flops_fwd(B, C, K, S, n_neg)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%s_B%d" % (args.workload, args.precision, B))
+            except Exception:       # noqa: BLE001
+                traffic = None
+        ach = ab / (ms_main * 1e-3)
+        roof = dict(bound="hbm", kernel="corr_fwd_kernel", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=ach / HBM_PEAK, traffic=traffic, algorithmic_bytes=ab, us_per_launch=ms_main * 1e3)
+        peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_BF16_PEAK / 3.0
+        roof_mfma = dict(bound="mfma", achieved=fl / (ms_main * 1e-3) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                         frac=fl / (ms_main * 1e-3) / peak, algorithmic_flops=fl,
+                         note="f32: v_mfma_f32_32x32x2_f32 peak; bf16x3: dense bf16 peak / 3 (three MFMAs per product)")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(B, C, H, W, K, S, n_neg, cfg)
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        rec = {
+            "metric": "image-pairs/sec through correspondence loss, B=32 224^2, ViT-S/8",
+            "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3-split (f32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "%s: B=%d/GPU, C=%d, %dx%d map, K=%d, S=%d, %d negatives, self+KNN+random "
+                                   "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,
+                                                             "forward only" if args.fwd_only else "forward+backward"),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
+                       "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)",
+                       "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
+            "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/*
+ * stego_corr.h  --  C ABI of libstego_corr.so: the MI355X (gfx950) implementation of
+ * STEGO's feature-correspondence distillation loss.
+ *
+ * The reference (mhamilton723/STEGO) has no FFI/plugin interface: its boundary for this
+ * path is the Python surface of src/modules.py.  Each entry point below therefore names
+ * the reference function(s) it replaces (file:line relative to the reference repo); the
+ * Python host layer (stego_amd/modules.py) re-creates the reference classes on top of
+ * these calls and INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - all tensors are device (HBM) pointers to float32 unless stated; index data is int64;
+ *   - inputs are read-only, outputs are fully overwritten; nothing is allocated, freed or
+ *     synchronised inside a call: work is enqueued on `stream` (a hipStream_t) and the
+ *     caller owns ordering; the only scratch is the caller-provided workspace;
+ *   - every function returns STEGO_OK (0) or an error code (never throws / aborts);
+ *     stego_error_string() renders a code.  Shape/argument errors are detected on the
+ *     host before anything is enqueued.
+ */
+#ifndef STEGO_CORR_H
+#define STEGO_CORR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEGO_ABI_VERSION 1
+
+enum {
+    STEGO_OK = 0,
+    STEGO_ERR_NULL = 1,         /* a required pointer is NULL                               */
+    STEGO_ERR_SHAPE = 2,        /* a dimension is <= 0 or inconsistent                      */
+    STEGO_ERR_UNSUPPORTED = 3,  /* valid request this build has no kernel for (see limits)  */
+    STEGO_ERR_WORKSPACE = 4,    /* workspace_bytes < stego_corr_workspace_bytes()           */
+    STEGO_ERR_ALIGN = 5,        /* a pointer is not 4-byte aligned                          */
+    STEGO_ERR_HIP = 1000        /* STEGO_ERR_HIP + hipError_t of a failed launch            */
+};
+
+/* Arithmetic used for the channel contraction (the einsum of modules.py:283-284). */
+enum {
+    STEGO_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate  */
+    STEGO_PREC_BF16X3 = 1    /* split-bf16 (hi*hi + hi*lo + lo*hi) on bf16 MFMA, fp32 accum.;  */
+                             /* ~1e-6 abs error on a cosine similarity (fp32 is ~1e-7)         */
+};
+
+/* hipStream_t without dragging the HIP headers into C callers. */
+typedef void* stego_stream_t;
+
+/* A float32 [N, C, H, W] map with arbitrary element strides (NCHW-contiguous, or the
+ * channels-last strided view DinoFeaturizer produces at modules.py:97). */
+typedef struct StegoMap {
+    const float* data;
+    int64_t stride_n, stride_c, stride_h, stride_w;   /* in elements */
+} StegoMap;
+
+/* Problem description = the cfg keys ContrastiveCorrelationLoss reads
+ * (modules.py:330-387; configs/train_config.yml:41-64) + tensor shapes. */
+typedef struct StegoCorrDesc {
+    int32_t B;                 /* local batch: orig_feats.shape[0]            (modules.py:355) */
+    int32_t C;                 /* feature channels (384 ViT-S, 768 ViT-B)                      */
+    int32_t K;                 /* code channels = cfg.dim                                      */
+    int32_t H, W;              /* feature-map height / width (28 at 224^2/8, 40 at 320^2/8)    */
+    int32_t S;                 /* cfg.feature_samples; S*S sample points per image             */
+    int32_t n_neg;             /* cfg.neg_samples                                              */
+    int32_t pointwise;         /* cfg.pointwise   (modules.py:330-333)                         */
+    int32_t zero_clamp;        /* cfg.zero_clamp  -> clamp min 0.0 else -9999.0 (:337-340)     */
+    int32_t stabalize;         /* cfg.stabalize   -> clamp max 0.8               (:342-345)    */
+    float pos_intra_shift;     /* cfg.pos_intra_shift (:376)                                   */
+    float pos_inter_shift;     /* cfg.pos_inter_shift (:378)                                   */
+    float neg_inter_shift;     /* cfg.neg_inter_shift (:387)                                   */
+    int32_t precision;         /* STEGO_PREC_*                                                 */
+} StegoCorrDesc;
+
+/* Limits of this build: S*S <= 128 (S <= 11), K <= 80 for the backward, every per-image
+ * element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED. */
+
+int stego_abi_version(void);
+const char* stego_error_string(int code);
+
+/* Scratch the forward/backward need (bytes; depends only on the descriptor). */
+size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc);
+
+/*
+ * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws
+ * made by the caller in the reference's order (coords1 :366, coords2 :367, super_perm
+ * x n_neg :383).  One fused kernel does, per (pair-set, image): bilinear border/
+ * align_corners sampling (sample, :287-288) of feats/code at S*S points, L2 normalise
+ * (norm, :275-276), both correlation tensors (tensor_correlation, :283-284) on MFMA, the
+ * pointwise mean shift (:330-333), clamp*(fd-shift) (:337-345); a second tiny kernel
+ * applies the batch-global mean (old_mean, :331) and the two .mean() reductions (:393,:395).
+ *
+ *   feats, feats_pos : [B,C,H,W]   (orig_feats, orig_feats_pos; never differentiated)
+ *   code, code_pos   : [B,K,H,W]   (orig_code, orig_code_pos)
+ *   coords1, coords2 : [B,S,S,2] contiguous, values in [-1,1] (x=width first)
+ *   perms            : int64 [n_neg,B] contiguous, values in [0,B)  (may be NULL iff n_neg==0)
+ * outputs (contiguous):
+ *   loss_means       : [2] = { pos_intra_loss.mean(), pos_inter_loss.mean() }
+ *   pos_intra_cd, pos_inter_cd : [B,S,S,S,S]
+ *   neg_inter_loss, neg_inter_cd : [n_neg*B,S,S,S,S]   (torch.cat over negatives, :390-391)
+ *   saved_w          : optional [(2+n_neg)*B, S^4]: (fd_centred - shift) per pair-set, and
+ *   saved_mean       : optional [2+n_neg]: old_mean per pair-set; both or neither; they are
+ *                      what stego_corr_bwd needs of the (no_grad) feature side.
+ */
+int stego_corr_fwd(const StegoCorrDesc* desc,
+                   const StegoMap* feats, const StegoMap* feats_pos,
+                   const StegoMap* code, const StegoMap* code_pos,
+                   const float* coords1, const float* coords2, const int64_t* perms,
+                   float* loss_means,
+                   float* pos_intra_cd, float* pos_inter_cd,
+                   float* neg_inter_loss, float* neg_inter_cd,
+                   float* saved_w, float* saved_mean,
+                   void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+/*
+ * Measurement hook: exactly stego_corr_fwd, run `iters` times with HIP events recorded on
+ * `stream` around (a) the fused tile kernel and (b) the finalize kernel; returns the mean
+ * duration of each in milliseconds (host pointers) after synchronising.  bench.py derives
+ * roofline.achieved from ms_main.
+ */
+int stego_corr_fwd_profile(const StegoCorrDesc* desc,
+                           const StegoMap* feats, const StegoMap* feats_pos,
+                           const StegoMap* code, const StegoMap* code_pos,
+                           const float* coords1, const float* coords2, const int64_t* perms,
+                           float* loss_means,
+                           float* pos_intra_cd, float* pos_inter_cd,
+                           float* neg_inter_loss, float* neg_inter_cd,
+                           float* saved_w, float* saved_mean,
+                           void* workspace, size_t workspace_bytes, stego_stream_t stream,
+                           int32_t iters, float* ms_main, float* ms_finalize);
+
+/*
+ * Backward of the above w.r.t. orig_code / orig_code_pos (what autograd derives through
+ * modules.py:335-347,369-391: clamp mask, the two code GEMM adjoints, normalize backward,
+ * bilinear scatter-add incl. the orig_code[perm] gather of :385).
+ *
+ *   g_intra, g_inter : device scalars, upstream of loss_means[0], loss_means[1]
+ *   g_neg_loss       : upstream of neg_inter_loss; g_neg_loss_stride = 1 -> dense
+ *                      [n_neg*B,S^4], 0 -> one broadcast device scalar (what .mean() feeds);
+ *                      NULL -> zero
+ *   g_intra_cd, g_inter_cd, g_neg_cd : optional dense upstreams of the cd outputs (NULL -> 0)
+ *   d_code, d_code_pos : OUT, channels-last dense [B,H,W,K] (i.e. grad.permute(0,2,3,1)),
+ *                      overwritten (zero-filled, then accumulated with fp32 atomics).
+ */
+int stego_corr_bwd(const StegoCorrDesc* desc,
+                   const StegoMap* code, const StegoMap* code_pos,
+                   const float* coords1, const float* coords2, const int64_t* perms,
+                   const float* saved_w, const float* saved_mean,
+                   const float* pos_intra_cd, const float* pos_inter_cd, const float* neg_inter_cd,
+                   const float* g_intra, const float* g_inter,
+                   const float* g_neg_loss, int32_t g_neg_loss_stride,
+                   const float* g_intra_cd, const float* g_inter_cd, const float* g_neg_cd,
+                   float* d_code, float* d_code_pos,
+                   void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+/*
+ * ContrastiveCorrelationLoss.helper (modules.py:325-347) on ALREADY SAMPLED tensors:
+ *   f1,f2 : [N,C,S1,S2]   c1,c2 : [N,K,S1,S2]   (desc->B = N, desc->H = S1, desc->W = S2,
+ *   desc->S is ignored, S1*S2 <= 128);  shift = desc->pos_intra_shift.
+ * outputs: loss, cd : [N,S1,S2,S1,S2]; saved_w/saved_mean as above with one pair-set.
+ */
+int stego_corr_helper_fwd(const StegoCorrDesc* desc,
+                          const StegoMap* f1, const StegoMap* f2,
+                          const StegoMap* c1, const StegoMap* c2,
+                          float* loss, float* cd, float* saved_w, float* saved_mean,
+                          void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+/* Backward of helper w.r.t. c1, c2 (dense upstreams g_loss / g_cd, either may be NULL).
+ * d_c1, d_c2: OUT channels-last dense [N,S1,S2,K], overwritten. */
+int stego_corr_helper_bwd(const StegoCorrDesc* desc,
+                          const StegoMap* c1, const StegoMap* c2,
+                          const float* saved_w, const float* saved_mean, const float* cd,
+                          const float* g_loss, const float* g_cd,
+                          float* d_c1, float* d_c2,
+                          void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEGO_CORR_H */

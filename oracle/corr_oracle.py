@@ -58,7 +58,8 @@ def tensor_correlation(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     """reference modules.py:283-284: einsum('nchw,ncij->nhwij')."""
     n, c, h, w = a.shape
     _, _, i, j = b.shape
-    out = np.matmul(a.reshape(n, c, h * w).transpose(0, 2, 1), b.reshape(n, c, i * j))
+    at = np.ascontiguousarray(a.reshape(n, c, h * w).transpose(0, 2, 1))     # (BLAS path needs dense operands)
+    out = np.matmul(at, np.ascontiguousarray(b.reshape(n, c, i * j)))
     return out.reshape(n, h, w, i, j)
 
 
@@ -234,11 +235,12 @@ def _helper_bwd_codes(c1s, c2s, fd_final, cd, shift, cfg, g_loss, g_cd):
     G = -(fd_final - shift) * passes * g_loss
     if g_cd is not None:
         G = G + g_cd
-    n, S = cd.shape[0], cd.shape[1]
-    P = S * S
-    Gm = G.reshape(n, P, P)
-    n1 = norm(c1s).reshape(n, -1, P)          # [n,K,P]
-    n2 = norm(c2s).reshape(n, -1, P)
+    n = cd.shape[0]
+    P1 = cd.shape[1] * cd.shape[2]            # A-side points (h,w)
+    P2 = cd.shape[3] * cd.shape[4]            # B-side points (i,j)
+    Gm = G.reshape(n, P1, P2)
+    n1 = norm(c1s).reshape(n, -1, P1)         # [n,K,P1]
+    n2 = norm(c2s).reshape(n, -1, P2)
     g_n1 = np.matmul(n2, Gm.transpose(0, 2, 1)).reshape(c1s.shape)   # dA[k,hw] = sum_ij G[hw,ij] B[k,ij]
     g_n2 = np.matmul(n1, Gm).reshape(c2s.shape)                      # dB[k,ij] = sum_hw G[hw,ij] A[k,hw]
     return _normalize_bwd(c1s, g_n1), _normalize_bwd(c2s, g_n2)

@@ -1,0 +1,10 @@
+"""stego_amd - MI355X-native (gfx950) implementation of STEGO's feature-correspondence
+distillation hot path (reference: mhamilton723/STEGO, src/modules.py:275-398), behind the
+reference's own Python API.  Compute = hand-written HIP kernels in ``csrc/`` reached through
+the C ABI of ``include/stego_corr.h``; PyTorch-ROCm supplies device memory, streams, autograd
+plumbing and torch.distributed (RCCL)."""
+from .modules import (ContrastiveCorrelationLoss, average_norm, norm, sample,  # noqa: F401
+                      sample_nonzero_locations, super_perm, tensor_correlation)
+
+__all__ = ["ContrastiveCorrelationLoss", "norm", "average_norm", "tensor_correlation", "sample",
+           "super_perm", "sample_nonzero_locations"]

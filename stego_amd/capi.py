@@ -1,0 +1,240 @@
+"""ctypes binding of libstego_corr.so (include/stego_corr.h) for torch tensors.
+
+This is the ONLY compute backend of stego_amd: there is no PyTorch/CPU fallback.  If the
+library is missing or the tensors are not on a HIP device the calls raise.
+PyTorch is used for device memory (caching allocator), streams and autograd plumbing only.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+from . import _build
+
+PREC_F32 = 0
+PREC_BF16X3 = 1
+
+
+class StegoMap(Structure):
+    _fields_ = [("data", c_void_p), ("stride_n", c_int64), ("stride_c", c_int64),
+                ("stride_h", c_int64), ("stride_w", c_int64)]
+
+
+class StegoCorrDesc(Structure):
+    _fields_ = [("B", c_int32), ("C", c_int32), ("K", c_int32), ("H", c_int32), ("W", c_int32),
+                ("S", c_int32), ("n_neg", c_int32), ("pointwise", c_int32), ("zero_clamp", c_int32),
+                ("stabalize", c_int32), ("pos_intra_shift", c_float), ("pos_inter_shift", c_float),
+                ("neg_inter_shift", c_float), ("precision", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/stego_corr.h declares
+_P = c_void_p
+SIGNATURES = {
+    "stego_abi_version": (c_int32, []),
+    "stego_error_string": (ctypes.c_char_p, [c_int32]),
+    "stego_corr_workspace_bytes": (c_size_t, [POINTER(StegoCorrDesc)]),
+    "stego_corr_fwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 3 + [_P] * 7
+                       + [_P, c_size_t, _P]),
+    "stego_corr_fwd_profile": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 3 + [_P] * 7
+                               + [_P, c_size_t, _P] + [c_int32, POINTER(c_float), POINTER(c_float)]),
+    "stego_corr_bwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 2 + [_P] * 3 + [_P] * 2 + [_P] * 3
+                       + [_P, _P, _P, c_int32] + [_P] * 3 + [_P, _P] + [_P, c_size_t, _P]),
+    "stego_corr_helper_fwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 4
+                              + [_P, c_size_t, _P]),
+    "stego_corr_helper_bwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 2 + [_P] * 5 + [_P, _P]
+                              + [_P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the in-tree library (never builds implicitly on a GPU box: build() is explicit)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "stego_amd: %s is missing - the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no fallback path." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so is stale / symbol missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.stego_abi_version() != 1:
+        raise RuntimeError("stego_amd: ABI version mismatch, rebuild the library")
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().stego_error_string(rc).decode()
+        raise RuntimeError("libstego_corr error %d: %s" % (rc, msg))
+
+
+def _require_dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("stego_amd runs on MI355X only: got a %s tensor (no CPU fallback exists)" % t.device)
+
+
+def _map(t):
+    if t.dtype != torch.float32 or t.dim() != 4:
+        raise RuntimeError("expected a float32 [N,C,H,W] tensor, got %s %s" % (t.dtype, tuple(t.shape)))
+    s = t.stride()
+    return StegoMap(t.data_ptr(), s[0], s[1], s[2], s[3])
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_desc(B, C, K, H, W, S, n_neg, cfg, shifts, precision=PREC_F32):
+    return StegoCorrDesc(B, C, K, H, W, S, n_neg, int(bool(cfg.pointwise)), int(bool(cfg.zero_clamp)),
+                         int(bool(cfg.stabalize)), float(shifts[0]), float(shifts[1]), float(shifts[2]),
+                         int(precision))
+
+
+def _dense(t, dtype):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad):
+    """stego_corr_fwd on torch tensors. Returns (loss_means[2], intra_cd, inter_cd, neg_loss, neg_cd,
+    saved_w|None, saved_mean|None)."""
+    _require_dev(feats, feats_pos, code, code_pos, coords1, coords2, perms)
+    lib = load()
+    B, S, n_neg = desc.B, desc.S, desc.n_neg
+    dev = feats.device
+    coords1 = _dense(coords1, torch.float32)
+    coords2 = _dense(coords2, torch.float32)
+    perms = _dense(perms, torch.int64) if n_neg else None
+    f32 = dict(dtype=torch.float32, device=dev)
+    loss_means = torch.empty(2, **f32)
+    intra_cd = torch.empty(B, S, S, S, S, **f32)
+    inter_cd = torch.empty(B, S, S, S, S, **f32)
+    neg_loss = torch.empty(n_neg * B, S, S, S, S, **f32)
+    neg_cd = torch.empty(n_neg * B, S, S, S, S, **f32)
+    saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
+    saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
+    ws_bytes = lib.stego_corr_workspace_bytes(byref(desc))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
+    with torch.cuda.device(dev):
+        _check(lib.stego_corr_fwd(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
+                                  _ptr(coords1), _ptr(coords2), _ptr(perms),
+                                  _ptr(loss_means), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_loss), _ptr(neg_cd),
+                                  _ptr(saved_w), _ptr(saved_mean), _ptr(ws), ws.numel(), _stream()))
+    return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean
+
+
+def corr_fwd_profile(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad, iters):
+    """stego_corr_fwd_profile: mean HIP-event duration (ms) of the tile kernel and of the finalize kernel."""
+    _require_dev(feats, feats_pos, code, code_pos, coords1, coords2, perms)
+    lib = load()
+    B, S, n_neg = desc.B, desc.S, desc.n_neg
+    dev = feats.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    loss_means = torch.empty(2, **f32)
+    intra_cd = torch.empty(B, S ** 4, **f32)
+    inter_cd = torch.empty(B, S ** 4, **f32)
+    neg_loss = torch.empty(max(n_neg * B, 1), S ** 4, **f32)
+    neg_cd = torch.empty(max(n_neg * B, 1), S ** 4, **f32)
+    saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
+    saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
+    ws = torch.empty(max(lib.stego_corr_workspace_bytes(byref(desc)), 16), dtype=torch.uint8, device=dev)
+    mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
+    ms_main, ms_fin = c_float(0), c_float(0)
+    with torch.cuda.device(dev):
+        _check(lib.stego_corr_fwd_profile(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
+                                          _ptr(coords1), _ptr(coords2), _ptr(perms),
+                                          _ptr(loss_means), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_loss),
+                                          _ptr(neg_cd), _ptr(saved_w), _ptr(saved_mean), _ptr(ws), ws.numel(),
+                                          _stream(), int(iters), byref(ms_main), byref(ms_fin)))
+    return ms_main.value, ms_fin.value
+
+
+def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved_w, saved_mean, intra_cd, inter_cd, neg_cd,
+             g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd):
+    """stego_corr_bwd. g_* may be None. Returns (d_code, d_code_pos) as [B,K,H,W] views of channels-last buffers."""
+    _require_dev(code, code_pos, saved_w)
+    lib = load()
+    dev = code.device
+    B, K, H, W = desc.B, desc.K, desc.H, desc.W
+    coords1 = _dense(coords1, torch.float32)
+    coords2 = _dense(coords2, torch.float32)
+    perms = _dense(perms, torch.int64) if desc.n_neg else None
+    stride = 1
+    if g_neg_loss is not None and g_neg_loss.numel() > 0:
+        if all(s == 0 for s in g_neg_loss.stride()):
+            stride = 0                      # expanded scalar: hand over the one element
+        else:
+            g_neg_loss = _dense(g_neg_loss, torch.float32)
+    else:
+        g_neg_loss = None
+    g_intra = None if g_intra is None else _dense(g_intra, torch.float32)
+    g_inter = None if g_inter is None else _dense(g_inter, torch.float32)
+    g_intra_cd = None if g_intra_cd is None else _dense(g_intra_cd, torch.float32)
+    g_inter_cd = None if g_inter_cd is None else _dense(g_inter_cd, torch.float32)
+    g_neg_cd = None if (g_neg_cd is None or g_neg_cd.numel() == 0) else _dense(g_neg_cd, torch.float32)
+    d_code = torch.empty(B, H, W, K, dtype=torch.float32, device=dev)
+    d_code_pos = torch.empty(B, H, W, K, dtype=torch.float32, device=dev)
+    mc, mcp = _map(code), _map(code_pos)
+    with torch.cuda.device(dev):
+        _check(lib.stego_corr_bwd(byref(desc), byref(mc), byref(mcp), _ptr(coords1), _ptr(coords2), _ptr(perms),
+                                  _ptr(saved_w), _ptr(saved_mean), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_cd),
+                                  _ptr(g_intra), _ptr(g_inter), _ptr(g_neg_loss), stride,
+                                  _ptr(g_intra_cd), _ptr(g_inter_cd), _ptr(g_neg_cd),
+                                  _ptr(d_code), _ptr(d_code_pos), None, 0, _stream()))
+    return d_code.permute(0, 3, 1, 2), d_code_pos.permute(0, 3, 1, 2)
+
+
+def helper_fwd(desc, f1, f2, c1, c2, need_grad):
+    _require_dev(f1, f2, c1, c2)
+    lib = load()
+    N, S1, S2 = desc.B, desc.H, desc.W
+    dev = f1.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    loss = torch.empty(N, S1, S2, S1, S2, **f32)
+    cd = torch.empty(N, S1, S2, S1, S2, **f32)
+    saved_w = torch.empty(N, (S1 * S2) ** 2, **f32) if need_grad else None
+    saved_mean = torch.empty(1, **f32) if need_grad else None
+    ws = torch.empty(max(N * 16, 16), dtype=torch.uint8, device=dev)
+    m1, m2, m3, m4 = _map(f1), _map(f2), _map(c1), _map(c2)
+    with torch.cuda.device(dev):
+        _check(lib.stego_corr_helper_fwd(byref(desc), byref(m1), byref(m2), byref(m3), byref(m4),
+                                         _ptr(loss), _ptr(cd), _ptr(saved_w), _ptr(saved_mean),
+                                         _ptr(ws), ws.numel(), _stream()))
+    return loss, cd, saved_w, saved_mean
+
+
+def helper_bwd(desc, c1, c2, saved_w, saved_mean, cd, g_loss, g_cd):
+    _require_dev(c1, c2, saved_w)
+    lib = load()
+    N, K, S1, S2 = desc.B, desc.K, desc.H, desc.W
+    dev = c1.device
+    g_loss = None if g_loss is None else _dense(g_loss, torch.float32)
+    g_cd = None if g_cd is None else _dense(g_cd, torch.float32)
+    d1 = torch.empty(N, S1, S2, K, dtype=torch.float32, device=dev)
+    d2 = torch.empty(N, S1, S2, K, dtype=torch.float32, device=dev)
+    m1, m2 = _map(c1), _map(c2)
+    with torch.cuda.device(dev):
+        _check(lib.stego_corr_helper_bwd(byref(desc), byref(m1), byref(m2), _ptr(saved_w), _ptr(saved_mean),
+                                         _ptr(cd), _ptr(g_loss), _ptr(g_cd), _ptr(d1), _ptr(d2), None, 0, _stream()))
+    return d1.permute(0, 3, 1, 2), d2.permute(0, 3, 1, 2)

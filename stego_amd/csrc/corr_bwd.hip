@@ -1,0 +1,282 @@
+// Backward of STEGO's ContrastiveCorrelationLoss w.r.t. orig_code / orig_code_pos (gfx950).
+//
+// One workgroup per (pair-set p, image b) tile, same tiling as the forward:
+//   G[hw][ij]  = dL/dcd = g_cd + g_loss * (-(fd_final - shift)) * 1[cmin <= cd <= cmax]   (clamp/mul backward)
+//   dAn = G . Bn          dBn = G^T . An          (the two bmm adjoints; An/Bn = normalised sampled codes)
+//   dA  = (dAn - An <An,dAn>) / ||a||             (F.normalize backward), likewise dB
+//   scatter-add dA/dB through the 4 bilinear taps into d_code (grid_sampler_2d_backward;
+//   negatives land in d_code[perm[b]] = the index_put of orig_code[perm], modules.py:385)
+// GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32).  Scatter uses hardware fp32 atomics into a
+// channels-last gradient buffer (a point's K channels are one contiguous 4*K-byte run).
+//
+// Reference: autograd through src/modules.py:335-347, 369-391.
+#include "corr_common.h"
+
+namespace stego {
+
+constexpr int LDC = 80;    // code tile row stride (K <= 80)
+constexpr int LDG = 130;   // G row stride
+constexpr int SMB_NRM = 0;                         // float nrm[2][128]
+constexpr int SMB_RED = SMB_NRM + 2 * TP * 4;      // float red[64]
+constexpr int SMB_TAPYX = SMB_RED + 64 * 4;        // int4 [256] packed pixel coords
+constexpr int SMB_TAPW = SMB_TAPYX + 256 * 16;     // float4 [256]
+constexpr int SMB_CA = SMB_TAPW + 256 * 16;        // float [128][80]
+constexpr int SMB_CB = SMB_CA + TP * LDC * 4;      // float [128][80]
+constexpr int SMB_G = SMB_CB + TP * LDC * 4;       // float [128][130]; first 4 KB doubles as gather offsets
+constexpr int SMB_TOTAL = SMB_G + TP * LDG * 4;
+static_assert(SMB_TOTAL <= 160 * 1024, "LDS budget");
+
+// normalize-backward + bilinear scatter of one side's gradient held in MFMA 16x16 C/D layout:
+// d[mt][nt][reg] <-> point 32*wave + 16*mt + 4*(lane>>4) + reg, channel 16*nt + (lane&15).
+template <int NT>
+__device__ __forceinline__ void normalize_bwd_scatter(f32x4 (&d)[2][NT], const float* __restrict__ Cn,
+                                                      const float* __restrict__ nrm, const int4* __restrict__ tapyx,
+                                                      const float4* __restrict__ tapw, float* __restrict__ dst_img,
+                                                      int W, int K, int P, int lane, int wave)
+{
+    const int cl = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int pt = 32 * wave + 16 * mt + 4 * rg + reg;
+            float dot = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dot += Cn[pt * LDC + 16 * nt + cl] * d[mt][nt][reg];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+            const float nr = nrm[pt];
+            const bool big = nr > 1e-10f;
+            const float inv = 1.f / fmaxf(nr, 1e-10f);
+            if (pt < P) {
+                const int4 yx = tapyx[pt];
+                const float4 w = tapw[pt];
+                const int pix0 = (yx.x >> 16) * W + (yx.x & 0xffff), pix1 = (yx.y >> 16) * W + (yx.y & 0xffff);
+                const int pix2 = (yx.z >> 16) * W + (yx.z & 0xffff), pix3 = (yx.w >> 16) * W + (yx.w & 0xffff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int ch = 16 * nt + cl;
+                    if (ch < K) {
+                        const float dn = d[mt][nt][reg];
+                        const float dt = big ? (dn - Cn[pt * LDC + ch] * dot) * inv : dn * inv;
+                        if (w.x != 0.f) atomicAdd(dst_img + (size_t)pix0 * K + ch, w.x * dt);
+                        if (w.y != 0.f) atomicAdd(dst_img + (size_t)pix1 * K + ch, w.y * dt);
+                        if (w.z != 0.f) atomicAdd(dst_img + (size_t)pix2 * K + ch, w.z * dt);
+                        if (w.w != 0.f) atomicAdd(dst_img + (size_t)pix3 * K + ch, w.w * dt);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int VC, int NT>
+__global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* nrm = reinterpret_cast<float*>(smem + SMB_NRM);
+    int4* tapyx = reinterpret_cast<int4*>(smem + SMB_TAPYX);
+    float4* tapw = reinterpret_cast<float4*>(smem + SMB_TAPW);
+    float* CA = reinterpret_cast<float*>(smem + SMB_CA);
+    float* CB = reinterpret_cast<float*>(smem + SMB_CB);
+    float* G = reinterpret_cast<float*>(smem + SMB_G);
+    int4* tapo = reinterpret_cast<int4*>(smem + SMB_G);     // gather offsets, dead before G is filled
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = prm.B, P = prm.P, K = prm.K;
+    const int tile = blockIdx.x;
+    const int b = tile % B, p = tile / B;
+    const bool direct = prm.mode == 1;
+
+    const bool usePos = direct || p == 1;
+    const bool sameAB = !direct && p == 0;
+    const MapV mcA = prm.code;
+    MapV mcB;
+    mcB.p = usePos ? prm.code_pos.p : prm.code.p;
+    mcB.sn = usePos ? prm.code_pos.sn : prm.code.sn;
+    mcB.sc = usePos ? prm.code_pos.sc : prm.code.sc;
+    mcB.sh = usePos ? prm.code_pos.sh : prm.code.sh;
+    mcB.sw = usePos ? prm.code_pos.sw : prm.code.sw;
+    const float* coordsB = (!direct && p >= 1) ? prm.coords2 : prm.coords1;
+    float* dstB = usePos ? prm.d_code_pos : prm.d_code;
+    int imgB = b;
+    if (!direct && p >= 2) imgB = (int)prm.perms[(size_t)(p - 2) * B + b];
+
+    {
+        const int side = tid >> 7, q = tid & (TP - 1);
+        const float* cimg = direct ? nullptr
+                                   : (side == 0 ? prm.coords1 + (size_t)b * P * 2 : coordsB + (size_t)b * P * 2);
+        int4 yx; float4 w;
+        tap_for_point(q, P, prm.S, prm.H, prm.W, direct, cimg, yx, w);
+        tapyx[tid] = yx;
+        tapw[tid] = w;
+        tapo[tid] = taps_to_offsets(yx, side == 0 ? mcA.sh : mcB.sh, side == 0 ? mcA.sw : mcB.sw);
+    }
+    __syncthreads();
+
+    // ---- gather raw sampled codes (K <= 80: one 64-wide chunk + one 16-wide chunk), norms
+    {
+        float ssA[TP * (KC / VC) / NTHREADS], ssB[TP * (KC / VC) / NTHREADS];
+#pragma unroll
+        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
+        const float* imgA = mcA.p + (long long)b * mcA.sn;
+        const float* imgBp = mcB.p + (long long)imgB * mcB.sn;
+        gather_chunk<VC, LDC>(imgA, mcA.sc, tapo, tapw, 0, K, 64, P, CA, ssA);
+        gather_chunk<VC, LDC>(imgA, mcA.sc, tapo, tapw, 64, K, 16, P, CA + 64, ssA);
+        if (!sameAB) {
+            gather_chunk<VC, LDC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 0, K, 64, P, CB, ssB);
+            gather_chunk<VC, LDC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 64, K, 16, P, CB + 64, ssB);
+        }
+        publish_norms<VC>(ssA, nrm);
+        if (!sameAB) publish_norms<VC>(ssB, nrm + TP);
+    }
+    __syncthreads();
+    // normalise in place: Cn = raw / max(||raw||, eps)
+    for (int e = tid; e < TP * LDC; e += NTHREADS) {
+        const int r = e / LDC;
+        CA[e] *= 1.f / fmaxf(nrm[r], 1e-10f);
+        if (!sameAB) CB[e] *= 1.f / fmaxf(nrm[TP + r], 1e-10f);
+    }
+    const float* CBn = sameAB ? CA : CB;
+    const float* nrmB = sameAB ? nrm : nrm + TP;
+    __syncthreads();    // tapo (aliased on G) is dead from here
+
+    // ---- G tile
+    {
+        const int P2 = P * P;
+        const float* cdp;
+        const float* gcd = nullptr;
+        float gl_scalar = 0.f;
+        const float* gl_dense = nullptr;
+        const float inv_numel = 1.f / ((float)B * (float)P2);
+        if (direct) {
+            cdp = prm.neg_cd + (size_t)b * P2;
+            if (prm.g_neg_loss) gl_dense = prm.g_neg_loss + (size_t)b * P2;
+            if (prm.g_neg_cd) gcd = prm.g_neg_cd + (size_t)b * P2;
+        } else if (p == 0) {
+            cdp = prm.intra_cd + (size_t)b * P2;
+            gl_scalar = prm.g_intra ? prm.g_intra[0] * inv_numel : 0.f;     // .mean() backward (modules.py:393)
+            if (prm.g_intra_cd) gcd = prm.g_intra_cd + (size_t)b * P2;
+        } else if (p == 1) {
+            cdp = prm.inter_cd + (size_t)b * P2;
+            gl_scalar = prm.g_inter ? prm.g_inter[0] * inv_numel : 0.f;     // (modules.py:395)
+            if (prm.g_inter_cd) gcd = prm.g_inter_cd + (size_t)b * P2;
+        } else {
+            const size_t t = ((size_t)(p - 2) * B + b) * P2;
+            cdp = prm.neg_cd + t;
+            if (prm.g_neg_loss) {
+                if (prm.g_neg_loss_stride) gl_dense = prm.g_neg_loss + t;
+                else gl_scalar = prm.g_neg_loss[0];
+            }
+            if (prm.g_neg_cd) gcd = prm.g_neg_cd + t;
+        }
+        const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
+        const float om = prm.saved_mean[p];
+        const float cmin = prm.cmin, cmax = prm.cmax;
+        for (int e = tid; e < TP * TP; e += NTHREADS) {
+            const int r = e >> 7, c = e & (TP - 1);
+            float g = 0.f;
+            if (r < P && c < P) {
+                const int idx = r * P + c;
+                const float cdv = cdp[idx];
+                const float gl = gl_dense ? gl_dense[idx] : gl_scalar;
+                if (cdv >= cmin && cdv <= cmax) g = -(wp[idx] + om) * gl;
+                if (gcd) g += gcd[idx];
+            }
+            G[r * LDG + c] = g;
+        }
+    }
+    __syncthreads();
+
+    // ---- dAn = G . Bn  and  dBn = G^T . An   on v_mfma_f32_16x16x4_f32
+    // operand lane map: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
+    f32x4 dA[2][NT], dB[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dA[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dB[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    {
+        const int cl = lane & 15, kq = lane >> 4;
+        const int row0 = 32 * wave + cl;
+        for (int kk = 0; kk < TP; kk += 4) {
+            const int k = kk + kq;
+            float ga[2], gt[2], bn[NT], an[NT];
+            ga[0] = G[row0 * LDG + k];                 // G[i][k]
+            ga[1] = G[(row0 + 16) * LDG + k];
+            gt[0] = G[k * LDG + row0];                 // G^T[i][k] = G[k][i]
+            gt[1] = G[k * LDG + row0 + 16];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bn[nt] = CBn[k * LDC + 16 * nt + cl];
+                an[nt] = CA[k * LDC + 16 * nt + cl];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                dA[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], bn[nt], dA[0][nt], 0, 0, 0);
+                dA[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], bn[nt], dA[1][nt], 0, 0, 0);
+                dB[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[0], an[nt], dB[0][nt], 0, 0, 0);
+                dB[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[1], an[nt], dB[1][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalize backward + scatter
+    const size_t img_elems = (size_t)prm.H * prm.W * K;
+    if (sameAB) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dA[mt][nt] += dB[mt][nt];   // c1 is c2: both adjoints hit the same samples
+    }
+    normalize_bwd_scatter<NT>(dA, CA, nrm, tapyx, tapw, prm.d_code + (size_t)b * img_elems, prm.W, K, P, lane, wave);
+    if (!sameAB)
+        normalize_bwd_scatter<NT>(dB, CBn, nrmB, tapyx + TP, tapw + TP, dstB + (size_t)imgB * img_elems, prm.W, K, P,
+                                  lane, wave);
+}
+
+template <int VC>
+static hipError_t launch_bwd_nt(const BwdParams& prm, int nt, dim3 grid, hipStream_t stream)
+{
+#define STEGO_BWD_CASE(N)                                                                                         \
+    case N: {                                                                                                     \
+        static bool done = false;                                                                                 \
+        if (!done) {                                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_kernel<VC, N>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMB_TOTAL);            \
+            if (e != hipSuccess) return e;                                                                        \
+            done = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((corr_bwd_kernel<VC, N>), grid, dim3(NTHREADS), SMB_TOTAL, stream, prm);               \
+        break;                                                                                                    \
+    }
+    switch (nt) {
+        STEGO_BWD_CASE(1)
+        STEGO_BWD_CASE(2)
+        STEGO_BWD_CASE(3)
+        STEGO_BWD_CASE(4)
+        default:
+        STEGO_BWD_CASE(5)
+    }
+#undef STEGO_BWD_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
+{
+    auto ok = [&](const MapV& m, int v) {
+        return m.sc == 1 && prm.K % v == 0 && (m.sn % v) == 0 && (m.sh % v) == 0 && (m.sw % v) == 0 &&
+               (reinterpret_cast<uintptr_t>(m.p) % (4 * v)) == 0;
+    };
+    int vc = 1;
+    if (ok(prm.code, 4) && ok(prm.code_pos, 4)) vc = 4;
+    else if (ok(prm.code, 2) && ok(prm.code_pos, 2)) vc = 2;
+    const int nt = (prm.K + 15) / 16;
+    const dim3 grid(prm.n_sets * prm.B);
+    switch (vc) {
+        case 4: return launch_bwd_nt<4>(prm, nt, grid, stream);
+        case 2: return launch_bwd_nt<2>(prm, nt, grid, stream);
+        default: return launch_bwd_nt<1>(prm, nt, grid, stream);
+    }
+}
+
+}  // namespace stego

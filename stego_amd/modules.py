@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's ``src/modules.py`` hot-path surface.
+
+Same names, argument meaning and return values as the reference so that
+``train_segmentation.py`` is a drop-in:
+
+* ``ContrastiveCorrelationLoss(cfg)`` - ``.forward`` (reference modules.py:349-398) and
+  ``.helper`` (:325-347) run on the hand-written HIP kernels in ``csrc/`` through the C ABI
+  (``include/stego_corr.h``); the RNG draws (coords1, coords2, super_perm x neg_samples) are
+  made here with torch in the reference's order (:366, :367, :383) so loss curves overlap.
+* ``norm`` :275, ``average_norm`` :279, ``tensor_correlation`` :283, ``sample`` :287,
+  ``super_perm`` :291, ``sample_nonzero_locations`` :298 - thin torch-on-device helpers the
+  other reference scripts import by name (they are not on the hot path; the fused kernel
+  does its own sampling/normalisation/contraction).
+
+There is no CPU / pure-PyTorch fallback for the loss: non-HIP tensors raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import capi
+
+
+# ------------------------------------------------------------------ small named helpers
+def norm(t):
+    """reference modules.py:275-276."""
+    return F.normalize(t, dim=1, eps=1e-10)
+
+
+def average_norm(t):
+    """reference modules.py:279-280."""
+    return t / t.square().sum(1, keepdim=True).sqrt().mean()
+
+
+def tensor_correlation(a, b):
+    """reference modules.py:283-284."""
+    return torch.einsum("nchw,ncij->nhwij", a, b)
+
+
+def sample(t: torch.Tensor, coords: torch.Tensor):
+    """reference modules.py:287-288."""
+    return F.grid_sample(t, coords.permute(0, 2, 1, 3), padding_mode='border', align_corners=True)
+
+
+def super_perm(size: int, device: torch.device):
+    """reference modules.py:291-295 (TorchScript there; same draws from the same generator)."""
+    perm = torch.randperm(size, device=device, dtype=torch.long)
+    perm[perm == torch.arange(size, device=device)] += 1
+    return perm % size
+
+
+def sample_nonzero_locations(t, target_size):
+    """reference modules.py:298-311 (salience-guided coords; cfg.use_salience, off by default)."""
+    nonzeros = torch.nonzero(t)
+    coords = torch.zeros(target_size, dtype=nonzeros.dtype, device=nonzeros.device)
+    n = target_size[1] * target_size[2]
+    for i in range(t.shape[0]):
+        selected_nonzeros = nonzeros[nonzeros[:, 0] == i]
+        if selected_nonzeros.shape[0] == 0:
+            selected_coords = torch.randint(t.shape[1], size=(n, 2), device=nonzeros.device)
+        else:
+            selected_coords = selected_nonzeros[torch.randint(len(selected_nonzeros), size=(n,)), 1:]
+        coords[i, :, :, :] = selected_coords.reshape(target_size[1], target_size[2], 2)
+    coords = coords.to(torch.float32) / t.shape[1]
+    coords = coords * 2 - 1
+    return torch.flip(coords, dims=[-1])
+
+
+# ----------------------------------------------------------------------- autograd glue
+_backend = capi      # tests may swap this for an oracle-backed double to exercise host logic on CPU
+
+
+def _precision_of(cfg):
+    name = getattr(cfg, "corr_precision", "f32")
+    if name in ("f32", "fp32", 0):
+        return capi.PREC_F32
+    if name in ("bf16x3", 1):
+        return capi.PREC_BF16X3
+    raise ValueError("unknown corr_precision %r" % (name,))
+
+
+class _CorrLossFunction(torch.autograd.Function):
+    """ContrastiveCorrelationLoss.forward as one op: stego_corr_fwd / stego_corr_bwd."""
+
+    @staticmethod
+    def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
+        need_grad = bool(code.requires_grad or code_pos.requires_grad)
+        (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean) = _backend.corr_fwd(
+            desc, feats.detach(), feats_pos.detach(), code.detach(), code_pos.detach(), coords1, coords2, perms,
+            need_grad)
+        ctx.desc = desc
+        if need_grad:
+            ctx.save_for_backward(code, code_pos, coords1, coords2, perms, saved_w, saved_mean,
+                                  intra_cd, inter_cd, neg_cd)
+        return loss_means[0], intra_cd, loss_means[1], inter_cd, neg_loss, neg_cd
+
+    @staticmethod
+    def backward(ctx, g_intra, g_intra_cd, g_inter, g_inter_cd, g_neg_loss, g_neg_cd):
+        (code, code_pos, coords1, coords2, perms, saved_w, saved_mean, intra_cd, inter_cd, neg_cd) = ctx.saved_tensors
+        d_code, d_code_pos = _backend.corr_bwd(ctx.desc, code.detach(), code_pos.detach(), coords1, coords2, perms,
+                                               saved_w, saved_mean, intra_cd, inter_cd, neg_cd,
+                                               g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd)
+        return (None, None,
+                d_code if ctx.needs_input_grad[2] else None,
+                d_code_pos if ctx.needs_input_grad[3] else None,
+                None, None, None, None)
+
+
+class _HelperFunction(torch.autograd.Function):
+    """ContrastiveCorrelationLoss.helper on pre-sampled tensors: stego_corr_helper_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, c1, c2, desc):
+        need_grad = bool(c1.requires_grad or c2.requires_grad)
+        loss, cd, saved_w, saved_mean = _backend.helper_fwd(desc, f1.detach(), f2.detach(), c1.detach(), c2.detach(),
+                                                            need_grad)
+        ctx.desc = desc
+        if need_grad:
+            ctx.save_for_backward(c1, c2, saved_w, saved_mean, cd)
+        return loss, cd
+
+    @staticmethod
+    def backward(ctx, g_loss, g_cd):
+        c1, c2, saved_w, saved_mean, cd = ctx.saved_tensors
+        d1, d2 = _backend.helper_bwd(ctx.desc, c1.detach(), c2.detach(), saved_w, saved_mean, cd, g_loss, g_cd)
+        return (None, None, d1 if ctx.needs_input_grad[2] else None, d2 if ctx.needs_input_grad[3] else None, None)
+
+
+# --------------------------------------------------------------------------- the loss
+class ContrastiveCorrelationLoss(nn.Module):
+    """Drop-in for the reference class (modules.py:314-398); same cfg keys:
+    feature_samples, neg_samples, pointwise, zero_clamp, stabalize, use_salience,
+    pos_intra_shift, pos_inter_shift, neg_inter_shift.  Optional extra key
+    ``corr_precision`` ('f32' default | 'bf16x3')."""
+
+    def __init__(self, cfg, ):
+        super(ContrastiveCorrelationLoss, self).__init__()
+        self.cfg = cfg
+
+    def standard_scale(self, t):
+        t1 = t - t.mean()
+        t2 = t1 / t1.std()
+        return t2
+
+    def helper(self, f1, f2, c1, c2, shift):
+        """(loss, cd) for already-sampled f1,f2 [N,C,S1,S2] / c1,c2 [N,K,S1,S2] (modules.py:325-347)."""
+        N, C, S1, S2 = f1.shape
+        K = c1.shape[1]
+        desc = capi.make_desc(N, C, K, S1, S2, S2, 0, self.cfg, (shift, shift, shift), _precision_of(self.cfg))
+        return _HelperFunction.apply(f1, f2, c1, c2, desc)
+
+    def draw_coords(self, orig_feats, orig_salience, orig_salience_pos):
+        """The coords1/coords2 draws of modules.py:355-367, same order, same generator."""
+        cfg = self.cfg
+        coord_shape = [orig_feats.shape[0], cfg.feature_samples, cfg.feature_samples, 2]
+        dev = orig_feats.device
+        if cfg.use_salience:
+            coords1_nonzero = sample_nonzero_locations(orig_salience, coord_shape)
+            coords2_nonzero = sample_nonzero_locations(orig_salience_pos, coord_shape)
+            coords1_reg = torch.rand(coord_shape, device=dev) * 2 - 1
+            coords2_reg = torch.rand(coord_shape, device=dev) * 2 - 1
+            mask = (torch.rand(coord_shape[:-1], device=dev) > .1).unsqueeze(-1).to(torch.float32)
+            coords1 = coords1_nonzero * mask + coords1_reg * (1 - mask)
+            coords2 = coords2_nonzero * mask + coords2_reg * (1 - mask)
+        else:
+            coords1 = torch.rand(coord_shape, device=dev) * 2 - 1
+            coords2 = torch.rand(coord_shape, device=dev) * 2 - 1
+        return coords1, coords2
+
+    def forward_explicit(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
+        """forward() with the RNG draws supplied by the caller (perms: int64 [neg_samples, B])."""
+        cfg = self.cfg
+        B, C, H, W = orig_feats.shape
+        K = orig_code.shape[1]
+        S = cfg.feature_samples
+        n_neg = int(perms.shape[0]) if perms is not None else 0
+        if perms is None:
+            perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
+        desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg,
+                              (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), _precision_of(cfg))
+        return _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos,
+                                       coords1, coords2, perms, desc)
+
+    def forward(self,
+                orig_feats: torch.Tensor, orig_feats_pos: torch.Tensor,
+                orig_salience: torch.Tensor, orig_salience_pos: torch.Tensor,
+                orig_code: torch.Tensor, orig_code_pos: torch.Tensor,
+                ):
+        coords1, coords2 = self.draw_coords(orig_feats, orig_salience, orig_salience_pos)
+        B = orig_feats.shape[0]
+        perms = [super_perm(B, orig_feats.device) for _ in range(self.cfg.neg_samples)]     # :382-383
+        perms = torch.stack(perms) if perms else None
+        return self.forward_explicit(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)

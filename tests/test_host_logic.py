@@ -1,0 +1,171 @@
+"""CPU tests of the host layer (stego_amd/modules.py): RNG draw order, argument packing,
+autograd wiring - using an oracle-backed double for the C-ABI backend - plus the C-ABI
+library's load/export/error behaviour (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_backend
+from conftest import ROOT, GoldenCase, assert_close, load_golden
+from oracle import corr_oracle as O
+from stego_amd import capi
+from stego_amd import modules as M
+
+
+@pytest.fixture
+def oracle_backed(monkeypatch):
+    monkeypatch.setattr(M, "_backend", oracle_backend)
+    oracle_backend.calls.clear()
+    return oracle_backend
+
+
+def _cfg(**kw):
+    c = O.CorrCfg()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_rng_draw_order_matches_reference_forward(oracle_backed):
+    """Same seed on the same generator => same coords1, coords2, perm x3 as the reference's
+    forward() (modules.py:366,367,383): outputs must equal the golden reference forward."""
+    g = load_golden("seeded_e2e")
+    cfg = _cfg(feature_samples=5, neg_samples=3)
+    f, fp, c, cp = (torch.from_numpy(g[k]) for k in ("in_feats", "in_feats_pos", "in_code", "in_code_pos"))
+    torch.manual_seed(123)
+    out = M.ContrastiveCorrelationLoss(cfg)(f, fp, None, None, c, cp)
+    names = ("pos_intra_loss", "pos_intra_cd", "pos_inter_loss", "pos_inter_cd", "neg_inter_loss", "neg_inter_cd")
+    for name, o in zip(names, out):
+        assert tuple(o.shape) == tuple(g[name].shape), name
+        assert_close(o.numpy(), g[name], rtol=1e-4, what=name)
+    # and the draws themselves
+    torch.manual_seed(123)
+    loss = M.ContrastiveCorrelationLoss(cfg)
+    c1, c2 = loss.draw_coords(f, None, None)
+    perms = torch.stack([M.super_perm(4, f.device) for _ in range(3)])
+    np.testing.assert_array_equal(c1.numpy(), g["coords1"])
+    np.testing.assert_array_equal(c2.numpy(), g["coords2"])
+    np.testing.assert_array_equal(perms.numpy(), g["perms"])
+
+
+def test_super_perm_known_answer():
+    torch.manual_seed(1)
+    rp = torch.randperm(8)
+    torch.manual_seed(1)
+    sp = M.super_perm(8, torch.device("cpu"))
+    assert np.array_equal(O.super_perm_from_randperm(rp.numpy()), sp.numpy())
+    assert not (sp == torch.arange(8)).any()
+
+
+def test_autograd_wiring_train_weights(oracle_backed):
+    c = GoldenCase("small_default")
+    t = {k: torch.from_numpy(v) for k, v in c.inputs.items()}
+    code = t["code"].clone().requires_grad_(True)
+    code_pos = t["code_pos"].clone().requires_grad_(True)
+    out = M.ContrastiveCorrelationLoss(c.cfg).forward_explicit(
+        t["feats"], t["feats_pos"], code, code_pos, t["coords1"], t["coords2"], torch.from_numpy(c.perms))
+    assert out[0].dim() == 0 and out[2].dim() == 0
+    (0.67 * out[0] + 0.25 * out[2] + 0.63 * out[4].mean()).backward()
+    assert oracle_backend.calls == ["corr_fwd", "corr_bwd"]
+    assert_close(code.grad.numpy(), c.g["d_code_train"], rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(code_pos.grad.numpy(), c.g["d_code_pos_train"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_autograd_wiring_general_upstream(oracle_backed):
+    c = GoldenCase("small_stab")
+    g = c.g
+    t = {k: torch.from_numpy(v) for k, v in c.inputs.items()}
+    code = t["code"].clone().requires_grad_(True)
+    code_pos = t["code_pos"].clone().requires_grad_(True)
+    out = M.ContrastiveCorrelationLoss(c.cfg).forward_explicit(
+        t["feats"], t["feats_pos"], code, code_pos, t["coords1"], t["coords2"], torch.from_numpy(c.perms))
+    u = {k: torch.from_numpy(g[k]) for k in ("u_neg_loss", "u_intra_cd", "u_inter_cd", "u_neg_cd")}
+    total = 1.3 * out[0] - 0.7 * out[2] + (out[4].reshape(-1) * u["u_neg_loss"]).sum() + \
+        (out[1].reshape(-1) * u["u_intra_cd"]).sum() + (out[3].reshape(-1) * u["u_inter_cd"]).sum() + \
+        (out[5].reshape(-1) * u["u_neg_cd"]).sum()
+    total.backward()
+    assert_close(code.grad.numpy(), g["d_code_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_gen")
+    assert_close(code_pos.grad.numpy(), g["d_code_pos_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos_gen")
+
+
+def test_no_grad_inputs_skip_saved_state(oracle_backed):
+    c = GoldenCase("small_noneg")
+    t = {k: torch.from_numpy(v) for k, v in c.inputs.items()}
+    out = M.ContrastiveCorrelationLoss(c.cfg).forward_explicit(
+        t["feats"], t["feats_pos"], t["code"], t["code_pos"], t["coords1"], t["coords2"], None)
+    assert not out[0].requires_grad
+    assert tuple(out[4].shape) == (0, c.S, c.S, c.S, c.S)
+    assert_close(out[0].numpy(), c.g["pos_intra_loss"], rtol=1e-3, atol_frac=1e-2)
+
+
+def test_helper_wiring(oracle_backed):
+    rng = np.random.default_rng(0)
+    f1 = torch.from_numpy(rng.standard_normal((2, 6, 3, 4)).astype(np.float32))
+    f2 = torch.from_numpy(rng.standard_normal((2, 6, 3, 4)).astype(np.float32))
+    c1 = torch.from_numpy(rng.standard_normal((2, 5, 3, 4)).astype(np.float32)).requires_grad_(True)
+    c2 = torch.from_numpy(rng.standard_normal((2, 5, 3, 4)).astype(np.float32)).requires_grad_(True)
+    cfg = _cfg()
+    loss, cd = M.ContrastiveCorrelationLoss(cfg).helper(f1, f2, c1, c2, 0.3)
+    el, ecd, _ = O.helper(f1.numpy().astype(np.float64), f2.numpy().astype(np.float64),
+                          c1.detach().numpy().astype(np.float64), c2.detach().numpy().astype(np.float64), 0.3, cfg)
+    assert tuple(loss.shape) == (2, 3, 4, 3, 4)
+    assert_close(loss.detach().numpy(), el, rtol=1e-4)
+    assert_close(cd.detach().numpy(), ecd, rtol=1e-4)
+    loss.mean().backward()
+    assert c1.grad is not None and c2.grad is not None and torch.isfinite(c1.grad).all()
+
+
+def test_real_backend_refuses_cpu_tensors():
+    """No CPU fallback: the product path must fail loudly off-device."""
+    cfg = _cfg(feature_samples=3, neg_samples=1)
+    f = torch.randn(2, 8, 5, 5)
+    c = torch.randn(2, 4, 5, 5)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        M.ContrastiveCorrelationLoss(cfg).helper(f[:, :, :3, :3], f[:, :, :3, :3], c[:, :, :3, :3], c[:, :, :3, :3], .1)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi._build, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="not built"):
+        capi.load()
+
+
+# ------------------------------------------------------------------ C ABI (no compute)
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "stego_corr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(stego_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    names = _header_functions()
+    assert "stego_corr_fwd" in names and "stego_corr_bwd" in names
+    for n in names:
+        assert hasattr(lib, n), "libstego_corr.so does not export %s" % n
+        assert n in capi.SIGNATURES, "capi.py has no signature for %s" % n
+    assert lib.stego_abi_version() == 1
+
+
+def test_library_validates_before_enqueueing():
+    """Argument errors are detected on the host (safe to call without a GPU)."""
+    lib = capi.load()
+    cfg = _cfg()
+    d = capi.make_desc(4, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46))
+    assert lib.stego_corr_workspace_bytes(ctypes.byref(d)) == 7 * 4 * 4 * 4
+    args_null = [None] * 4 + [None] * 3 + [None] * 7 + [None, 0, None]
+    assert lib.stego_corr_fwd(None, *args_null) == 1                      # STEGO_ERR_NULL
+    assert lib.stego_corr_fwd(ctypes.byref(d), *args_null) == 1
+    d12 = capi.make_desc(4, 384, 70, 28, 28, 12, 5, cfg, (.18, .12, .46))  # S*S = 144 > 128
+    assert lib.stego_corr_fwd(ctypes.byref(d12), *args_null) == 3         # STEGO_ERR_UNSUPPORTED
+    d0 = capi.make_desc(0, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46))
+    assert lib.stego_corr_fwd(ctypes.byref(d0), *args_null) == 2          # STEGO_ERR_SHAPE
+    assert b"unsupported" in lib.stego_error_string(3)
+    assert lib.stego_error_string(0) == b"ok"

@@ -1,0 +1,276 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden vectors and
+the fp64 oracle.  Tolerance (north_star): 1e-3 relative in fp32, written out in
+conftest.assert_close (rtol=1e-3, atol = 1e-4 * mean|expected|).  Needs the MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ALL_CASES, GoldenCase, assert_close
+from oracle import corr_oracle as O
+from stego_amd import capi
+from stego_amd import modules as M
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def _channels_last(t):
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None):
+    """Run the HIP forward (+ backward) on a golden/synthetic case. Returns numpy outputs."""
+    t = {k: _dev(v) for k, v in case_inputs.items()}
+    f, fp, c, cp = t["feats"], t["feats_pos"], t["code"], t["code_pos"]
+    if layout == "cl":
+        f, fp, c, cp = (_channels_last(x) for x in (f, fp, c, cp))
+    c = c.detach().requires_grad_(grad)
+    cp = cp.detach().requires_grad_(grad)
+    perms_t = _dev(perms) if perms is not None and len(perms) else None
+    out = M.ContrastiveCorrelationLoss(cfg).forward_explicit(f, fp, c, cp, t["coords1"], t["coords2"], perms_t)
+    res = dict(out=[o.detach().cpu().numpy() for o in out])
+    if grad:
+        if upstream is None:
+            total = 0.67 * out[0] + 0.25 * out[2]
+            if out[4].numel():
+                total = total + 0.63 * out[4].mean()
+        else:
+            total = upstream(out)
+        total.backward()
+        res["d_code"] = c.grad.cpu().numpy()
+        res["d_code_pos"] = cp.grad.cpu().numpy()
+    torch.cuda.synchronize()
+    return res
+
+
+def test_library_loaded_is_the_in_tree_hip_extension():
+    lib = capi.load()
+    assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
+    assert lib.stego_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "cl"])
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_forward_backward_match_reference_golden(name, layout):
+    c = GoldenCase(name)
+    g = c.g
+    r = _run(c.inputs, c.perms, c.cfg, layout=layout)
+    out = r["out"]
+    scale = float(np.mean(np.abs(g["neg_inter_loss"]))) if c.n_neg else float(np.mean(np.abs(g["pos_inter_cd"])))
+    assert abs(float(out[0]) - float(g["pos_intra_loss"])) <= 1e-3 * scale + 1e-3 * abs(float(g["pos_intra_loss"]))
+    assert abs(float(out[2]) - float(g["pos_inter_loss"])) <= 1e-3 * scale + 1e-3 * abs(float(g["pos_inter_loss"]))
+    assert_close(c.sub(out[1]), g["pos_intra_cd"], what="pos_intra_cd")
+    assert_close(c.sub(out[3]), g["pos_inter_cd"], what="pos_inter_cd")
+    assert_close(c.sub(out[4]), g["neg_inter_loss"], what="neg_inter_loss")
+    assert_close(c.sub(out[5]), g["neg_inter_cd"], what="neg_inter_cd")
+    S = c.S
+    assert out[1].shape == (c.B, S, S, S, S) and out[4].shape == (c.n_neg * c.B, S, S, S, S)
+    # backward vs reference autograd (atomics reorder sums: slightly looser atol)
+    assert_close(c.sub(r["d_code"]), g["d_code_train"], rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(c.sub(r["d_code_pos"]), g["d_code_pos_train"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+    np.testing.assert_allclose(np.linalg.norm(r["d_code"].astype(np.float64)), g["d_code_train_norm"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["small_default", "small_noclamp_stab", "small_stab", "small_dinolike_S11"])
+def test_backward_general_upstream(name):
+    """Upstream gradients on every output (scalars, neg loss tensor, the three cd tensors)."""
+    c = GoldenCase(name)
+    g = c.g
+    u = {k: _dev(g[k]) for k in ("u_neg_loss", "u_intra_cd", "u_inter_cd", "u_neg_cd")}
+
+    def upstream(out):
+        return 1.3 * out[0] - 0.7 * out[2] + (out[4].reshape(-1) * u["u_neg_loss"]).sum() + \
+            (out[1].reshape(-1) * u["u_intra_cd"]).sum() + (out[3].reshape(-1) * u["u_inter_cd"]).sum() + \
+            (out[5].reshape(-1) * u["u_neg_cd"]).sum()
+
+    r = _run(c.inputs, c.perms, c.cfg, upstream=upstream)
+    assert_close(r["d_code"], g["d_code_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_gen")
+    assert_close(r["d_code_pos"], g["d_code_pos_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos_gen")
+
+
+def test_full_size_cfg2_against_fp64_oracle():
+    """BASELINE config 2 (B=32, ViT-S/8 224^2: C=384, 28x28, K=70, S=11, 5 negatives), channels-last."""
+    B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=2024, dino_like=True)
+    cfg = O.CorrCfg()
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg, layout="cl")
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    out = r["out"]
+    assert_close(out[1], ref.pos_intra_cd, what="intra_cd")
+    assert_close(out[3], ref.pos_inter_cd, what="inter_cd")
+    assert_close(out[4], ref.neg_inter_loss, what="neg_loss")
+    assert_close(out[5], ref.neg_inter_cd, what="neg_cd")
+    scale = float(np.abs(ref.neg_inter_loss).mean())
+    assert abs(float(out[0]) - float(ref.pos_intra_loss)) < 1e-3 * scale
+    assert abs(float(out[2]) - float(ref.pos_inter_loss)) < 1e-3 * scale
+    numel = B * S ** 4
+    g_nl = np.full((n_neg * B, S, S, S, S), 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+    # size-independent properties of the path
+    icd = out[1].reshape(B, S * S, S * S)
+    np.testing.assert_allclose(icd, icd.transpose(0, 2, 1), atol=2e-6)           # intra cd is symmetric
+    np.testing.assert_allclose(np.diagonal(icd, axis1=1, axis2=2), 1.0, atol=1e-5)  # unit self-similarity
+    assert np.abs(out[5]).max() <= 1.0 + 1e-5                                     # cosines
+
+
+def test_cfg4_vitb_shape_against_oracle():
+    """BASELINE config 4 shape: ViT-B/8 at 320^2 -> C=768, 40x40 (B=4 keeps the oracle quick)."""
+    B, C, H, W, K, S, n_neg = 4, 768, 40, 40, 70, 11, 5
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=77)
+    cfg = O.CorrCfg()
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg, layout="cl")
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][4], ref.neg_inter_loss, what="neg_loss")
+    assert_close(r["out"][3], ref.pos_inter_cd, what="inter_cd")
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=1, C=8, H=4, W=4, K=4, S=1, n_neg=1),        # single sample point, B=1 (perm = [0])
+    dict(B=2, C=5, H=3, W=9, K=3, S=2, n_neg=3),        # odd channel counts -> scalar gather path
+    dict(B=5, C=130, H=7, W=6, K=66, S=7, n_neg=2),     # C, K straddle the 64-wide chunk
+    dict(B=3, C=64, H=1, W=1, K=80, S=3, n_neg=1),      # 1x1 map (every tap clamps), K at the bwd limit
+    dict(B=2, C=16, H=5, W=5, K=2, S=11, n_neg=0),      # no negatives
+])
+def test_edge_shapes(shape):
+    d = O.synth_inputs(seed=5, **shape)
+    cfg = O.CorrCfg(feature_samples=shape["S"], neg_samples=shape["n_neg"])
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][1], ref.pos_intra_cd, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, what="neg_loss")
+    numel = shape["B"] * shape["S"] ** 4
+    g_nl = None
+    if shape["n_neg"]:
+        g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (shape["n_neg"] * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_border_coords_zero_vectors_and_duplicate_perm():
+    """coords outside [-1,1] (border clip), exactly +-1, all-zero feature/code vectors (eps branch
+    of normalize), and a perm with duplicates (super_perm can produce them)."""
+    B, C, H, W, K, S, n_neg = 4, 32, 6, 6, 8, 5, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=9)
+    rng = np.random.default_rng(1)
+    d["coords1"] = (rng.random((B, S, S, 2)) * 2.6 - 1.3).astype(np.float32)
+    d["coords2"][0, 0, 0] = [1.0, 1.0]
+    d["coords2"][0, 0, 1] = [-1.0, 1.0]
+    d["coords2"][0, 1, 0] = [1.0, -1.0]
+    d["feats"][1] = 0.0
+    d["code_pos"][2] = 0.0
+    d["perms"] = np.array([[1, 1, 3, 0], [2, 0, 0, 1]], dtype=np.int64)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    for i, name in ((1, "pos_intra_cd"), (3, "pos_inter_cd"), (4, "neg_inter_loss"), (5, "neg_inter_cd")):
+        assert np.isfinite(r["out"][i]).all(), name
+        assert_close(r["out"][i], getattr(ref, name), what=name)
+    numel = B * S ** 4
+    g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert np.isfinite(r["d_code"]).all() and np.isfinite(r["d_code_pos"]).all()
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    # code_pos[2] == 0 puts its samples on the eps branch (grad = g/eps, huge but finite): compare the rest
+    keep = [0, 1, 3]
+    assert_close(r["d_code_pos"][keep], dcp[keep], rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_helper_matches_oracle_and_reference_semantics():
+    """ContrastiveCorrelationLoss.helper on pre-sampled tensors (modules.py:325-347), S1 != S2."""
+    rng = np.random.default_rng(3)
+    N, C, K, S1, S2 = 3, 48, 10, 5, 7
+    f1, f2 = (rng.standard_normal((N, C, S1, S2)).astype(np.float32) for _ in range(2))
+    c1, c2 = (rng.standard_normal((N, K, S1, S2)).astype(np.float32) for _ in range(2))
+    for kw in (dict(), dict(pointwise=False), dict(zero_clamp=False, stabalize=True)):
+        cfg = O.CorrCfg(**kw)
+        tc1 = _dev(c1).requires_grad_(True)
+        tc2 = _dev(c2).requires_grad_(True)
+        loss, cd = M.ContrastiveCorrelationLoss(cfg).helper(_dev(f1), _dev(f2), tc1, tc2, 0.31)
+        el, ecd, efd = O.helper(f1.astype(np.float64), f2.astype(np.float64), c1.astype(np.float64),
+                                c2.astype(np.float64), 0.31, cfg)
+        assert tuple(loss.shape) == (N, S1, S2, S1, S2)
+        assert_close(loss.detach().cpu().numpy(), el, what="helper loss %s" % kw)
+        assert_close(cd.detach().cpu().numpy(), ecd, what="helper cd %s" % kw)
+        u = rng.standard_normal(el.shape) / el.size
+        v = rng.standard_normal(el.shape) / el.size
+        ((loss * _dev(u.astype(np.float32))).sum() + (cd * _dev(v.astype(np.float32))).sum()).backward()
+        ga, gb = O._helper_bwd_codes(c1.astype(np.float64), c2.astype(np.float64), efd, ecd, 0.31, cfg, u, v)
+        assert_close(tc1.grad.cpu().numpy(), ga, rtol=1e-3, atol_frac=1e-3, what="helper d_c1 %s" % kw)
+        assert_close(tc2.grad.cpu().numpy(), gb, rtol=1e-3, atol_frac=1e-3, what="helper d_c2 %s" % kw)
+
+
+def test_forward_is_deterministic_and_batch_equivariant():
+    B, C, H, W, K, S, n_neg = 8, 64, 10, 10, 12, 6, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=21)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    a = _run(inputs, d["perms"], cfg, grad=False)["out"]
+    b = _run(inputs, d["perms"], cfg, grad=False)["out"]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)            # no atomics in the forward: bitwise repeatable
+    # relabelling the batch permutes the per-image outputs (reductions are per image except old_mean)
+    sigma = np.array([3, 0, 7, 1, 6, 2, 5, 4])
+    inv = np.argsort(sigma)
+    inputs2 = {k: v[sigma] for k, v in inputs.items()}
+    perms2 = inv[d["perms"][:, sigma]]
+    c = _run(inputs2, perms2, cfg, grad=False)["out"]
+    np.testing.assert_allclose(c[1], a[1][sigma], atol=1e-6)
+    np.testing.assert_allclose(c[5].reshape(n_neg, B, -1), a[5].reshape(n_neg, B, -1)[:, sigma], atol=1e-6)
+    np.testing.assert_allclose(c[4].reshape(n_neg, B, -1), a[4].reshape(n_neg, B, -1)[:, sigma], atol=2e-6)
+
+
+def test_backward_is_linear_in_upstream():
+    B, C, H, W, K, S, n_neg = 4, 32, 8, 8, 16, 5, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=33)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    g1 = _run(inputs, d["perms"], cfg, upstream=lambda o: o[0])
+    g2 = _run(inputs, d["perms"], cfg, upstream=lambda o: o[2] + o[4].sum())
+    g3 = _run(inputs, d["perms"], cfg, upstream=lambda o: 2.0 * o[0] - 3.0 * (o[2] + o[4].sum()))
+    np.testing.assert_allclose(g3["d_code"], 2.0 * g1["d_code"] - 3.0 * g2["d_code"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(g3["d_code_pos"], 2.0 * g1["d_code_pos"] - 3.0 * g2["d_code_pos"], rtol=1e-4, atol=1e-7)
+
+
+def test_on_device_rng_path_equals_explicit_draws():
+    """forward() draws coords/perms on the device generator in the reference's order; replaying the
+    same seed by hand and calling forward_explicit must give identical outputs."""
+    B, C, H, W, K = 6, 32, 8, 8, 10
+    cfg = O.CorrCfg(feature_samples=4, neg_samples=3)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    f = torch.randn(B, C, H, W, device=DEV, generator=g)
+    fp = torch.randn(B, C, H, W, device=DEV, generator=g)
+    c = torch.randn(B, K, H, W, device=DEV, generator=g)
+    cp = torch.randn(B, K, H, W, device=DEV, generator=g)
+    loss = M.ContrastiveCorrelationLoss(cfg)
+    torch.manual_seed(99)
+    a = loss(f, fp, None, None, c, cp)
+    torch.manual_seed(99)
+    coords1 = torch.rand(B, 4, 4, 2, device=DEV) * 2 - 1
+    coords2 = torch.rand(B, 4, 4, 2, device=DEV) * 2 - 1
+    perms = torch.stack([M.super_perm(B, f.device) for _ in range(3)])
+    b = loss.forward_explicit(f, fp, c, cp, coords1, coords2, perms)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert not (perms == torch.arange(B, device=DEV)).any()
+
+
+def test_unsupported_configs_fail_loudly():
+    cfg = O.CorrCfg(feature_samples=12, neg_samples=1)      # 144 sample points > 128
+    f = torch.randn(2, 16, 8, 8, device=DEV)
+    c = torch.randn(2, 4, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
