@@ -1,13 +1,14 @@
 // extern "C" boundary of libstego_corr.so (declared in include/stego_corr.h).
 // Host-side validation + parameter packing only; all arithmetic is in the HIP kernels.
+#include <cstdlib>
 #include <limits>
 
 #include "../../include/stego_corr.h"
 #include "corr_common.h"
 
 namespace stego {
-hipError_t launch_corr_fwd(const CorrParams& prm, hipStream_t stream);
-hipError_t launch_corr_fwd_main(const CorrParams& prm, hipStream_t stream);
+hipError_t launch_corr_fwd(const CorrParams& prm, int precision, int variant, hipStream_t stream);
+hipError_t launch_corr_fwd_main(const CorrParams& prm, int precision, int variant, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream);
 }  // namespace stego
@@ -48,13 +49,21 @@ int check_desc(const StegoCorrDesc* d, bool helper)
         if (d->S * d->S > TP) return STEGO_ERR_UNSUPPORTED;
         if (d->n_neg + 2 > 256) return STEGO_ERR_UNSUPPORTED;
     }
-    if (d->precision != STEGO_PREC_F32) return STEGO_ERR_UNSUPPORTED;
+    if (d->precision != STEGO_PREC_F32 && d->precision != STEGO_PREC_BF16X3) return STEGO_ERR_UNSUPPORTED;
     return STEGO_OK;
 }
 
 size_t ws_bytes(const StegoCorrDesc* d) { return (size_t)(2 + (d->n_neg > 0 ? d->n_neg : 0)) * d->B * 4 * sizeof(float); }
 
 int hip_rc(hipError_t e) { return e == hipSuccess ? STEGO_OK : STEGO_ERR_HIP + (int)e; }
+
+// Measurement knobs (read per call so a bench can flip them): STEGO_DEBUG = ablation bit mask
+// (see CorrParams::debug / BwdParams::debug), STEGO_FWD_VARIANT = 0 simple kernel, 1 warp-specialised.
+int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
 
 }  // namespace
 
@@ -110,6 +119,7 @@ static int pack_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMa
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;                                   // modules.py:337-340
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();      // modules.py:342-345
     prm.shift[0] = d->pos_intra_shift; prm.shift[1] = d->pos_inter_shift; prm.shift[2] = d->neg_inter_shift;
+    prm.debug = env_int("STEGO_DEBUG", 0);
     *out = prm;
     return STEGO_OK;
 }
@@ -124,7 +134,7 @@ int stego_corr_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap
     int rc = pack_fwd(d, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
                       pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, workspace, workspace_bytes, &prm);
     if (rc) return rc;
-    return hip_rc(launch_corr_fwd(prm, static_cast<hipStream_t>(stream)));
+    return hip_rc(launch_corr_fwd(prm, d->precision, env_int("STEGO_FWD_VARIANT", 1), static_cast<hipStream_t>(stream)));
 }
 
 int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos,
@@ -148,7 +158,7 @@ int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const 
     double tm = 0.0, tf = 0.0;
     for (int i = 0; i < iters && e == hipSuccess; ++i) {
         hipEventRecord(e0, s);
-        e = launch_corr_fwd_main(prm, s);
+        e = launch_corr_fwd_main(prm, d->precision, env_int("STEGO_FWD_VARIANT", 1), s);
         hipEventRecord(e1, s);
         if (e == hipSuccess) e = launch_corr_finalize(prm, s);
         hipEventRecord(e2, s);
@@ -191,6 +201,7 @@ int stego_corr_bwd(const StegoCorrDesc* d, const StegoMap* code, const StegoMap*
     prm.d_code = d_code; prm.d_code_pos = d_code_pos;
     prm.B = d->B; prm.K = d->K; prm.H = d->H; prm.W = d->W; prm.S = d->S; prm.P = d->S * d->S;
     prm.n_neg = d->n_neg; prm.n_sets = 2 + d->n_neg; prm.mode = 0;
+    prm.debug = env_int("STEGO_DEBUG_BWD", 0);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -223,7 +234,8 @@ int stego_corr_helper_fwd(const StegoCorrDesc* d, const StegoMap* f1, const Steg
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
     prm.shift[0] = prm.shift[1] = prm.shift[2] = d->pos_intra_shift;
-    return hip_rc(launch_corr_fwd(prm, static_cast<hipStream_t>(stream)));
+    prm.debug = env_int("STEGO_DEBUG", 0);
+    return hip_rc(launch_corr_fwd(prm, d->precision, env_int("STEGO_FWD_VARIANT", 1), static_cast<hipStream_t>(stream)));
 }
 
 int stego_corr_helper_bwd(const StegoCorrDesc* d, const StegoMap* c1, const StegoMap* c2, const float* saved_w,

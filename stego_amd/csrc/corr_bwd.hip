@@ -121,14 +121,15 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
         for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
         const float* imgA = mcA.p + (long long)b * mcA.sn;
         const float* imgBp = mcB.p + (long long)imgB * mcB.sn;
-        gather_chunk<VC, LDC>(imgA, mcA.sc, tapo, tapw, 0, K, 64, P, CA, ssA);
-        gather_chunk<VC, LDC>(imgA, mcA.sc, tapo, tapw, 64, K, 16, P, CA + 64, ssA);
+        constexpr int BC = VC == 1 ? 8 : 4;
+        gather_chunk<VC, LDC, PREC_F32, BC>(imgA, mcA.sc, tapo, tapw, 0, K, 64, CA, ssA, tid);
+        gather_chunk<VC, LDC, PREC_F32, BC>(imgA, mcA.sc, tapo, tapw, 64, K, 16, CA + 64, ssA, tid);
         if (!sameAB) {
-            gather_chunk<VC, LDC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 0, K, 64, P, CB, ssB);
-            gather_chunk<VC, LDC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 64, K, 16, P, CB + 64, ssB);
+            gather_chunk<VC, LDC, PREC_F32, BC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 0, K, 64, CB, ssB, tid);
+            gather_chunk<VC, LDC, PREC_F32, BC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 64, K, 16, CB + 64, ssB, tid);
         }
-        publish_norms<VC>(ssA, nrm);
-        if (!sameAB) publish_norms<VC>(ssB, nrm + TP);
+        publish_norms<VC>(ssA, nrm, tid);
+        if (!sameAB) publish_norms<VC>(ssB, nrm + TP, tid);
     }
     __syncthreads();
     // normalise in place: Cn = raw / max(||raw||, eps)
@@ -141,49 +142,59 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
     const float* nrmB = sameAB ? nrm : nrm + TP;
     __syncthreads();    // tapo (aliased on G) is dead from here
 
-    // ---- G tile
+    // ---- G tile: row-wise, branch-free, 8 loads x up to 4 arrays in flight per lane.
+    // Upstreams are folded into (pointer, index multiplier, scale) triples so that absent / broadcast
+    // gradients need no branches: g = -(w + old_mean) * gl * 1[cmin<=cd<=cmax] + gc.
     {
         const int P2 = P * P;
-        const float* cdp;
-        const float* gcd = nullptr;
-        float gl_scalar = 0.f;
-        const float* gl_dense = nullptr;
-        const float inv_numel = 1.f / ((float)B * (float)P2);
-        if (direct) {
-            cdp = prm.neg_cd + (size_t)b * P2;
-            if (prm.g_neg_loss) gl_dense = prm.g_neg_loss + (size_t)b * P2;
-            if (prm.g_neg_cd) gcd = prm.g_neg_cd + (size_t)b * P2;
-        } else if (p == 0) {
-            cdp = prm.intra_cd + (size_t)b * P2;
-            gl_scalar = prm.g_intra ? prm.g_intra[0] * inv_numel : 0.f;     // .mean() backward (modules.py:393)
-            if (prm.g_intra_cd) gcd = prm.g_intra_cd + (size_t)b * P2;
-        } else if (p == 1) {
-            cdp = prm.inter_cd + (size_t)b * P2;
-            gl_scalar = prm.g_inter ? prm.g_inter[0] * inv_numel : 0.f;     // (modules.py:395)
-            if (prm.g_inter_cd) gcd = prm.g_inter_cd + (size_t)b * P2;
-        } else {
-            const size_t t = ((size_t)(p - 2) * B + b) * P2;
-            cdp = prm.neg_cd + t;
-            if (prm.g_neg_loss) {
-                if (prm.g_neg_loss_stride) gl_dense = prm.g_neg_loss + t;
-                else gl_scalar = prm.g_neg_loss[0];
-            }
-            if (prm.g_neg_cd) gcd = prm.g_neg_cd + t;
-        }
+        const size_t t0 = direct ? (size_t)b * P2 : (p < 2 ? (size_t)b * P2 : ((size_t)(p - 2) * B + b) * P2);
         const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
+        const float* cdp = direct ? prm.neg_cd + t0 : (p == 0 ? prm.intra_cd + t0 : (p == 1 ? prm.inter_cd + t0 : prm.neg_cd + t0));
+        const float inv_numel = 1.f / ((float)B * (float)P2);
+        const float* glp = wp;      // dummy when there is no upstream (scale 0)
+        int gl_mul = 0;
+        float gl_scale = 0.f;
+        if (direct || p >= 2) {
+            if (prm.g_neg_loss) {
+                const bool dense = direct || prm.g_neg_loss_stride != 0;
+                glp = dense ? prm.g_neg_loss + t0 : prm.g_neg_loss;
+                gl_mul = dense ? 1 : 0;
+                gl_scale = 1.f;
+            }
+        } else {
+            const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
+            if (gs) { glp = gs; gl_scale = inv_numel; }
+        }
+        const float* gcd = direct ? prm.g_neg_cd : (p == 0 ? prm.g_intra_cd : (p == 1 ? prm.g_inter_cd : prm.g_neg_cd));
+        const float gc_scale = gcd ? 1.f : 0.f;
+        const float* gcp = gcd ? gcd + t0 : wp;
         const float om = prm.saved_mean[p];
         const float cmin = prm.cmin, cmax = prm.cmax;
-        for (int e = tid; e < TP * TP; e += NTHREADS) {
-            const int r = e >> 7, c = e & (TP - 1);
-            float g = 0.f;
-            if (r < P && c < P) {
-                const int idx = r * P + c;
-                const float cdv = cdp[idx];
-                const float gl = gl_dense ? gl_dense[idx] : gl_scalar;
-                if (cdv >= cmin && cdv <= cmax) g = -(wp[idx] + om) * gl;
-                if (gcd) g += gcd[idx];
-            }
-            G[r * LDG + c] = g;
+        constexpr int RB = 4;
+        for (int i0 = 0; i0 < TP / 4; i0 += RB) {
+            float cdv[RB][2], wv[RB][2], glv[RB][2], gcv[RB][2];
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
+                    const int idx = min(r, P - 1) * P + min(c, P - 1);
+                    if (prm.debug & 4) { cdv[j][h] = 0.5f; wv[j][h] = 0.1f; glv[j][h] = 1.f; gcv[j][h] = 0.f; continue; }
+                    cdv[j][h] = cdp[idx];
+                    wv[j][h] = wp[idx];
+                    glv[j][h] = glp[idx * gl_mul];
+                    gcv[j][h] = gcp[idx];
+                }
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
+                    const bool pass = cdv[j][h] >= cmin && cdv[j][h] <= cmax;
+                    float g = pass ? -(wv[j][h] + om) * (glv[j][h] * gl_scale) : 0.f;
+                    g += gcv[j][h] * gc_scale;
+                    G[r * LDG + c] = (r < P && c < P) ? g : 0.f;
+                }
         }
     }
     __syncthreads();
@@ -198,7 +209,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
     {
         const int cl = lane & 15, kq = lane >> 4;
         const int row0 = 32 * wave + cl;
-        for (int kk = 0; kk < TP; kk += 4) {
+        for (int kk = 0; kk < ((prm.debug & 1) ? 0 : TP); kk += 4) {
             const int k = kk + kq;
             float ga[2], gt[2], bn[NT], an[NT];
             ga[0] = G[row0 * LDG + k];                 // G[i][k]
@@ -227,6 +238,15 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dA[mt][nt] += dB[mt][nt];   // c1 is c2: both adjoints hit the same samples
+    }
+    if (prm.debug & 2) {       // measurement ablation: keep the GEMM results alive, skip the scatter
+        float keep = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) keep += dA[mt][nt][0] + dB[mt][nt][1];
+        if (keep == 123.456f) prm.d_code[0] = keep;
+        return;
     }
     normalize_bwd_scatter<NT>(dA, CA, nrm, tapyx, tapw, prm.d_code + (size_t)b * img_elems, prm.W, K, P, lane, wave);
     if (!sameAB)

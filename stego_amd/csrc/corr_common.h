@@ -8,12 +8,18 @@ namespace stego {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TP = 128;        // sample points per side, padded (S*S <= 128)
-constexpr int NTHREADS = 256;  // 4 wave64 per workgroup, one per SIMD
+constexpr int NTHREADS = 256;  // 4 wave64 (the gather team size everywhere)
 constexpr int KC = 64;         // channels per staged chunk
-constexpr int LDA = KC + 4;    // stage row stride in floats: 272 B rows, conflict-free ds_read_b128
+constexpr int LDA = KC + 4;    // f32 stage row stride in floats: 272 B rows, conflict-free ds_read_b128
+constexpr int LDH = KC + 8;    // bf16 stage row stride in elements: 144 B rows, conflict-free ds_read_b128
 constexpr int LDT = 129;       // epilogue tile row stride (odd -> conflict-free column walks)
+
+enum { PREC_F32 = 0, PREC_BF16X3 = 1 };
 
 // float32 [N,C,H,W] view; strides in elements. Per-image offsets are < 2^31 (host-checked).
 struct MapV {
@@ -38,6 +44,7 @@ struct CorrParams {
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int mode;                                  // 0 = forward() semantics, 1 = helper() on pre-sampled maps
     int pointwise;
+    int debug;                                 // measurement ablations (STEGO_DEBUG env): 1 skip MFMA, 2 skip gather
     float cmin, cmax;
     float shift[3];
 };
@@ -63,6 +70,7 @@ struct BwdParams {
     int g_neg_loss_stride;                     // 1 dense, 0 broadcast scalar
     int B, K, H, W, S, P, n_neg, n_sets;
     int mode;
+    int debug;                                 // 1 skip MFMA, 2 skip scatter, 4 skip G fill
     float cmin, cmax;
 };
 
@@ -93,15 +101,8 @@ __device__ __forceinline__ int4 taps_to_offsets(const int4 yx, int sh, int sw)
                      (yx.z >> 16) * sh + (yx.z & 0xffff) * sw, (yx.w >> 16) * sh + (yx.w & 0xffff) * sw);
 }
 
-// Per-workgroup description of the two sides of a tile.
-struct SideSel {
-    const MapV* mf;      // feature map
-    const MapV* mc;      // code map
-    const float* coords; // [B][S][S][2] or null (direct)
-    int img;
-};
-
-// Build tap tables for the 2 x 128 points of a tile.  tid<128: A point tid; else B point tid-128.
+// Tap table entry of one sample point.  Padding points (q >= P) get offset 0 / weight 0: their
+// loads are harmless re-reads of pixel (0,0) and they only ever feed padded rows/cols.
 // forward mode: point q=(h,w) samples coords[b][w][h]  (sample() permutes the grid, modules.py:288)
 // direct mode : point q=(h,w) IS pixel (h,w) of an already-sampled [N,C,S1,S2] map.
 __device__ __forceinline__ void tap_for_point(int q, int P, int S, int H, int W, bool direct,
@@ -122,78 +123,119 @@ __device__ __forceinline__ void tap_for_point(int q, int P, int S, int H, int W,
     }
 }
 
-// Gather one chunk of channels [c0, c0+ncols) of 128 sampled points into an LDS tile
-// dst[point][col] (row stride LD floats), blending the 4 bilinear taps on the fly and
-// accumulating each point's sum of squares (for the L2 norm) in ss[].
-// V = channels per lane-load (4/2 need channel stride 1 and 16/8-byte aligned pixels; 1 is generic).
-// Thread mapping: SLOTS=KC/V lanes cover one point's chunk -> one contiguous KC*4-byte
-// read per tap per point; a wave covers 64/SLOTS points.
-template <int V, int LD>
-__device__ __forceinline__ void gather_chunk(const float* __restrict__ img, int sc, const int4* __restrict__ tapo,
-                                             const float4* __restrict__ tapw, int c0, int Ctot, int ncols, int P,
-                                             float* __restrict__ dst, float (&ss)[TP * (KC / V) / NTHREADS])
+template <int V> struct VecT;
+template <> struct VecT<4> { typedef f32x4 type; };
+template <> struct VecT<2> { typedef f32x2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+// fp32 -> (hi, lo) bf16 split, both round-to-nearest-even (v_cvt_pk_bf16_f32):  x ~= hi + lo with
+// |x - hi - lo| <= 2^-16 |x|.  Returns the two packed dwords for a pair of values.
+__device__ __forceinline__ void split_bf16_pair(float x, float y, unsigned& hi, unsigned& lo)
 {
+    const bf16x2 h = __builtin_convertvector(f32x2{x, y}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float hx = __builtin_bit_cast(float, hi << 16), hy = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf16x2 l = __builtin_convertvector(f32x2{x - hx, y - hy}, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Gather one chunk of channels [c0, c0+ncols) of 128 sampled points into an LDS tile, blending
+// the 4 bilinear taps on the fly and accumulating each point's sum of squares (for the L2 norm).
+//   PREC_F32   : dst is float  [128][LD]          (LD in floats)
+//   PREC_BF16X3: dst is bf16 hi[128][LD] followed by lo[128][LD] (LD in bf16 elements; lo at +128*LD)
+// V = channels per lane-load (4/2 need channel stride 1 and 16/8-byte aligned pixels; 1 is generic).
+// Thread mapping (team of 256 threads, index t): SLOTS=KC/V lanes cover one point's chunk -> one
+// contiguous KC*4-byte read per tap per point.  The loop is branch-free and loads are issued
+// BATCH items (4*BATCH loads) at a time so that many loads are in flight per lane.
+template <int V, int LD, int PREC, int BATCH>
+__device__ __forceinline__ void gather_chunk(const float* __restrict__ img, int sc, const int4* __restrict__ tapo,
+                                             const float4* __restrict__ tapw, int c0, int Ctot, int ncols,
+                                             void* __restrict__ dst_, float (&ss)[TP * (KC / V) / NTHREADS], int t)
+{
+    typedef typename VecT<V>::type vec;
     constexpr int SLOTS = KC / V;
     constexpr int ITEMS = TP * SLOTS / NTHREADS;
     constexpr int PPI = NTHREADS / SLOTS;
-    const int tid = threadIdx.x;
-    const int slot = tid % SLOTS, prow = tid / SLOTS;
+    static_assert(ITEMS % BATCH == 0, "batch must divide the item count");
+    const int slot = t % SLOTS, prow = t / SLOTS;
     const int col = slot * V;
-    const int ch = c0 + col;
     if (col >= ncols) return;
+    const int ch = c0 + col;
+    const bool chok = ch < Ctot;                       // beyond the last channel: zero fill
+    const float* base = img + (long long)(chok ? ch : 0) * sc;
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int q = it * PPI + prow;
-        float v[V];
+    for (int it0 = 0; it0 < ITEMS; it0 += BATCH) {
+        int4 o[BATCH];
+        float4 w[BATCH];
+        vec tv[BATCH][4];
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = 0.f;
-        if (q < P && ch < Ctot) {
-            const int4 o = tapo[q];
-            const float4 w = tapw[q];
-            const float* base = img + (long long)ch * sc;
-            if constexpr (V == 4) {
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(base + o.x);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(base + o.y);
-                const f32x4 t2 = *reinterpret_cast<const f32x4*>(base + o.z);
-                const f32x4 t3 = *reinterpret_cast<const f32x4*>(base + o.w);
+        for (int j = 0; j < BATCH; ++j) {
+            const int q = (it0 + j) * PPI + prow;
+            o[j] = tapo[q];
+            w[j] = tapw[q];
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = w.x * t0[e] + w.y * t1[e] + w.z * t2[e] + w.w * t3[e];
-            } else if constexpr (V == 2) {
-                const f32x2 t0 = *reinterpret_cast<const f32x2*>(base + o.x);
-                const f32x2 t1 = *reinterpret_cast<const f32x2*>(base + o.y);
-                const f32x2 t2 = *reinterpret_cast<const f32x2*>(base + o.z);
-                const f32x2 t3 = *reinterpret_cast<const f32x2*>(base + o.w);
+        for (int j = 0; j < BATCH; ++j) {
+            tv[j][0] = *reinterpret_cast<const vec*>(base + o[j].x);
+            tv[j][1] = *reinterpret_cast<const vec*>(base + o[j].y);
+            tv[j][2] = *reinterpret_cast<const vec*>(base + o[j].z);
+            tv[j][3] = *reinterpret_cast<const vec*>(base + o[j].w);
+        }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) v[e] = w.x * t0[e] + w.y * t1[e] + w.z * t2[e] + w.w * t3[e];
-            } else {
-                v[0] = w.x * base[o.x] + w.y * base[o.y] + w.z * base[o.z] + w.w * base[o.w];
-            }
+        for (int j = 0; j < BATCH; ++j) {
+            const int q = (it0 + j) * PPI + prow;
+            float v[V];
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < V; ++e) s += v[e] * v[e];
-            ss[it] += s;
-        }
-        float* d = dst + q * LD + col;
-        if constexpr (V == 4) {
-            *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-        } else if constexpr (V == 2) {
-            *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
-        } else {
-            d[0] = v[0];
+            for (int e = 0; e < V; ++e) {
+                float t0, t1, t2, t3;
+                if constexpr (V == 1) { t0 = tv[j][0]; t1 = tv[j][1]; t2 = tv[j][2]; t3 = tv[j][3]; }
+                else { t0 = tv[j][0][e]; t1 = tv[j][1][e]; t2 = tv[j][2][e]; t3 = tv[j][3][e]; }
+                float r = w[j].x * t0 + w[j].y * t1 + w[j].z * t2 + w[j].w * t3;
+                r = chok ? r : 0.f;
+                v[e] = r;
+                s += r * r;
+            }
+            ss[it0 + j] += s;
+            if constexpr (PREC == PREC_F32) {
+                float* d = static_cast<float*>(dst_) + q * LD + col;
+                if constexpr (V == 4) *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                else if constexpr (V == 2) *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+                else d[0] = v[0];
+            } else {
+                __bf16* dh = static_cast<__bf16*>(dst_) + q * LD + col;
+                __bf16* dl = dh + TP * LD;
+                if constexpr (V == 4) {
+                    unsigned h0, l0, h1, l1;
+                    split_bf16_pair(v[0], v[1], h0, l0);
+                    split_bf16_pair(v[2], v[3], h1, l1);
+                    *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(dl) = u32x2{l0, l1};
+                } else if constexpr (V == 2) {
+                    unsigned h0, l0;
+                    split_bf16_pair(v[0], v[1], h0, l0);
+                    *reinterpret_cast<unsigned*>(dh) = h0;
+                    *reinterpret_cast<unsigned*>(dl) = l0;
+                } else {
+                    unsigned h0, l0;
+                    split_bf16_pair(v[0], 0.f, h0, l0);
+                    *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h0 & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(dl) = (unsigned short)(l0 & 0xffffu);
+                }
+            }
         }
     }
 }
 
 // Reduce the per-thread sum-of-squares partials over the SLOTS lanes that share a point and
-// publish nrm (=||t||) for the points this thread group owns.
+// publish nrm (=||t||) for the points this thread group owns. t = index in the 256-thread team.
 template <int V>
-__device__ __forceinline__ void publish_norms(float (&ss)[TP * (KC / V) / NTHREADS], float* __restrict__ nrm_out)
+__device__ __forceinline__ void publish_norms(float (&ss)[TP * (KC / V) / NTHREADS], float* __restrict__ nrm_out, int t)
 {
     constexpr int SLOTS = KC / V;
     constexpr int ITEMS = TP * SLOTS / NTHREADS;
     constexpr int PPI = NTHREADS / SLOTS;
-    const int tid = threadIdx.x;
-    const int slot = tid % SLOTS, prow = tid / SLOTS;
+    const int slot = t % SLOTS, prow = t / SLOTS;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         float s = ss[it];
@@ -203,14 +245,19 @@ __device__ __forceinline__ void publish_norms(float (&ss)[TP * (KC / V) / NTHREA
     }
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red /*>=4 floats*/)
+// Sum over the whole workgroup (NW waves); red needs >= NW floats.  Two barriers inside.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
 }
 
 }  // namespace stego

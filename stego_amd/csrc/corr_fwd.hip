@@ -2,22 +2,32 @@
 //
 // One workgroup = one (pair-set p, image b) tile:  A side = image b sampled at coords1[b],
 // B side = {same | feats_pos/code_pos[b] @ coords2[b] | feats/code[perm[b]] @ coords2[b]}.
-// Per tile:  bilinear gather (channels-last: one contiguous KC*4 B read per tap) -> LDS ->
-// fp32 MFMA 32x32x2 for fd = A_f.B_f^T (contraction C) and cd = A_c.B_c^T (contraction K)
-// on RAW sampled values; the L2 normalisation is applied in the epilogue as row/col scales
+// Per tile:  bilinear gather (channels-last: one contiguous 256 B read per tap per 64-channel
+// chunk) -> LDS -> MFMA for fd = A_f.B_f^T (contraction C) and cd = A_c.B_c^T (contraction K) on
+// RAW sampled values; the L2 normalisation is applied in the epilogue as row/col scales
 // (fd[i][j] * invn_A[i] * invn_B[j]) - the norms are accumulated during the gather.
 // Epilogue: row-centring of fd (the reference's fd -= fd.mean([3,4]), modules.py:332),
-// clamp(cd)*(fd-shift), coalesced stores, per-tile partial sums.  The batch-global
+// clamp(cd)*(fd-shift), coalesced row stores, per-tile partial sums.  The batch-global
 // old_mean (modules.py:331) needs every tile of the pair-set, so it is applied by
 // corr_finalize_kernel from the per-tile sums (deterministic order, no atomics).
+//
+// Main kernel (corr_fwd_ws_kernel): 8 waves = 4 MFMA consumer waves (one 64x64 quadrant each,
+// one per SIMD) + 4 gather producer waves (one per SIMD, sharing it with a consumer), LDS
+// double-buffered by 64-channel chunk: the producers' global loads / bilinear blend / ds_write of
+// chunk t+1 run beside the consumers' ds_read + MFMA of chunk t.  The two roles live in separate
+// top-level branches so their registers (accumulators vs. in-flight loads) overlap.
+// Contraction arithmetic: PREC_F32 = v_mfma_f32_32x32x2_f32 (exact fp32); PREC_BF16X3 = each fp32
+// operand split into bf16 hi+lo by the producers, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation (5.3x the f32 MFMA rate, ~1e-6 absolute error on a cosine).
+//
+// corr_fwd_kernel (4 waves, no overlap, f32) is the simple first version kept as a cross-check.
 //
 // Reference path: src/modules.py:275-398.
 #include "corr_common.h"
 
 namespace stego {
 
-// smem carve (bytes): small persistent arrays first, then one big region that is the staging
-// area during the contraction and the two 128x129 result tiles during the epilogue.
+// ------------------------------------------------------------------ simple kernel smem carve
 constexpr int SM_NRM = 0;                         // float nrm[4][128]: Af, Bf, Ac, Bc
 constexpr int SM_ROWMEAN = SM_NRM + 4 * TP * 4;   // float rowmean[128]
 constexpr int SM_RED = SM_ROWMEAN + TP * 4;       // float red[64]
@@ -25,6 +35,15 @@ constexpr int SM_BIG = SM_RED + 64 * 4;           // 2816, 16-byte aligned
 constexpr int SM_STAGE_BYTES = 2 * TP * LDA * 4 + 3 * 256 * 16;
 constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;
 constexpr int SM_FWD_TOTAL = SM_BIG + (SM_TILES_BYTES > SM_STAGE_BYTES ? SM_TILES_BYTES : SM_STAGE_BYTES);
+
+// ------------------------------------------------------ warp-specialised kernel smem carve
+constexpr int SW_TAPS = SM_BIG;                                 // tapf[256] int4, tapc[256] int4, tapw[256] float4
+constexpr int SW_BIG = SW_TAPS + 3 * 256 * 16;                  // 15104, 16-byte aligned
+constexpr int SW_BUF_F32 = 2 * TP * LDA * 4;                    // A + B, one buffer: 69632 B
+constexpr int SW_BUF_BF16 = 4 * TP * LDH * 2;                   // A hi/lo + B hi/lo: 73728 B
+constexpr int SW_TOTAL_F32 = SW_BIG + 2 * SW_BUF_F32;           // 154368
+constexpr int SW_TOTAL_BF16 = SW_BIG + 2 * SW_BUF_BF16;         // 162560
+static_assert(SW_TOTAL_BF16 <= 160 * 1024 && 2 * SW_BUF_F32 >= SM_TILES_BYTES, "LDS budget");
 
 // One staged chunk of the contraction on v_mfma_f32_32x32x2_f32.  Wave (wr,wc) owns the
 // 64x64 quadrant; lanes 0-31 take k = kk..kk+3, lanes 32-63 k = kk+4..kk+7 of every 8-wide
@@ -52,6 +71,39 @@ __device__ __forceinline__ void mma_chunk_f32(const float* __restrict__ As, cons
     }
 }
 
+// Split-bf16 contraction of one chunk: a.b ~= ah.bh + ah.bl + al.bh (the al.bl term is < 2^-16).
+// Stage layout: hi[128][LDH] then lo[128][LDH] (bf16).  Each lane reads 8 consecutive k
+// (lanes 0-31: kk..kk+7, lanes 32-63: kk+8..kk+15) per operand with one ds_read_b128.
+__device__ __forceinline__ void mma_chunk_bf16x3(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int kc16,
+                                                 f32x16 (&acc)[2][2], int lane, int wr, int wc)
+{
+    constexpr int LO = TP * LDH;
+    const int r = lane & 31, half = lane >> 5;
+    const __bf16* a0p = As + (64 * wr + r) * LDH + 8 * half;
+    const __bf16* a1p = a0p + 32 * LDH;
+    const __bf16* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
+    const __bf16* b1p = b0p + 32 * LDH;
+    for (int kk = 0; kk < kc16; kk += 16) {
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0p + kk), al0 = *reinterpret_cast<const bf16x8*>(a0p + LO + kk);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1p + kk), al1 = *reinterpret_cast<const bf16x8*>(a1p + LO + kk);
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b0p + kk), bl0 = *reinterpret_cast<const bf16x8*>(b0p + LO + kk);
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b1p + kk), bl1 = *reinterpret_cast<const bf16x8*>(b1p + LO + kk);
+        // small cross terms first, then the leading term; accumulators interleaved
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
+    }
+}
+
 // Scale the raw accumulators by the inverse norms and park the tile in LDS.
 // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 __device__ __forceinline__ void park_tile(const f32x16 (&acc)[2][2], float* __restrict__ T,
@@ -74,137 +126,41 @@ __device__ __forceinline__ void park_tile(const f32x16 (&acc)[2][2], float* __re
     }
 }
 
-template <int VF, int VC>
-__global__ void __launch_bounds__(NTHREADS) corr_fwd_kernel(const CorrParams prm)
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2])
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* nrm = reinterpret_cast<float*>(smem + SM_NRM);
-    float* rowmean = reinterpret_cast<float*>(smem + SM_ROWMEAN);
-    float* red = reinterpret_cast<float*>(smem + SM_RED);
-    float* As = reinterpret_cast<float*>(smem + SM_BIG);
-    float* Bs = As + TP * LDA;
-    int4* tapf = reinterpret_cast<int4*>(Bs + TP * LDA);   // feature-map tap offsets [256]
-    int4* tapc = tapf + 256;                               // code-map tap offsets    [256]
-    float4* tapw = reinterpret_cast<float4*>(tapc + 256);  // tap weights             [256]
-    float* Tfd = reinterpret_cast<float*>(smem + SM_BIG);  // epilogue alias
-    float* Tcd = Tfd + TP * LDT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
 
+// Epilogue shared by both kernels (NW waves).  Tfd/Tcd hold the normalised correlation tiles.
+// A wave owns rows wave, wave+NW, ...; its lanes walk the columns, so LDS reads are conflict-free
+// and every global store instruction covers one contiguous run of a row.
+template <int NW>
+__device__ __forceinline__ void tile_epilogue(const CorrParams& prm, const float* __restrict__ Tfd,
+                                              const float* __restrict__ Tcd, float* __restrict__ rowmean,
+                                              float* __restrict__ red, int p, int b, bool direct)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
     const int B = prm.B, P = prm.P;
-    const int tile = blockIdx.x;
-    const int b = tile % B, p = tile / B;      // all pair-sets of image b share blockIdx%8 (XCD L2) when B%8==0
-
-    // ---- which maps feed the two sides (modules.py:369-386)
-    // (selected by value: a pointer into the kernarg struct would force it into scratch)
-    const bool direct = prm.mode == 1;
-    const bool usePos = direct || p == 1;
-    const bool sameAB = !direct && p == 0;
-    const MapV mfA = prm.feats;
-    const MapV mcA = prm.code;
-    MapV mfB, mcB;
-    mfB.p = usePos ? prm.feats_pos.p : prm.feats.p;     mcB.p = usePos ? prm.code_pos.p : prm.code.p;
-    mfB.sn = usePos ? prm.feats_pos.sn : prm.feats.sn;  mcB.sn = usePos ? prm.code_pos.sn : prm.code.sn;
-    mfB.sc = usePos ? prm.feats_pos.sc : prm.feats.sc;  mcB.sc = usePos ? prm.code_pos.sc : prm.code.sc;
-    mfB.sh = usePos ? prm.feats_pos.sh : prm.feats.sh;  mcB.sh = usePos ? prm.code_pos.sh : prm.code.sh;
-    mfB.sw = usePos ? prm.feats_pos.sw : prm.feats.sw;  mcB.sw = usePos ? prm.code_pos.sw : prm.code.sw;
-    const float* coordsB = (!direct && p >= 1) ? prm.coords2 : prm.coords1;
-    int imgB = b;
-    if (!direct && p >= 2) imgB = (int)prm.perms[(size_t)(p - 2) * B + b];
-
-    // ---- tap tables
-    {
-        const int side = tid >> 7, q = tid & (TP - 1);
-        const float* cimg = direct ? nullptr
-                                   : (side == 0 ? prm.coords1 + (size_t)b * P * 2 : coordsB + (size_t)b * P * 2);
-        int4 yx; float4 w;
-        tap_for_point(q, P, prm.S, prm.H, prm.W, direct, cimg, yx, w);
-        tapf[tid] = taps_to_offsets(yx, side == 0 ? mfA.sh : mfB.sh, side == 0 ? mfA.sw : mfB.sw);
-        tapc[tid] = taps_to_offsets(yx, side == 0 ? mcA.sh : mcB.sh, side == 0 ? mcA.sw : mcB.sw);
-        tapw[tid] = w;
-    }
-    __syncthreads();
-
-    const float* Bsrc = sameAB ? As : Bs;
-
-    // ---- feature contraction: fd_raw = A_f . B_f^T over C
-    f32x16 accf[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accf[i][j][r] = 0.f;
-    {
-        float ssA[TP * (KC / VF) / NTHREADS], ssB[TP * (KC / VF) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VF) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
-        const float* imgA = mfA.p + (long long)b * mfA.sn;
-        const float* imgBp = mfB.p + (long long)imgB * mfB.sn;
-        for (int c0 = 0; c0 < prm.C; c0 += KC) {
-            const int kc = min(KC, prm.C - c0);
-            const int kc8 = (kc + 7) & ~7;
-            gather_chunk<VF, LDA>(imgA, mfA.sc, tapf, tapw, c0, prm.C, kc8, P, As, ssA);
-            if (!sameAB) gather_chunk<VF, LDA>(imgBp, mfB.sc, tapf + TP, tapw + TP, c0, prm.C, kc8, P, Bs, ssB);
-            __syncthreads();
-            mma_chunk_f32(As, Bsrc, kc8, accf, lane, wr, wc);
-            __syncthreads();
-        }
-        publish_norms<VF>(ssA, nrm + 0 * TP);
-        if (!sameAB) publish_norms<VF>(ssB, nrm + 1 * TP);
-    }
-
-    // ---- code contraction: cd_raw = A_c . B_c^T over K
-    f32x16 accc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accc[i][j][r] = 0.f;
-    {
-        float ssA[TP * (KC / VC) / NTHREADS], ssB[TP * (KC / VC) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
-        const float* imgA = mcA.p + (long long)b * mcA.sn;
-        const float* imgBp = mcB.p + (long long)imgB * mcB.sn;
-        for (int c0 = 0; c0 < prm.K; c0 += KC) {
-            const int kc = min(KC, prm.K - c0);
-            const int kc8 = (kc + 7) & ~7;
-            gather_chunk<VC, LDA>(imgA, mcA.sc, tapc, tapw, c0, prm.K, kc8, P, As, ssA);
-            if (!sameAB) gather_chunk<VC, LDA>(imgBp, mcB.sc, tapc + TP, tapw + TP, c0, prm.K, kc8, P, Bs, ssB);
-            __syncthreads();
-            mma_chunk_f32(As, Bsrc, kc8, accc, lane, wr, wc);
-            __syncthreads();
-        }
-        publish_norms<VC>(ssA, nrm + 2 * TP);
-        if (!sameAB) publish_norms<VC>(ssB, nrm + 3 * TP);
-    }
-    __syncthreads();   // norms visible; staging area is dead from here on
-
-    const float* nAf = nrm, *nBf = sameAB ? nrm : nrm + TP;
-    const float* nAc = nrm + 2 * TP, *nBc = sameAB ? nrm + 2 * TP : nrm + 3 * TP;
-    park_tile(accf, Tfd, nAf, nBf, lane, wr, wc);
-    park_tile(accc, Tcd, nAc, nBc, lane, wr, wc);
-    __syncthreads();
-
-    // ---- row means of fd over the B-side points (fd.mean([3,4]), modules.py:332); two threads per row
+    // row means of fd over the B-side points (fd.mean([3,4]), modules.py:332)
     float fdsum_part = 0.f;
-    {
-        const int r = tid >> 1, hsel = tid & 1;
-        const int cbeg = hsel ? (P >> 1) : 0, cend = hsel ? P : (P >> 1);
+    for (int r = wave; r < TP; r += NW) {
         float s = 0.f;
         if (r < P)
-            for (int c = cbeg; c < cend; ++c) s += Tfd[r * LDT + c];
-        s += __shfl_xor(s, 1, 64);
-        if (hsel == 0) {
+            for (int c = lane; c < P; c += 64) s += Tfd[r * LDT + c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) {
             rowmean[r] = prm.pointwise ? s / (float)P : 0.f;
-            fdsum_part = (r < P) ? s : 0.f;
+            fdsum_part += s;
         }
     }
-    const float fd_sum = block_sum(fdsum_part, red);   // (syncs inside: rowmean visible after)
+    const float fd_sum = block_sum<NW>(fdsum_part, red);   // (barriers inside: rowmean visible after)
 
-    // ---- elementwise epilogue over the P*P outputs, linear (coalesced) order
     const int P2 = P * P;
     float* cd_out;
     float* loss_out = nullptr;
@@ -220,31 +176,266 @@ __global__ void __launch_bounds__(NTHREADS) corr_fwd_kernel(const CorrParams prm
     float* w_out = prm.saved_w ? prm.saved_w + ((size_t)p * B + b) * P2 : nullptr;
     const float cmin = prm.cmin, cmax = prm.cmax;
     float loss_part = 0.f, clamp_part = 0.f;
-    for (int idx = tid; idx < P2; idx += NTHREADS) {
-        const int r = idx / P, c = idx - r * P;
-        const float w = Tfd[r * LDT + c] - rowmean[r] - shift;     // fd_centred - shift
-        const float cdv = Tcd[r * LDT + c];
-        const float cl = fminf(fmaxf(cdv, cmin), cmax);
-        const float lp = -cl * w;                                  // loss without the old_mean term
-        cd_out[idx] = cdv;
-        if (loss_out) loss_out[idx] = lp;
-        if (w_out) w_out[idx] = w;
-        loss_part += lp;
-        clamp_part += cl;
+    for (int r = wave; r < P; r += NW) {
+        const float rm = rowmean[r] + shift;
+        for (int c = lane; c < P; c += 64) {
+            const int idx = r * P + c;
+            const float w = Tfd[r * LDT + c] - rm;                     // fd_centred - shift
+            const float cdv = Tcd[r * LDT + c];
+            const float cl = fminf(fmaxf(cdv, cmin), cmax);
+            const float lp = -cl * w;                                  // loss without the old_mean term
+            cd_out[idx] = cdv;
+            if (loss_out) loss_out[idx] = lp;
+            if (w_out) w_out[idx] = w;
+            loss_part += lp;
+            clamp_part += cl;
+        }
     }
-    const float loss_sum = block_sum(loss_part, red);
-    const float clamp_sum = block_sum(clamp_part, red);
+    const float loss_sum = block_sum<NW>(loss_part, red);
+    const float clamp_sum = block_sum<NW>(clamp_part, red);
     if (tid == 0) {
         float* st = prm.stats + ((size_t)p * B + b) * 4;
         st[0] = fd_sum; st[1] = loss_sum; st[2] = clamp_sum; st[3] = 0.f;
     }
 }
 
+// Which maps feed the B side of tile (p, b) (modules.py:369-386).  Selected by value: a pointer
+// into the kernarg struct would force the whole struct into scratch.
+struct TileSel {
+    MapV mfB, mcB;
+    const float* coordsB;
+    int imgB;
+    bool sameAB, direct;
+};
+
+__device__ __forceinline__ TileSel select_tile(const CorrParams& prm, int p, int b)
+{
+    TileSel s;
+    s.direct = prm.mode == 1;
+    const bool usePos = s.direct || p == 1;
+    s.sameAB = !s.direct && p == 0;
+    s.mfB.p = usePos ? prm.feats_pos.p : prm.feats.p;     s.mcB.p = usePos ? prm.code_pos.p : prm.code.p;
+    s.mfB.sn = usePos ? prm.feats_pos.sn : prm.feats.sn;  s.mcB.sn = usePos ? prm.code_pos.sn : prm.code.sn;
+    s.mfB.sc = usePos ? prm.feats_pos.sc : prm.feats.sc;  s.mcB.sc = usePos ? prm.code_pos.sc : prm.code.sc;
+    s.mfB.sh = usePos ? prm.feats_pos.sh : prm.feats.sh;  s.mcB.sh = usePos ? prm.code_pos.sh : prm.code.sh;
+    s.mfB.sw = usePos ? prm.feats_pos.sw : prm.feats.sw;  s.mcB.sw = usePos ? prm.code_pos.sw : prm.code.sw;
+    s.coordsB = (!s.direct && p >= 1) ? prm.coords2 : prm.coords1;
+    s.imgB = b;
+    if (!s.direct && p >= 2) s.imgB = (int)prm.perms[(size_t)(p - 2) * prm.B + b];
+    return s;
+}
+
+// tap tables for the 2 x 128 points of a tile; t in [0,256): t<128 -> A point t, else B point t-128
+__device__ __forceinline__ void build_taps(const CorrParams& prm, const TileSel& s, int b, int t, int4* tapf, int4* tapc,
+                                           float4* tapw)
+{
+    const int side = t >> 7, q = t & (TP - 1);
+    const float* cimg = s.direct ? nullptr
+                                 : (side == 0 ? prm.coords1 + (size_t)b * prm.P * 2 : s.coordsB + (size_t)b * prm.P * 2);
+    int4 yx; float4 w;
+    tap_for_point(q, prm.P, prm.S, prm.H, prm.W, s.direct, cimg, yx, w);
+    tapf[t] = taps_to_offsets(yx, side == 0 ? prm.feats.sh : s.mfB.sh, side == 0 ? prm.feats.sw : s.mfB.sw);
+    tapc[t] = taps_to_offsets(yx, side == 0 ? prm.code.sh : s.mcB.sh, side == 0 ? prm.code.sw : s.mcB.sw);
+    tapw[t] = w;
+}
+
+// =============================================================== simple kernel (4 waves, f32)
+template <int VF, int VC>
+__global__ void __launch_bounds__(NTHREADS) corr_fwd_kernel(const CorrParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* nrm = reinterpret_cast<float*>(smem + SM_NRM);
+    float* rowmean = reinterpret_cast<float*>(smem + SM_ROWMEAN);
+    float* red = reinterpret_cast<float*>(smem + SM_RED);
+    float* As = reinterpret_cast<float*>(smem + SM_BIG);
+    float* Bs = As + TP * LDA;
+    int4* tapf = reinterpret_cast<int4*>(Bs + TP * LDA);
+    int4* tapc = tapf + 256;
+    float4* tapw = reinterpret_cast<float4*>(tapc + 256);
+    float* Tfd = reinterpret_cast<float*>(smem + SM_BIG);  // epilogue alias
+    float* Tcd = Tfd + TP * LDT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int B = prm.B;
+    const int tile = blockIdx.x;
+    const int b = tile % B, p = tile / B;      // all pair-sets of image b share blockIdx%8 (XCD L2) when B%8==0
+    const TileSel sel = select_tile(prm, p, b);
+    build_taps(prm, sel, b, tid, tapf, tapc, tapw);
+    __syncthreads();
+
+    const float* Bsrc = sel.sameAB ? As : Bs;
+    constexpr int BF = VF == 4 ? 4 : 8, BC = 4;
+
+    f32x16 accf[2][2];
+    zero_acc(accf);
+    {
+        float ssA[TP * (KC / VF) / NTHREADS], ssB[TP * (KC / VF) / NTHREADS];
+#pragma unroll
+        for (int i = 0; i < TP * (KC / VF) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
+        const float* imgA = prm.feats.p + (long long)b * prm.feats.sn;
+        const float* imgBp = sel.mfB.p + (long long)sel.imgB * sel.mfB.sn;
+        for (int c0 = 0; c0 < prm.C; c0 += KC) {
+            const int kc = min(KC, prm.C - c0);
+            const int kc8 = (kc + 7) & ~7;
+            if (!(prm.debug & 2)) {
+                gather_chunk<VF, LDA, PREC_F32, BF>(imgA, prm.feats.sc, tapf, tapw, c0, prm.C, kc8, As, ssA, tid);
+                if (!sel.sameAB)
+                    gather_chunk<VF, LDA, PREC_F32, BF>(imgBp, sel.mfB.sc, tapf + TP, tapw + TP, c0, prm.C, kc8, Bs, ssB, tid);
+            }
+            __syncthreads();
+            if (!(prm.debug & 1)) mma_chunk_f32(As, Bsrc, kc8, accf, lane, wr, wc);
+            __syncthreads();
+        }
+        publish_norms<VF>(ssA, nrm + 0 * TP, tid);
+        if (!sel.sameAB) publish_norms<VF>(ssB, nrm + 1 * TP, tid);
+    }
+
+    f32x16 accc[2][2];
+    zero_acc(accc);
+    {
+        float ssA[TP * (KC / VC) / NTHREADS], ssB[TP * (KC / VC) / NTHREADS];
+#pragma unroll
+        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
+        const float* imgA = prm.code.p + (long long)b * prm.code.sn;
+        const float* imgBp = sel.mcB.p + (long long)sel.imgB * sel.mcB.sn;
+        for (int c0 = 0; c0 < prm.K; c0 += KC) {
+            const int kc = min(KC, prm.K - c0);
+            const int kc8 = (kc + 7) & ~7;
+            if (!(prm.debug & 2)) {
+                gather_chunk<VC, LDA, PREC_F32, BC>(imgA, prm.code.sc, tapc, tapw, c0, prm.K, kc8, As, ssA, tid);
+                if (!sel.sameAB)
+                    gather_chunk<VC, LDA, PREC_F32, BC>(imgBp, sel.mcB.sc, tapc + TP, tapw + TP, c0, prm.K, kc8, Bs, ssB, tid);
+            }
+            __syncthreads();
+            if (!(prm.debug & 1)) mma_chunk_f32(As, Bsrc, kc8, accc, lane, wr, wc);
+            __syncthreads();
+        }
+        publish_norms<VC>(ssA, nrm + 2 * TP, tid);
+        if (!sel.sameAB) publish_norms<VC>(ssB, nrm + 3 * TP, tid);
+    }
+    __syncthreads();   // norms visible; staging area is dead from here on
+
+    const float* nAf = nrm, *nBf = sel.sameAB ? nrm : nrm + TP;
+    const float* nAc = nrm + 2 * TP, *nBc = sel.sameAB ? nrm + 2 * TP : nrm + 3 * TP;
+    park_tile(accf, Tfd, nAf, nBf, lane, wr, wc);
+    park_tile(accc, Tcd, nAc, nBc, lane, wr, wc);
+    __syncthreads();
+    tile_epilogue<4>(prm, Tfd, Tcd, rowmean, red, p, b, sel.direct);
+}
+
+// ===================================================== warp-specialised kernel (8 waves)
+template <int VF, int VC, int PREC>
+__global__ void __launch_bounds__(512) corr_fwd_ws_kernel(const CorrParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* nrm = reinterpret_cast<float*>(smem + SM_NRM);
+    float* rowmean = reinterpret_cast<float*>(smem + SM_ROWMEAN);
+    float* red = reinterpret_cast<float*>(smem + SM_RED);
+    int4* tapf = reinterpret_cast<int4*>(smem + SW_TAPS);
+    int4* tapc = tapf + 256;
+    float4* tapw = reinterpret_cast<float4*>(tapc + 256);
+    unsigned char* stage = smem + SW_BIG;
+    float* Tfd = reinterpret_cast<float*>(smem + SW_BIG);  // epilogue alias of the stage buffers
+    float* Tcd = Tfd + TP * LDT;
+    constexpr int BUF = PREC == PREC_F32 ? SW_BUF_F32 : SW_BUF_BF16;      // bytes per stage buffer
+    constexpr int BOFF = PREC == PREC_F32 ? TP * LDA * 4 : 2 * TP * LDH * 2;   // B side offset inside a buffer
+    constexpr int LD = PREC == PREC_F32 ? LDA : LDH;
+    constexpr int KR = PREC == PREC_F32 ? 8 : 16;                         // k granularity of the MFMA loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform role
+    const int B = prm.B;
+    const int tile = blockIdx.x;
+    const int b = tile % B, p = tile / B;
+    const TileSel sel = select_tile(prm, p, b);
+    if (tid < 256) build_taps(prm, sel, b, tid, tapf, tapc, tapw);
+    __syncthreads();
+
+    const int nF = (prm.C + KC - 1) / KC, nK = (prm.K + KC - 1) / KC, T = nF + nK;
+
+    if (wave >= 4) {
+        // ---------------- producers: gather chunk it into stage[it&1] while consumers work on it-1
+        const int t = tid - 256;
+        constexpr int BF = 8, BC = VC == 1 ? 8 : 4;
+        float ssAf[TP * (KC / VF) / NTHREADS], ssBf[TP * (KC / VF) / NTHREADS];
+        float ssAc[TP * (KC / VC) / NTHREADS], ssBc[TP * (KC / VC) / NTHREADS];
+#pragma unroll
+        for (int i = 0; i < TP * (KC / VF) / NTHREADS; ++i) { ssAf[i] = 0.f; ssBf[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssAc[i] = 0.f; ssBc[i] = 0.f; }
+        const float* fA = prm.feats.p + (long long)b * prm.feats.sn;
+        const float* fB = sel.mfB.p + (long long)sel.imgB * sel.mfB.sn;
+        const float* cA = prm.code.p + (long long)b * prm.code.sn;
+        const float* cB = sel.mcB.p + (long long)sel.imgB * sel.mcB.sn;
+        for (int it = 0; it <= T; ++it) {
+            if (it < T && !(prm.debug & 2)) {
+                unsigned char* Ab = stage + (it & 1) * BUF;
+                unsigned char* Bb = Ab + BOFF;
+                if (it < nF) {
+                    const int c0 = it * KC;
+                    const int kr = (min(KC, prm.C - c0) + KR - 1) & ~(KR - 1);
+                    gather_chunk<VF, LD, PREC, BF>(fA, prm.feats.sc, tapf, tapw, c0, prm.C, kr, Ab, ssAf, t);
+                    if (!sel.sameAB)
+                        gather_chunk<VF, LD, PREC, BF>(fB, sel.mfB.sc, tapf + TP, tapw + TP, c0, prm.C, kr, Bb, ssBf, t);
+                } else {
+                    const int c0 = (it - nF) * KC;
+                    const int kr = (min(KC, prm.K - c0) + KR - 1) & ~(KR - 1);
+                    gather_chunk<VC, LD, PREC, BC>(cA, prm.code.sc, tapc, tapw, c0, prm.K, kr, Ab, ssAc, t);
+                    if (!sel.sameAB)
+                        gather_chunk<VC, LD, PREC, BC>(cB, sel.mcB.sc, tapc + TP, tapw + TP, c0, prm.K, kr, Bb, ssBc, t);
+                }
+            }
+            __syncthreads();
+        }
+        publish_norms<VF>(ssAf, nrm + 0 * TP, t);
+        if (!sel.sameAB) publish_norms<VF>(ssBf, nrm + 1 * TP, t);
+        publish_norms<VC>(ssAc, nrm + 2 * TP, t);
+        if (!sel.sameAB) publish_norms<VC>(ssBc, nrm + 3 * TP, t);
+        __syncthreads();      // norms published
+        __syncthreads();      // tiles parked
+    } else {
+        // ---------------- consumers: MFMA on chunk it-1
+        const int wr = wave >> 1, wc = wave & 1;
+        f32x16 accf[2][2], accc[2][2];
+        zero_acc(accf);
+        zero_acc(accc);
+        for (int it = 0; it <= T; ++it) {
+            if (it >= 1 && !(prm.debug & 1)) {
+                const int tt = it - 1;
+                const unsigned char* Ab = stage + (tt & 1) * BUF;
+                const unsigned char* Bb = sel.sameAB ? Ab : Ab + BOFF;
+                if (tt < nF) {
+                    const int kr = (min(KC, prm.C - tt * KC) + KR - 1) & ~(KR - 1);
+                    if constexpr (PREC == PREC_F32)
+                        mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), kr, accf, lane, wr, wc);
+                    else
+                        mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), kr, accf, lane, wr, wc);
+                } else {
+                    const int kr = (min(KC, prm.K - (tt - nF) * KC) + KR - 1) & ~(KR - 1);
+                    if constexpr (PREC == PREC_F32)
+                        mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), kr, accc, lane, wr, wc);
+                    else
+                        mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), kr, accc, lane, wr, wc);
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();      // norms published by the producers; stage buffers are dead
+        const float* nAf = nrm, *nBf = sel.sameAB ? nrm : nrm + TP;
+        const float* nAc = nrm + 2 * TP, *nBc = sel.sameAB ? nrm + 2 * TP : nrm + 3 * TP;
+        park_tile(accf, Tfd, nAf, nBf, lane, wr, wc);
+        park_tile(accc, Tcd, nAc, nBc, lane, wr, wc);
+        __syncthreads();      // tiles parked
+    }
+    tile_epilogue<8>(prm, Tfd, Tcd, rowmean, red, p, b, sel.direct);
+}
+
 // Applies the batch-global mean of each pair-set:  old_mean_p = mean_{b,hw,ij} fd  (modules.py:331),
 // fd_final = fd_centred + old_mean (:333, the middle fd.mean() is identically 0), hence
 //   loss = lp - old_mean * clamp(cd);   mean(loss) = (sum lp - old_mean * sum clamp) / (B*P^2).
-// grid.x = blocks over the loss tensor elements of the sets that output one; block 0 also
-// writes the scalar means and saved_mean.
+// grid.x = blocks over the loss tensor elements of the sets that output one (4096 per block, inside
+// one set); block 0 also writes the scalar means and saved_mean.
 __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParams prm)
 {
     __shared__ float s_mean;
@@ -264,9 +455,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
     }
     if (!prm.pointwise) return;
     const int n_loss_sets = prm.n_sets - first_loss_set;
-    const size_t total = (size_t)n_loss_sets * B * P2;
     const size_t per_set = (size_t)B * P2;
-    // each block handles a contiguous span that lies inside one set (host sizes the grid so)
     const size_t span = (size_t)NTHREADS * 16;
     const size_t blocks_per_set = (per_set + span - 1) / span;
     const int ps = (int)(blockIdx.x / blocks_per_set);
@@ -283,68 +472,92 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
     const size_t beg = (size_t)(blockIdx.x % blocks_per_set) * span;
     float* loss = prm.neg_loss + (size_t)ps * per_set;
     const float* cd = prm.neg_cd + (size_t)ps * per_set;
-    (void)total;
+    const bool vec_ok = (per_set % 4 == 0) && ((reinterpret_cast<uintptr_t>(loss) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(cd) & 15) == 0);
+    if (vec_ok) {
+        f32x4 l[4], c[4];
+        size_t e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e[i] = beg + ((size_t)i * NTHREADS + threadIdx.x) * 4;
+            if (e[i] < per_set) {
+                l[i] = *reinterpret_cast<const f32x4*>(loss + e[i]);
+                c[i] = *reinterpret_cast<const f32x4*>(cd + e[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (e[i] < per_set) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) l[i][k] -= om * fminf(fmaxf(c[i][k], cmin), cmax);
+                *reinterpret_cast<f32x4*>(loss + e[i]) = l[i];
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const size_t e = beg + (size_t)i * NTHREADS + threadIdx.x;
-        if (e < per_set) loss[e] -= om * fminf(fmaxf(cd[e], cmin), cmax);
+        for (int i = 0; i < 16; ++i) {
+            const size_t e = beg + (size_t)i * NTHREADS + threadIdx.x;
+            if (e < per_set) loss[e] -= om * fminf(fmaxf(cd[e], cmin), cmax);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------ launch
-static int pick_vec(const MapV& a, const MapV& b, int channels)
+static int pick_vec(const MapV& a, const MapV& b, int channels, bool allow2)
 {
     auto ok = [&](const MapV& m, int v) {
         return m.sc == 1 && channels % v == 0 && (m.sn % v) == 0 && (m.sh % v) == 0 && (m.sw % v) == 0 &&
                (reinterpret_cast<uintptr_t>(m.p) % (4 * v)) == 0;
     };
     if (ok(a, 4) && ok(b, 4)) return 4;
-    if (ok(a, 2) && ok(b, 2)) return 2;
+    if (allow2 && ok(a, 2) && ok(b, 2)) return 2;
     return 1;
 }
 
-template <int VF>
-static hipError_t launch_fwd_vc(const CorrParams& prm, int vc, dim3 grid, hipStream_t stream)
+template <typename K>
+static hipError_t launch_one(K kernel, int lds, bool& attr_done, const CorrParams& prm, int threads, hipStream_t stream)
 {
-    switch (vc) {
-        case 4: hipLaunchKernelGGL((corr_fwd_kernel<VF, 4>), grid, dim3(NTHREADS), SM_FWD_TOTAL, stream, prm); break;
-        case 2: hipLaunchKernelGGL((corr_fwd_kernel<VF, 2>), grid, dim3(NTHREADS), SM_FWD_TOTAL, stream, prm); break;
-        default: hipLaunchKernelGGL((corr_fwd_kernel<VF, 1>), grid, dim3(NTHREADS), SM_FWD_TOTAL, stream, prm); break;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
     }
+    hipLaunchKernelGGL(kernel, dim3(prm.n_sets * prm.B), dim3(threads), lds, stream, prm);
     return hipGetLastError();
 }
 
-template <int VF, int VC>
-static hipError_t set_attr()
+#define STEGO_LAUNCH(KERNEL, LDS, THREADS)                                         \
+    do {                                                                           \
+        static bool done = false;                                                  \
+        return launch_one(KERNEL, LDS, done, prm, THREADS, stream);                \
+    } while (0)
+
+template <int PREC>
+static hipError_t launch_ws(const CorrParams& prm, int vf, int vc, hipStream_t stream)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_kernel<VF, VC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SM_FWD_TOTAL);
+    constexpr int LDS = PREC == PREC_F32 ? SW_TOTAL_F32 : SW_TOTAL_BF16;
+    if (vf == 4) {
+        if (vc == 4) STEGO_LAUNCH((corr_fwd_ws_kernel<4, 4, PREC>), LDS, 512);
+        if (vc == 2) STEGO_LAUNCH((corr_fwd_ws_kernel<4, 2, PREC>), LDS, 512);
+        STEGO_LAUNCH((corr_fwd_ws_kernel<4, 1, PREC>), LDS, 512);
+    }
+    if (vc == 4) STEGO_LAUNCH((corr_fwd_ws_kernel<1, 4, PREC>), LDS, 512);
+    if (vc == 2) STEGO_LAUNCH((corr_fwd_ws_kernel<1, 2, PREC>), LDS, 512);
+    STEGO_LAUNCH((corr_fwd_ws_kernel<1, 1, PREC>), LDS, 512);
 }
 
-hipError_t launch_corr_fwd_main(const CorrParams& prm, hipStream_t stream)
+hipError_t launch_corr_fwd_main(const CorrParams& prm, int precision, int variant, hipStream_t stream)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e;
-        if ((e = set_attr<4, 4>()) != hipSuccess) return e;
-        if ((e = set_attr<4, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<4, 1>()) != hipSuccess) return e;
-        if ((e = set_attr<2, 4>()) != hipSuccess) return e;
-        if ((e = set_attr<2, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<2, 1>()) != hipSuccess) return e;
-        if ((e = set_attr<1, 4>()) != hipSuccess) return e;
-        if ((e = set_attr<1, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<1, 1>()) != hipSuccess) return e;
-        attr_done = true;
+    const int vf = pick_vec(prm.feats, prm.feats_pos, prm.C, false);
+    const int vc = pick_vec(prm.code, prm.code_pos, prm.K, true);
+    if (variant == 0 && precision == PREC_F32) {      // simple cross-check kernel
+        if (vf == 4 && vc == 4) STEGO_LAUNCH((corr_fwd_kernel<4, 4>), SM_FWD_TOTAL, NTHREADS);
+        if (vf == 4 && vc == 2) STEGO_LAUNCH((corr_fwd_kernel<4, 2>), SM_FWD_TOTAL, NTHREADS);
+        STEGO_LAUNCH((corr_fwd_kernel<1, 1>), SM_FWD_TOTAL, NTHREADS);
     }
-    const int vf = pick_vec(prm.feats, prm.feats_pos, prm.C);
-    const int vc = pick_vec(prm.code, prm.code_pos, prm.K);
-    const dim3 grid(prm.n_sets * prm.B);
-    switch (vf) {
-        case 4: return launch_fwd_vc<4>(prm, vc, grid, stream);
-        case 2: return launch_fwd_vc<2>(prm, vc, grid, stream);
-        default: return launch_fwd_vc<1>(prm, vc, grid, stream);
-    }
+    if (precision == PREC_BF16X3) return launch_ws<PREC_BF16X3>(prm, vf, vc, stream);
+    return launch_ws<PREC_F32>(prm, vf, vc, stream);
 }
 
 // finalize: block 0 writes scalars; the rest fix the loss tensors of the sets that output one
@@ -361,9 +574,9 @@ hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_corr_fwd(const CorrParams& prm, hipStream_t stream)
+hipError_t launch_corr_fwd(const CorrParams& prm, int precision, int variant, hipStream_t stream)
 {
-    hipError_t e = launch_corr_fwd_main(prm, stream);
+    hipError_t e = launch_corr_fwd_main(prm, precision, variant, stream);
     if (e != hipSuccess) return e;
     return launch_corr_finalize(prm, stream);
 }
