@@ -125,7 +125,7 @@ def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
     # hardware threads of the bench box, so take the fastest of a few candidates, one trial step each
     t_lim = time.perf_counter() + budget_s
     best, cores = None, 1
-    for n in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
+    for n in sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail}):
         torch.set_num_threads(n)
         step()
         t0 = time.perf_counter()
@@ -147,9 +147,9 @@ def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
     med = times[len(times) // 2]
     return dict(value=B / med, unit="image-pairs/s", cores=cores, kind="port",
                 sample="%d fwd+bwd steps of the same B=%d workload (median %.1f ms), torch %s CPU, %d threads "
-                       "(fastest of 8/16/32/64/%d tried; %d hardware threads visible); port = "
+                       "(fastest of 8/16/32/64 tried; %d hardware threads visible); port = "
                        "oracle/torch_cpu_port.py (the ATen CPU kernels the reference calls)"
-                       % (len(times), B, med * 1e3, torch.__version__, cores, avail, avail))
+                       % (len(times), B, med * 1e3, torch.__version__, cores, avail))
 
 
 def main():
