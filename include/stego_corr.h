@@ -42,8 +42,9 @@ enum {
 /* Arithmetic used for the channel contraction (the einsum of modules.py:283-284). */
 enum {
     STEGO_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate  */
-    STEGO_PREC_BF16X3 = 1    /* split-bf16 (hi*hi + hi*lo + lo*hi) on bf16 MFMA, fp32 accum.;  */
-                             /* ~1e-6 abs error on a cosine similarity (fp32 is ~1e-7)         */
+    STEGO_PREC_BF16X3 = 1    /* feature correlation on split-bf16 (hi*hi + hi*lo + lo*hi, bf16  */
+                             /* MFMA, fp32 accumulate; ~1e-6 abs error on a cosine, fp32 ~1e-7); */
+                             /* the code correlation (which carries gradients) stays exact fp32  */
 };
 
 /* hipStream_t without dragging the HIP headers into C callers. */
@@ -74,23 +75,32 @@ typedef struct StegoCorrDesc {
     int32_t precision;         /* STEGO_PREC_*                                                 */
 } StegoCorrDesc;
 
-/* Limits of this build: S*S <= 128 (S <= 11), K <= 80 for the backward, every per-image
+/* Limits of this build: S*S <= 128 (S <= 11), K <= 72 (cfg.dim; the reference ships 70), every per-image
  * element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED. */
 
 int stego_abi_version(void);
 const char* stego_error_string(int code);
 
-/* Scratch the forward/backward need (bytes; depends only on the descriptor). */
+/* Buffer sizes (bytes; depend only on the descriptor; 0 for an invalid/unsupported descriptor).
+ *   workspace : scratch of one forward call (sampled operand images + per-tile partial sums)
+ *   saved_ctx : what the forward leaves for the backward of the CODE side (normalised sampled codes,
+ *               their norms and the bilinear tap tables); pass NULL to the forward when no backward
+ *               will follow (the data then lives in the workspace). */
 size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc);
+size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc);
+size_t stego_corr_helper_workspace_bytes(const StegoCorrDesc* desc);
+size_t stego_corr_helper_saved_ctx_bytes(const StegoCorrDesc* desc);
 
 /*
- * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws
- * made by the caller in the reference's order (coords1 :366, coords2 :367, super_perm
- * x n_neg :383).  One fused kernel does, per (pair-set, image): bilinear border/
- * align_corners sampling (sample, :287-288) of feats/code at S*S points, L2 normalise
- * (norm, :275-276), both correlation tensors (tensor_correlation, :283-284) on MFMA, the
- * pointwise mean shift (:330-333), clamp*(fd-shift) (:337-345); a second tiny kernel
- * applies the batch-global mean (old_mean, :331) and the two .mean() reductions (:393,:395).
+ * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws made by the
+ * caller in the reference's order (coords1 :366, coords2 :367, super_perm x n_neg :383).
+ * Three launches on `stream`:
+ *   1. sample_norm_kernel: every (role,image) set - anchor @coords1, positive @coords2, negatives
+ *      orig[perm] @coords2 - bilinearly sampled (sample, :287-288: border, align_corners) and
+ *      L2-normalised (norm, :275-276) once;
+ *   2. corr_tile_kernel: per (pair-set,image) both correlation tensors (tensor_correlation, :283-284)
+ *      on MFMA, the pointwise row centring (:332), clamp*(fd-shift) (:337-345), per-tile partial sums;
+ *   3. corr_finalize_kernel: the batch-global mean (old_mean, :331,:333) and the two .mean()s (:393,:395).
  *
  *   feats, feats_pos : [B,C,H,W]   (orig_feats, orig_feats_pos; never differentiated)
  *   code, code_pos   : [B,K,H,W]   (orig_code, orig_code_pos)
@@ -101,8 +111,9 @@ size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc);
  *   pos_intra_cd, pos_inter_cd : [B,S,S,S,S]
  *   neg_inter_loss, neg_inter_cd : [n_neg*B,S,S,S,S]   (torch.cat over negatives, :390-391)
  *   saved_w          : optional [(2+n_neg)*B, S^4]: (fd_centred - shift) per pair-set, and
- *   saved_mean       : optional [2+n_neg]: old_mean per pair-set; both or neither; they are
- *                      what stego_corr_bwd needs of the (no_grad) feature side.
+ *   saved_mean       : optional [2+n_neg]: old_mean per pair-set; both or neither;
+ *   saved_ctx        : optional, stego_corr_saved_ctx_bytes(); with saved_w/saved_mean it is all the
+ *                      backward needs (the feature side is no_grad in the reference, :326).
  */
 int stego_corr_fwd(const StegoCorrDesc* desc,
                    const StegoMap* feats, const StegoMap* feats_pos,
@@ -111,14 +122,14 @@ int stego_corr_fwd(const StegoCorrDesc* desc,
                    float* loss_means,
                    float* pos_intra_cd, float* pos_inter_cd,
                    float* neg_inter_loss, float* neg_inter_cd,
-                   float* saved_w, float* saved_mean,
+                   float* saved_w, float* saved_mean, void* saved_ctx,
                    void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
 /*
- * Measurement hook: exactly stego_corr_fwd, run `iters` times with HIP events recorded on
- * `stream` around (a) the fused tile kernel and (b) the finalize kernel; returns the mean
- * duration of each in milliseconds (host pointers) after synchronising.  bench.py derives
- * roofline.achieved from ms_main.
+ * Measurement hook: exactly stego_corr_fwd, run `iters` times with HIP events recorded on `stream`
+ * around each of the three launches; ms_kernels[3] (host) receives the mean duration in milliseconds
+ * of { sample_norm_kernel, corr_tile_kernel, corr_finalize_kernel } after synchronising.
+ * bench.py derives roofline.achieved from these.
  */
 int stego_corr_fwd_profile(const StegoCorrDesc* desc,
                            const StegoMap* feats, const StegoMap* feats_pos,
@@ -127,9 +138,9 @@ int stego_corr_fwd_profile(const StegoCorrDesc* desc,
                            float* loss_means,
                            float* pos_intra_cd, float* pos_inter_cd,
                            float* neg_inter_loss, float* neg_inter_cd,
-                           float* saved_w, float* saved_mean,
+                           float* saved_w, float* saved_mean, void* saved_ctx,
                            void* workspace, size_t workspace_bytes, stego_stream_t stream,
-                           int32_t iters, float* ms_main, float* ms_finalize);
+                           int32_t iters, float* ms_kernels);
 
 /*
  * Backward of the above w.r.t. orig_code / orig_code_pos (what autograd derives through
@@ -141,13 +152,12 @@ int stego_corr_fwd_profile(const StegoCorrDesc* desc,
  *                      [n_neg*B,S^4], 0 -> one broadcast device scalar (what .mean() feeds);
  *                      NULL -> zero
  *   g_intra_cd, g_inter_cd, g_neg_cd : optional dense upstreams of the cd outputs (NULL -> 0)
- *   d_code, d_code_pos : OUT, channels-last dense [B,H,W,K] (i.e. grad.permute(0,2,3,1)),
- *                      overwritten (zero-filled, then accumulated with fp32 atomics).
+ *   d_code, d_code_pos : OUT, channels-last dense [B,H,W,K] (i.e. grad.permute(0,2,3,1)), overwritten.
  */
 int stego_corr_bwd(const StegoCorrDesc* desc,
                    const StegoMap* code, const StegoMap* code_pos,
                    const float* coords1, const float* coords2, const int64_t* perms,
-                   const float* saved_w, const float* saved_mean,
+                   const float* saved_w, const float* saved_mean, const void* saved_ctx,
                    const float* pos_intra_cd, const float* pos_inter_cd, const float* neg_inter_cd,
                    const float* g_intra, const float* g_inter,
                    const float* g_neg_loss, int32_t g_neg_loss_stride,
@@ -159,19 +169,20 @@ int stego_corr_bwd(const StegoCorrDesc* desc,
  * ContrastiveCorrelationLoss.helper (modules.py:325-347) on ALREADY SAMPLED tensors:
  *   f1,f2 : [N,C,S1,S2]   c1,c2 : [N,K,S1,S2]   (desc->B = N, desc->H = S1, desc->W = S2,
  *   desc->S is ignored, S1*S2 <= 128);  shift = desc->pos_intra_shift.
- * outputs: loss, cd : [N,S1,S2,S1,S2]; saved_w/saved_mean as above with one pair-set.
+ * outputs: loss, cd : [N,S1,S2,S1,S2]; saved_w/saved_mean/saved_ctx as above with one pair-set
+ * (sizes from the stego_corr_helper_* functions).
  */
 int stego_corr_helper_fwd(const StegoCorrDesc* desc,
                           const StegoMap* f1, const StegoMap* f2,
                           const StegoMap* c1, const StegoMap* c2,
-                          float* loss, float* cd, float* saved_w, float* saved_mean,
+                          float* loss, float* cd, float* saved_w, float* saved_mean, void* saved_ctx,
                           void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
 /* Backward of helper w.r.t. c1, c2 (dense upstreams g_loss / g_cd, either may be NULL).
  * d_c1, d_c2: OUT channels-last dense [N,S1,S2,K], overwritten. */
 int stego_corr_helper_bwd(const StegoCorrDesc* desc,
                           const StegoMap* c1, const StegoMap* c2,
-                          const float* saved_w, const float* saved_mean, const float* cd,
+                          const float* saved_w, const float* saved_mean, const void* saved_ctx, const float* cd,
                           const float* g_loss, const float* g_cd,
                           float* d_c1, float* d_c2,
                           void* workspace, size_t workspace_bytes, stego_stream_t stream);

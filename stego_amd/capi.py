@@ -30,20 +30,22 @@ class StegoCorrDesc(Structure):
 
 # name -> (restype, argtypes); every symbol include/stego_corr.h declares
 _P = c_void_p
+_D = POINTER(StegoCorrDesc)
+_M = POINTER(StegoMap)
 SIGNATURES = {
     "stego_abi_version": (c_int32, []),
     "stego_error_string": (ctypes.c_char_p, [c_int32]),
-    "stego_corr_workspace_bytes": (c_size_t, [POINTER(StegoCorrDesc)]),
-    "stego_corr_fwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 3 + [_P] * 7
-                       + [_P, c_size_t, _P]),
-    "stego_corr_fwd_profile": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 3 + [_P] * 7
-                               + [_P, c_size_t, _P] + [c_int32, POINTER(c_float), POINTER(c_float)]),
-    "stego_corr_bwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 2 + [_P] * 3 + [_P] * 2 + [_P] * 3
-                       + [_P, _P, _P, c_int32] + [_P] * 3 + [_P, _P] + [_P, c_size_t, _P]),
-    "stego_corr_helper_fwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 4 + [_P] * 4
-                              + [_P, c_size_t, _P]),
-    "stego_corr_helper_bwd": (c_int32, [POINTER(StegoCorrDesc)] + [POINTER(StegoMap)] * 2 + [_P] * 5 + [_P, _P]
-                              + [_P, c_size_t, _P]),
+    "stego_corr_workspace_bytes": (c_size_t, [_D]),
+    "stego_corr_saved_ctx_bytes": (c_size_t, [_D]),
+    "stego_corr_helper_workspace_bytes": (c_size_t, [_D]),
+    "stego_corr_helper_saved_ctx_bytes": (c_size_t, [_D]),
+    "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
+    "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
+                               + [c_int32, POINTER(c_float)]),
+    "stego_corr_bwd": (c_int32, [_D] + [_M] * 2 + [_P] * 3 + [_P] * 3 + [_P] * 3 + [_P, _P, _P, c_int32] + [_P] * 3
+                       + [_P, _P] + [_P, c_size_t, _P]),
+    "stego_corr_helper_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 5 + [_P, c_size_t, _P]),
+    "stego_corr_helper_bwd": (c_int32, [_D] + [_M] * 2 + [_P] * 6 + [_P, _P] + [_P, c_size_t, _P]),
 }
 
 _lib = None
@@ -115,64 +117,69 @@ def _dense(t, dtype):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _empty_bytes(n, dev):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
+
+
+def _fwd_buffers(lib, desc, dev, need_grad, flat=False):
+    B, S, n_neg = desc.B, desc.S, desc.n_neg
+    f32 = dict(dtype=torch.float32, device=dev)
+    shp = (S ** 4,) if flat else (S, S, S, S)
+    loss_means = torch.empty(2, **f32)
+    intra_cd = torch.empty(B, *shp, **f32)
+    inter_cd = torch.empty(B, *shp, **f32)
+    neg_loss = torch.empty(n_neg * B, *shp, **f32)
+    neg_cd = torch.empty(n_neg * B, *shp, **f32)
+    saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
+    saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
+    saved_ctx = _empty_bytes(lib.stego_corr_saved_ctx_bytes(byref(desc)), dev) if need_grad else None
+    ws = _empty_bytes(lib.stego_corr_workspace_bytes(byref(desc)), dev)
+    return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean, saved_ctx, ws
+
+
 def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad):
     """stego_corr_fwd on torch tensors. Returns (loss_means[2], intra_cd, inter_cd, neg_loss, neg_cd,
-    saved_w|None, saved_mean|None)."""
+    saved) where saved = (saved_w, saved_mean, saved_ctx) or None."""
     _require_dev(feats, feats_pos, code, code_pos, coords1, coords2, perms)
     lib = load()
-    B, S, n_neg = desc.B, desc.S, desc.n_neg
     dev = feats.device
     coords1 = _dense(coords1, torch.float32)
     coords2 = _dense(coords2, torch.float32)
-    perms = _dense(perms, torch.int64) if n_neg else None
-    f32 = dict(dtype=torch.float32, device=dev)
-    loss_means = torch.empty(2, **f32)
-    intra_cd = torch.empty(B, S, S, S, S, **f32)
-    inter_cd = torch.empty(B, S, S, S, S, **f32)
-    neg_loss = torch.empty(n_neg * B, S, S, S, S, **f32)
-    neg_cd = torch.empty(n_neg * B, S, S, S, S, **f32)
-    saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
-    saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
-    ws_bytes = lib.stego_corr_workspace_bytes(byref(desc))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    perms = _dense(perms, torch.int64) if desc.n_neg else None
+    (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean, saved_ctx, ws) = _fwd_buffers(
+        lib, desc, dev, need_grad)
     mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
     with torch.cuda.device(dev):
         _check(lib.stego_corr_fwd(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
                                   _ptr(coords1), _ptr(coords2), _ptr(perms),
                                   _ptr(loss_means), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_loss), _ptr(neg_cd),
-                                  _ptr(saved_w), _ptr(saved_mean), _ptr(ws), ws.numel(), _stream()))
-    return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean
+                                  _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx), _ptr(ws), ws.numel(), _stream()))
+    saved = (saved_w, saved_mean, saved_ctx) if need_grad else None
+    return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved
 
 
 def corr_fwd_profile(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad, iters):
-    """stego_corr_fwd_profile: mean HIP-event duration (ms) of the tile kernel and of the finalize kernel."""
+    """stego_corr_fwd_profile: mean HIP-event duration (ms) of (sample kernel, tile kernel, finalize kernel)."""
     _require_dev(feats, feats_pos, code, code_pos, coords1, coords2, perms)
     lib = load()
-    B, S, n_neg = desc.B, desc.S, desc.n_neg
     dev = feats.device
-    f32 = dict(dtype=torch.float32, device=dev)
-    loss_means = torch.empty(2, **f32)
-    intra_cd = torch.empty(B, S ** 4, **f32)
-    inter_cd = torch.empty(B, S ** 4, **f32)
-    neg_loss = torch.empty(max(n_neg * B, 1), S ** 4, **f32)
-    neg_cd = torch.empty(max(n_neg * B, 1), S ** 4, **f32)
-    saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
-    saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
-    ws = torch.empty(max(lib.stego_corr_workspace_bytes(byref(desc)), 16), dtype=torch.uint8, device=dev)
+    (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean, saved_ctx, ws) = _fwd_buffers(
+        lib, desc, dev, need_grad, flat=True)
     mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
-    ms_main, ms_fin = c_float(0), c_float(0)
+    ms = (c_float * 3)()
     with torch.cuda.device(dev):
         _check(lib.stego_corr_fwd_profile(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
-                                          _ptr(coords1), _ptr(coords2), _ptr(perms),
+                                          _ptr(coords1), _ptr(coords2), _ptr(perms) if desc.n_neg else None,
                                           _ptr(loss_means), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_loss),
-                                          _ptr(neg_cd), _ptr(saved_w), _ptr(saved_mean), _ptr(ws), ws.numel(),
-                                          _stream(), int(iters), byref(ms_main), byref(ms_fin)))
-    return ms_main.value, ms_fin.value
+                                          _ptr(neg_cd), _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx),
+                                          _ptr(ws), ws.numel(), _stream(), int(iters), ms))
+    return ms[0], ms[1], ms[2]
 
 
-def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved_w, saved_mean, intra_cd, inter_cd, neg_cd,
+def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, inter_cd, neg_cd,
              g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd):
     """stego_corr_bwd. g_* may be None. Returns (d_code, d_code_pos) as [B,K,H,W] views of channels-last buffers."""
+    saved_w, saved_mean, saved_ctx = saved
     _require_dev(code, code_pos, saved_w)
     lib = load()
     dev = code.device
@@ -198,7 +205,8 @@ def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved_w, saved_mean,
     mc, mcp = _map(code), _map(code_pos)
     with torch.cuda.device(dev):
         _check(lib.stego_corr_bwd(byref(desc), byref(mc), byref(mcp), _ptr(coords1), _ptr(coords2), _ptr(perms),
-                                  _ptr(saved_w), _ptr(saved_mean), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_cd),
+                                  _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx),
+                                  _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_cd),
                                   _ptr(g_intra), _ptr(g_inter), _ptr(g_neg_loss), stride,
                                   _ptr(g_intra_cd), _ptr(g_inter_cd), _ptr(g_neg_cd),
                                   _ptr(d_code), _ptr(d_code_pos), None, 0, _stream()))
@@ -215,16 +223,18 @@ def helper_fwd(desc, f1, f2, c1, c2, need_grad):
     cd = torch.empty(N, S1, S2, S1, S2, **f32)
     saved_w = torch.empty(N, (S1 * S2) ** 2, **f32) if need_grad else None
     saved_mean = torch.empty(1, **f32) if need_grad else None
-    ws = torch.empty(max(N * 16, 16), dtype=torch.uint8, device=dev)
+    saved_ctx = _empty_bytes(lib.stego_corr_helper_saved_ctx_bytes(byref(desc)), dev) if need_grad else None
+    ws = _empty_bytes(lib.stego_corr_helper_workspace_bytes(byref(desc)), dev)
     m1, m2, m3, m4 = _map(f1), _map(f2), _map(c1), _map(c2)
     with torch.cuda.device(dev):
         _check(lib.stego_corr_helper_fwd(byref(desc), byref(m1), byref(m2), byref(m3), byref(m4),
-                                         _ptr(loss), _ptr(cd), _ptr(saved_w), _ptr(saved_mean),
+                                         _ptr(loss), _ptr(cd), _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx),
                                          _ptr(ws), ws.numel(), _stream()))
-    return loss, cd, saved_w, saved_mean
+    return loss, cd, ((saved_w, saved_mean, saved_ctx) if need_grad else None)
 
 
-def helper_bwd(desc, c1, c2, saved_w, saved_mean, cd, g_loss, g_cd):
+def helper_bwd(desc, c1, c2, saved, cd, g_loss, g_cd):
+    saved_w, saved_mean, saved_ctx = saved
     _require_dev(c1, c2, saved_w)
     lib = load()
     N, K, S1, S2 = desc.B, desc.K, desc.H, desc.W
@@ -236,5 +246,6 @@ def helper_bwd(desc, c1, c2, saved_w, saved_mean, cd, g_loss, g_cd):
     m1, m2 = _map(c1), _map(c2)
     with torch.cuda.device(dev):
         _check(lib.stego_corr_helper_bwd(byref(desc), byref(m1), byref(m2), _ptr(saved_w), _ptr(saved_mean),
-                                         _ptr(cd), _ptr(g_loss), _ptr(g_cd), _ptr(d1), _ptr(d2), None, 0, _stream()))
+                                         _ptr(saved_ctx), _ptr(cd), _ptr(g_loss), _ptr(g_cd), _ptr(d1), _ptr(d2),
+                                         None, 0, _stream()))
     return d1.permute(0, 3, 1, 2), d2.permute(0, 3, 1, 2)

@@ -41,12 +41,33 @@ struct CorrParams {
     float* saved_mean;                         // [n_sets] or null
     float* loss_means;                         // [2] or null (mode 1)
     float* stats;                              // workspace [n_sets*B][4]
+    const void* fs;                            // stage-1 outputs (dense kernel): sampled normalised features
+    const float* cs;                           //                                 sampled normalised codes
+    int NCH, KQ, LDK;
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int mode;                                  // 0 = forward() semantics, 1 = helper() on pre-sampled maps
     int pointwise;
     int debug;                                 // measurement ablations (STEGO_DEBUG env): 1 skip MFMA, 2 skip gather
     float cmin, cmax;
     float shift[3];
+};
+
+// Stage-1 (sampling) parameters; see corr_sample.hip.
+struct SampleParams {
+    MapV feats, feats_pos, code, code_pos;     // helper mode: f1, f2, c1, c2
+    const float* coords1;
+    const float* coords2;
+    const long long* perms;                    // [n_neg][B]
+    void* fs;                                  // f32: [nset][NCH][128][LDA] float; bf16x3: [nset][NCH][2][128][LDH] bf16
+    float* cs;                                 // [nset][128][LDK] normalised sampled codes
+    float* nrm;                                // [nset][128] code norms before normalisation
+    int4* tapyx;                               // optional [nset][128] packed tap pixels (for the backward)
+    float4* tapw;                              // optional [nset][128] tap weights
+    int B, C, K, H, W, S, P;
+    int n_roles;                               // 2 + n_neg (helper: 2)
+    int NCH;                                   // ceil(C/64)
+    int KQ, LDK;                               // round_up(K,8), KQ+4
+    int mode;                                  // 0 forward(), 1 helper() (pixel-for-pixel)
 };
 
 struct BwdParams {

@@ -11,16 +11,20 @@
 // old_mean (modules.py:331) needs every tile of the pair-set, so it is applied by
 // corr_finalize_kernel from the per-tile sums (deterministic order, no atomics).
 //
-// Main kernel (corr_fwd_ws_kernel): 8 waves = 4 MFMA consumer waves (one 64x64 quadrant each,
-// one per SIMD) + 4 gather producer waves (one per SIMD, sharing it with a consumer), LDS
-// double-buffered by 64-channel chunk: the producers' global loads / bilinear blend / ds_write of
-// chunk t+1 run beside the consumers' ds_read + MFMA of chunk t.  The two roles live in separate
-// top-level branches so their registers (accumulators vs. in-flight loads) overlap.
-// Contraction arithmetic: PREC_F32 = v_mfma_f32_32x32x2_f32 (exact fp32); PREC_BF16X3 = each fp32
-// operand split into bf16 hi+lo by the producers, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
-// with fp32 accumulation (5.3x the f32 MFMA rate, ~1e-6 absolute error on a cosine).
+// Production path (two launches + finalize):
+//   corr_sample.hip : sample_norm_kernel  - every (role, image) set sampled + L2-normalised ONCE, placed on
+//                     the XCD of its source image, written as ready-made LDS images;
+//   corr_tile_kernel (here) - one workgroup (4 waves, one per SIMD) per (pair-set, image) tile: both
+//                     operands are dense, so the MFMA waves themselves issue async global_load_lds copies
+//                     of chunk t+1 (no VGPRs, no VALU) and run the MFMAs of chunk t in their shadow
+//                     (an f32 MFMA stream starves any OTHER wave on its SIMD, so loader waves do not work).
+// Contraction arithmetic: PREC_F32 = v_mfma_f32_32x32x2_f32 (exact fp32) for both correlations;
+// PREC_BF16X3 = the feature correlation fd (no_grad side, 85 % of the flops) on split-bf16
+// (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_bf16, fp32 accumulate, ~1e-6 abs error on a cosine); the code
+// correlation cd stays exact f32 because its sign decides the clamp mask of the backward.
 //
-// corr_fwd_kernel (4 waves, no overlap, f32) is the simple first version kept as a cross-check.
+// corr_fwd_kernel (fused gather, 4 waves, no overlap, f32) is the first version kept as a cross-check
+// (STEGO_FWD_VARIANT=0).
 //
 // Reference path: src/modules.py:275-398.
 #include "corr_common.h"
@@ -36,14 +40,12 @@ constexpr int SM_STAGE_BYTES = 2 * TP * LDA * 4 + 3 * 256 * 16;
 constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;
 constexpr int SM_FWD_TOTAL = SM_BIG + (SM_TILES_BYTES > SM_STAGE_BYTES ? SM_TILES_BYTES : SM_STAGE_BYTES);
 
-// ------------------------------------------------------ warp-specialised kernel smem carve
-constexpr int SW_TAPS = SM_BIG;                                 // tapf[256] int4, tapc[256] int4, tapw[256] float4
-constexpr int SW_BIG = SW_TAPS + 3 * 256 * 16;                  // 15104, 16-byte aligned
-constexpr int SW_BUF_F32 = 2 * TP * LDA * 4;                    // A + B, one buffer: 69632 B
-constexpr int SW_BUF_BF16 = 4 * TP * LDH * 2;                   // A hi/lo + B hi/lo: 73728 B
-constexpr int SW_TOTAL_F32 = SW_BIG + 2 * SW_BUF_F32;           // 154368
-constexpr int SW_TOTAL_BF16 = SW_BIG + 2 * SW_BUF_BF16;         // 162560
-static_assert(SW_TOTAL_BF16 <= 160 * 1024 && 2 * SW_BUF_F32 >= SM_TILES_BYTES, "LDS budget");
+// ------------------------------------------------------------------ dense tile kernel smem carve
+constexpr int SD_ROWMEAN = 0;                     // float rowmean[128]
+constexpr int SD_RED = SD_ROWMEAN + TP * 4;       // float red[64]
+constexpr int SD_BIG = SD_RED + 64 * 4;           // 768: two stage buffers, aliased by the result tiles
+constexpr int FEAT_SIDE_F32 = TP * LDA * 4;       // 34816 = 34 x 1 KB : one operand, one 64-channel chunk
+constexpr int FEAT_SIDE_BF16 = 2 * TP * LDH * 2;  // 36864 = 36 x 1 KB : hi + lo
 
 // One staged chunk of the contraction on v_mfma_f32_32x32x2_f32.  Wave (wr,wc) owns the
 // 64x64 quadrant; lanes 0-31 take k = kk..kk+3, lanes 32-63 k = kk+4..kk+7 of every 8-wide
@@ -57,6 +59,30 @@ __device__ __forceinline__ void mma_chunk_f32(const float* __restrict__ As, cons
     const float* b0p = Bs + (64 * wc + r) * LDA + 4 * half;
     const float* b1p = b0p + 32 * LDA;
     for (int kk = 0; kk < kc8; kk += 8) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + kk);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + kk);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + kk);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1p + kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+// Code contraction (exact f32) over the whole K in one go; operands [128][ld] floats, ld = KQ+4.
+__device__ __forceinline__ void mma_code_f32(const float* __restrict__ As, const float* __restrict__ Bs, int kq, int ld,
+                                             f32x16 (&acc)[2][2], int lane, int wr, int wc)
+{
+    const int r = lane & 31, half = lane >> 5;
+    const float* a0p = As + (64 * wr + r) * ld + 4 * half;
+    const float* a1p = a0p + 32 * ld;
+    const float* b0p = Bs + (64 * wc + r) * ld + 4 * half;
+    const float* b1p = b0p + 32 * ld;
+    for (int kk = 0; kk < kq; kk += 8) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + kk);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + kk);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + kk);
@@ -184,9 +210,11 @@ __device__ __forceinline__ void tile_epilogue(const CorrParams& prm, const float
             const float cdv = Tcd[r * LDT + c];
             const float cl = fminf(fmaxf(cdv, cmin), cmax);
             const float lp = -cl * w;                                  // loss without the old_mean term
-            cd_out[idx] = cdv;
-            if (loss_out) loss_out[idx] = lp;
-            if (w_out) w_out[idx] = w;
+            if (!(prm.debug & 4)) {
+                cd_out[idx] = cdv;
+                if (loss_out) loss_out[idx] = lp;
+                if (w_out) w_out[idx] = w;
+            }
             loss_part += lp;
             clamp_part += cl;
         }
@@ -324,111 +352,174 @@ __global__ void __launch_bounds__(NTHREADS) corr_fwd_kernel(const CorrParams prm
     tile_epilogue<4>(prm, Tfd, Tcd, rowmean, red, p, b, sel.direct);
 }
 
-// ===================================================== warp-specialised kernel (8 waves)
-template <int VF, int VC, int PREC>
-__global__ void __launch_bounds__(512) corr_fwd_ws_kernel(const CorrParams prm)
+// ============================================================ dense tile kernel (production)
+// Linear async copy of npieces KiB from global to LDS, split over the 4 waves.  The LDS destination
+// of a global_load_lds is wave-uniform base + lane*16, i.e. each piece is one contiguous KiB.
+__device__ __forceinline__ void issue_copy(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int npieces,
+                                           int wave, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* nrm = reinterpret_cast<float*>(smem + SM_NRM);
-    float* rowmean = reinterpret_cast<float*>(smem + SM_ROWMEAN);
-    float* red = reinterpret_cast<float*>(smem + SM_RED);
-    int4* tapf = reinterpret_cast<int4*>(smem + SW_TAPS);
-    int4* tapc = tapf + 256;
-    float4* tapw = reinterpret_cast<float4*>(tapc + 256);
-    unsigned char* stage = smem + SW_BIG;
-    float* Tfd = reinterpret_cast<float*>(smem + SW_BIG);  // epilogue alias of the stage buffers
-    float* Tcd = Tfd + TP * LDT;
-    constexpr int BUF = PREC == PREC_F32 ? SW_BUF_F32 : SW_BUF_BF16;      // bytes per stage buffer
-    constexpr int BOFF = PREC == PREC_F32 ? TP * LDA * 4 : 2 * TP * LDH * 2;   // B side offset inside a buffer
-    constexpr int LD = PREC == PREC_F32 ? LDA : LDH;
-    constexpr int KR = PREC == PREC_F32 ? 8 : 16;                         // k granularity of the MFMA loop
+    for (int pc = wave; pc < npieces; pc += 4) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(gsrc + (size_t)pc * 1024 + lane * 16),
+            (__attribute__((address_space(3))) void*)(lds_dst + pc * 1024), 16, 0, 0);
+    }
+}
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform role
-    const int B = prm.B;
-    const int tile = blockIdx.x;
-    const int b = tile % B, p = tile / B;
-    const TileSel sel = select_tile(prm, p, b);
-    if (tid < 256) build_taps(prm, sel, b, tid, tapf, tapc, tapw);
+__device__ __forceinline__ void park_plain(const f32x16 (&acc)[2][2], float* __restrict__ T, int lane, int wr, int wc)
+{
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = 64 * wc + 32 * ni + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                T[row * LDT + col] = acc[mi][ni][r];
+            }
+    }
+}
+
+// Epilogue of the dense kernel (4 waves): row means by one lane per row (121 independent LDS reads,
+// no cross-lane traffic), row-wise coalesced stores, one 3-value block reduction at the end.
+__device__ __forceinline__ void tile_epilogue_dense(const CorrParams& prm, const float* __restrict__ Tfd,
+                                                    const float* __restrict__ Tcd, float* __restrict__ rowmean,
+                                                    float* __restrict__ red, int p, int b, bool direct)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = prm.B, P = prm.P;
+    float fd_part = 0.f;
+    if (tid < TP) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (tid < P) {
+            const float* row = Tfd + tid * LDT;
+            int c = 0;
+            for (; c + 4 <= P; c += 4) { s0 += row[c]; s1 += row[c + 1]; s2 += row[c + 2]; s3 += row[c + 3]; }
+            for (; c < P; ++c) s0 += row[c];
+        }
+        fd_part = (s0 + s1) + (s2 + s3);
+        rowmean[tid] = prm.pointwise ? fd_part / (float)P : 0.f;    // fd.mean([3,4]) (modules.py:332)
+    }
     __syncthreads();
 
-    const int nF = (prm.C + KC - 1) / KC, nK = (prm.K + KC - 1) / KC, T = nF + nK;
-
-    if (wave >= 4) {
-        // ---------------- producers: gather chunk it into stage[it&1] while consumers work on it-1
-        const int t = tid - 256;
-        constexpr int BF = 8, BC = VC == 1 ? 8 : 4;
-        float ssAf[TP * (KC / VF) / NTHREADS], ssBf[TP * (KC / VF) / NTHREADS];
-        float ssAc[TP * (KC / VC) / NTHREADS], ssBc[TP * (KC / VC) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VF) / NTHREADS; ++i) { ssAf[i] = 0.f; ssBf[i] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssAc[i] = 0.f; ssBc[i] = 0.f; }
-        const float* fA = prm.feats.p + (long long)b * prm.feats.sn;
-        const float* fB = sel.mfB.p + (long long)sel.imgB * sel.mfB.sn;
-        const float* cA = prm.code.p + (long long)b * prm.code.sn;
-        const float* cB = sel.mcB.p + (long long)sel.imgB * sel.mcB.sn;
-        for (int it = 0; it <= T; ++it) {
-            if (it < T && !(prm.debug & 2)) {
-                unsigned char* Ab = stage + (it & 1) * BUF;
-                unsigned char* Bb = Ab + BOFF;
-                if (it < nF) {
-                    const int c0 = it * KC;
-                    const int kr = (min(KC, prm.C - c0) + KR - 1) & ~(KR - 1);
-                    gather_chunk<VF, LD, PREC, BF>(fA, prm.feats.sc, tapf, tapw, c0, prm.C, kr, Ab, ssAf, t);
-                    if (!sel.sameAB)
-                        gather_chunk<VF, LD, PREC, BF>(fB, sel.mfB.sc, tapf + TP, tapw + TP, c0, prm.C, kr, Bb, ssBf, t);
-                } else {
-                    const int c0 = (it - nF) * KC;
-                    const int kr = (min(KC, prm.K - c0) + KR - 1) & ~(KR - 1);
-                    gather_chunk<VC, LD, PREC, BC>(cA, prm.code.sc, tapc, tapw, c0, prm.K, kr, Ab, ssAc, t);
-                    if (!sel.sameAB)
-                        gather_chunk<VC, LD, PREC, BC>(cB, sel.mcB.sc, tapc + TP, tapw + TP, c0, prm.K, kr, Bb, ssBc, t);
-                }
-            }
-            __syncthreads();
-        }
-        publish_norms<VF>(ssAf, nrm + 0 * TP, t);
-        if (!sel.sameAB) publish_norms<VF>(ssBf, nrm + 1 * TP, t);
-        publish_norms<VC>(ssAc, nrm + 2 * TP, t);
-        if (!sel.sameAB) publish_norms<VC>(ssBc, nrm + 3 * TP, t);
-        __syncthreads();      // norms published
-        __syncthreads();      // tiles parked
-    } else {
-        // ---------------- consumers: MFMA on chunk it-1
-        const int wr = wave >> 1, wc = wave & 1;
-        f32x16 accf[2][2], accc[2][2];
-        zero_acc(accf);
-        zero_acc(accc);
-        for (int it = 0; it <= T; ++it) {
-            if (it >= 1 && !(prm.debug & 1)) {
-                const int tt = it - 1;
-                const unsigned char* Ab = stage + (tt & 1) * BUF;
-                const unsigned char* Bb = sel.sameAB ? Ab : Ab + BOFF;
-                if (tt < nF) {
-                    const int kr = (min(KC, prm.C - tt * KC) + KR - 1) & ~(KR - 1);
-                    if constexpr (PREC == PREC_F32)
-                        mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), kr, accf, lane, wr, wc);
-                    else
-                        mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), kr, accf, lane, wr, wc);
-                } else {
-                    const int kr = (min(KC, prm.K - (tt - nF) * KC) + KR - 1) & ~(KR - 1);
-                    if constexpr (PREC == PREC_F32)
-                        mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), kr, accc, lane, wr, wc);
-                    else
-                        mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), kr, accc, lane, wr, wc);
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();      // norms published by the producers; stage buffers are dead
-        const float* nAf = nrm, *nBf = sel.sameAB ? nrm : nrm + TP;
-        const float* nAc = nrm + 2 * TP, *nBc = sel.sameAB ? nrm + 2 * TP : nrm + 3 * TP;
-        park_tile(accf, Tfd, nAf, nBf, lane, wr, wc);
-        park_tile(accc, Tcd, nAc, nBc, lane, wr, wc);
-        __syncthreads();      // tiles parked
+    const int P2 = P * P;
+    float* cd_out;
+    float* loss_out = nullptr;
+    float shift;
+    if (direct) { cd_out = prm.neg_cd + (size_t)b * P2; loss_out = prm.neg_loss + (size_t)b * P2; shift = prm.shift[0]; }
+    else if (p == 0) { cd_out = prm.intra_cd + (size_t)b * P2; shift = prm.shift[0]; }
+    else if (p == 1) { cd_out = prm.inter_cd + (size_t)b * P2; shift = prm.shift[1]; }
+    else {
+        cd_out = prm.neg_cd + ((size_t)(p - 2) * B + b) * P2;
+        loss_out = prm.neg_loss + ((size_t)(p - 2) * B + b) * P2;
+        shift = prm.shift[2];
     }
-    tile_epilogue<8>(prm, Tfd, Tcd, rowmean, red, p, b, sel.direct);
+    float* w_out = prm.saved_w ? prm.saved_w + ((size_t)p * B + b) * P2 : nullptr;
+    const float cmin = prm.cmin, cmax = prm.cmax;
+    float loss_part = 0.f, clamp_part = 0.f;
+    if (!(prm.debug & 8)) {
+        for (int r = wave; r < P; r += 4) {
+            const float rm = rowmean[r] + shift;
+#pragma unroll 2
+            for (int c = lane; c < P; c += 64) {
+                const int idx = r * P + c;
+                const float w = Tfd[r * LDT + c] - rm;                     // fd_centred - shift
+                const float cdv = Tcd[r * LDT + c];
+                const float cl = fminf(fmaxf(cdv, cmin), cmax);
+                const float lp = -cl * w;                                  // loss without the old_mean term
+                if (!(prm.debug & 4)) {
+                    cd_out[idx] = cdv;
+                    if (loss_out) loss_out[idx] = lp;
+                    if (w_out) w_out[idx] = w;
+                }
+                loss_part += lp;
+                clamp_part += cl;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        fd_part += __shfl_xor(fd_part, m, 64);
+        loss_part += __shfl_xor(loss_part, m, 64);
+        clamp_part += __shfl_xor(clamp_part, m, 64);
+    }
+    if (lane == 0) { red[wave * 3 + 0] = fd_part; red[wave * 3 + 1] = loss_part; red[wave * 3 + 2] = clamp_part; }
+    __syncthreads();
+    if (tid == 0) {
+        float* st = prm.stats + ((size_t)p * B + b) * 4;
+        st[0] = (red[0] + red[3]) + (red[6] + red[9]);
+        st[1] = (red[1] + red[4]) + (red[7] + red[10]);
+        st[2] = (red[2] + red[5]) + (red[8] + red[11]);
+        st[3] = 0.f;
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams prm, const int stage_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* rowmean = reinterpret_cast<float*>(smem + SD_ROWMEAN);
+    float* red = reinterpret_cast<float*>(smem + SD_RED);
+    unsigned char* stage = smem + SD_BIG;
+    float* Tfd = reinterpret_cast<float*>(smem + SD_BIG);   // epilogue alias of the stage buffers
+    float* Tcd = Tfd + TP * LDT;
+    constexpr int FSIDE = PREC == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_BF16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int B = prm.B;
+    const int tile = blockIdx.x;
+    const int b = tile % B, p = tile / B;       // the 2+n_neg tiles of image b share blockIdx%8: its anchor set is L2-local
+    const bool direct = prm.mode == 1;
+    const bool sameAB = !direct && p == 0;
+    const int sA = b;
+    const int sB = direct ? B + b : (p == 0 ? b : p * B + b);
+    const int NCH = prm.NCH;
+    const int cside = TP * prm.LDK * 4;          // bytes of one code operand (a multiple of 1 KiB)
+    const unsigned char* fsA = static_cast<const unsigned char*>(prm.fs) + (size_t)sA * NCH * FSIDE;
+    const unsigned char* fsB = static_cast<const unsigned char*>(prm.fs) + (size_t)sB * NCH * FSIDE;
+    const unsigned char* csA = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sA * cside;
+    const unsigned char* csB = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sB * cside;
+
+    auto issue = [&](int t) {
+        unsigned char* dst = stage + (t & 1) * stage_bytes;
+        if (t < NCH) {
+            issue_copy(fsA + (size_t)t * FSIDE, dst, FSIDE / 1024, wave, lane);
+            if (!sameAB) issue_copy(fsB + (size_t)t * FSIDE, dst + FSIDE, FSIDE / 1024, wave, lane);
+        } else {
+            issue_copy(csA, dst, cside / 1024, wave, lane);
+            if (!sameAB) issue_copy(csB, dst + cside, cside / 1024, wave, lane);
+        }
+    };
+
+    f32x16 accf[2][2], accc[2][2];
+    zero_acc(accf);
+    zero_acc(accc);
+    const int T = NCH + 1;                       // feature chunks, then the whole code operand pair
+    if (!(prm.debug & 2)) issue(0);
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();                         // (waits vmcnt(0)) chunk t has landed; everyone is done with chunk t-1
+        if (t + 1 < T && !(prm.debug & 2)) issue(t + 1);
+        if (prm.debug & 1) continue;
+        const unsigned char* Ab = stage + (t & 1) * stage_bytes;
+        if (t < NCH) {
+            const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
+            const int kc = min(KC, prm.C - t * KC);
+            if constexpr (PREC == PREC_F32)
+                mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), (kc + 7) & ~7, accf, lane, wr, wc);
+            else
+                mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), (kc + 15) & ~15, accf, lane, wr, wc);
+        } else {
+            const unsigned char* Bb = sameAB ? Ab : Ab + cside;
+            mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
+        }
+    }
+    __syncthreads();                             // stage buffers are dead: park the result tiles over them
+    park_plain(accf, Tfd, lane, wr, wc);
+    park_plain(accc, Tcd, lane, wr, wc);
+    __syncthreads();
+    tile_epilogue_dense(prm, Tfd, Tcd, rowmean, red, p, b, direct);
 }
 
 // Applies the batch-global mean of each pair-set:  old_mean_p = mean_{b,hw,ij} fd  (modules.py:331),
@@ -533,31 +624,47 @@ static hipError_t launch_one(K kernel, int lds, bool& attr_done, const CorrParam
         return launch_one(KERNEL, LDS, done, prm, THREADS, stream);                \
     } while (0)
 
-template <int PREC>
-static hipError_t launch_ws(const CorrParams& prm, int vf, int vc, hipStream_t stream)
+// bytes of one stage buffer of the dense kernel: max(feature chunk pair, code operand pair)
+int dense_stage_bytes(int precision, int LDK)
 {
-    constexpr int LDS = PREC == PREC_F32 ? SW_TOTAL_F32 : SW_TOTAL_BF16;
-    if (vf == 4) {
-        if (vc == 4) STEGO_LAUNCH((corr_fwd_ws_kernel<4, 4, PREC>), LDS, 512);
-        if (vc == 2) STEGO_LAUNCH((corr_fwd_ws_kernel<4, 2, PREC>), LDS, 512);
-        STEGO_LAUNCH((corr_fwd_ws_kernel<4, 1, PREC>), LDS, 512);
-    }
-    if (vc == 4) STEGO_LAUNCH((corr_fwd_ws_kernel<1, 4, PREC>), LDS, 512);
-    if (vc == 2) STEGO_LAUNCH((corr_fwd_ws_kernel<1, 2, PREC>), LDS, 512);
-    STEGO_LAUNCH((corr_fwd_ws_kernel<1, 1, PREC>), LDS, 512);
+    const int f = 2 * (precision == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_BF16);
+    const int c = 2 * TP * LDK * 4;
+    return f > c ? f : c;
 }
 
-hipError_t launch_corr_fwd_main(const CorrParams& prm, int precision, int variant, hipStream_t stream)
+int dense_lds_bytes(int precision, int LDK)
+{
+    const int st = 2 * dense_stage_bytes(precision, LDK);
+    return SD_BIG + (st > SM_TILES_BYTES ? st : SM_TILES_BYTES);
+}
+
+hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream)
+{
+    const int stage = dense_stage_bytes(precision, prm.LDK);
+    const int lds = dense_lds_bytes(precision, prm.LDK);
+    static int attr_f32 = 0, attr_bf16 = 0;
+    int& have = precision == PREC_F32 ? attr_f32 : attr_bf16;
+    const void* fn = precision == PREC_F32 ? reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32>)
+                                           : reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3>);
+    if (have < lds) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        have = lds;
+    }
+    const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
+    if (precision == PREC_F32) hipLaunchKernelGGL((corr_tile_kernel<PREC_F32>), grid, block, lds, stream, prm, stage);
+    else hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3>), grid, block, lds, stream, prm, stage);
+    return hipGetLastError();
+}
+
+// the fused-gather cross-check kernel (f32 only)
+hipError_t launch_corr_fwd_simple(const CorrParams& prm, hipStream_t stream)
 {
     const int vf = pick_vec(prm.feats, prm.feats_pos, prm.C, false);
     const int vc = pick_vec(prm.code, prm.code_pos, prm.K, true);
-    if (variant == 0 && precision == PREC_F32) {      // simple cross-check kernel
-        if (vf == 4 && vc == 4) STEGO_LAUNCH((corr_fwd_kernel<4, 4>), SM_FWD_TOTAL, NTHREADS);
-        if (vf == 4 && vc == 2) STEGO_LAUNCH((corr_fwd_kernel<4, 2>), SM_FWD_TOTAL, NTHREADS);
-        STEGO_LAUNCH((corr_fwd_kernel<1, 1>), SM_FWD_TOTAL, NTHREADS);
-    }
-    if (precision == PREC_BF16X3) return launch_ws<PREC_BF16X3>(prm, vf, vc, stream);
-    return launch_ws<PREC_F32>(prm, vf, vc, stream);
+    if (vf == 4 && vc == 4) STEGO_LAUNCH((corr_fwd_kernel<4, 4>), SM_FWD_TOTAL, NTHREADS);
+    if (vf == 4 && vc == 2) STEGO_LAUNCH((corr_fwd_kernel<4, 2>), SM_FWD_TOTAL, NTHREADS);
+    STEGO_LAUNCH((corr_fwd_kernel<1, 1>), SM_FWD_TOTAL, NTHREADS);
 }
 
 // finalize: block 0 writes scalars; the rest fix the loss tensors of the sets that output one
@@ -572,13 +679,6 @@ hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream)
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(corr_finalize_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, prm);
     return hipGetLastError();
-}
-
-hipError_t launch_corr_fwd(const CorrParams& prm, int precision, int variant, hipStream_t stream)
-{
-    hipError_t e = launch_corr_fwd_main(prm, precision, variant, stream);
-    if (e != hipSuccess) return e;
-    return launch_corr_finalize(prm, stream);
 }
 
 }  // namespace stego

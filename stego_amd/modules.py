@@ -85,20 +85,21 @@ class _CorrLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
         need_grad = bool(code.requires_grad or code_pos.requires_grad)
-        (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean) = _backend.corr_fwd(
+        (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved) = _backend.corr_fwd(
             desc, feats.detach(), feats_pos.detach(), code.detach(), code_pos.detach(), coords1, coords2, perms,
             need_grad)
         ctx.desc = desc
         if need_grad:
-            ctx.save_for_backward(code, code_pos, coords1, coords2, perms, saved_w, saved_mean,
-                                  intra_cd, inter_cd, neg_cd)
+            ctx.n_saved = len(saved)
+            ctx.save_for_backward(code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd, *saved)
         return loss_means[0], intra_cd, loss_means[1], inter_cd, neg_loss, neg_cd
 
     @staticmethod
     def backward(ctx, g_intra, g_intra_cd, g_inter, g_inter_cd, g_neg_loss, g_neg_cd):
-        (code, code_pos, coords1, coords2, perms, saved_w, saved_mean, intra_cd, inter_cd, neg_cd) = ctx.saved_tensors
+        code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd = ctx.saved_tensors[:8]
+        saved = tuple(ctx.saved_tensors[8:])
         d_code, d_code_pos = _backend.corr_bwd(ctx.desc, code.detach(), code_pos.detach(), coords1, coords2, perms,
-                                               saved_w, saved_mean, intra_cd, inter_cd, neg_cd,
+                                               saved, intra_cd, inter_cd, neg_cd,
                                                g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd)
         return (None, None,
                 d_code if ctx.needs_input_grad[2] else None,
@@ -112,17 +113,16 @@ class _HelperFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f1, f2, c1, c2, desc):
         need_grad = bool(c1.requires_grad or c2.requires_grad)
-        loss, cd, saved_w, saved_mean = _backend.helper_fwd(desc, f1.detach(), f2.detach(), c1.detach(), c2.detach(),
-                                                            need_grad)
+        loss, cd, saved = _backend.helper_fwd(desc, f1.detach(), f2.detach(), c1.detach(), c2.detach(), need_grad)
         ctx.desc = desc
         if need_grad:
-            ctx.save_for_backward(c1, c2, saved_w, saved_mean, cd)
+            ctx.save_for_backward(c1, c2, cd, *saved)
         return loss, cd
 
     @staticmethod
     def backward(ctx, g_loss, g_cd):
-        c1, c2, saved_w, saved_mean, cd = ctx.saved_tensors
-        d1, d2 = _backend.helper_bwd(ctx.desc, c1.detach(), c2.detach(), saved_w, saved_mean, cd, g_loss, g_cd)
+        c1, c2, cd = ctx.saved_tensors[:3]
+        d1, d2 = _backend.helper_bwd(ctx.desc, c1.detach(), c2.detach(), tuple(ctx.saved_tensors[3:]), cd, g_loss, g_cd)
         return (None, None, d1 if ctx.needs_input_grad[2] else None, d2 if ctx.needs_input_grad[3] else None, None)
 
 

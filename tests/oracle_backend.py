@@ -33,17 +33,16 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
                               list(_np(perms)) if desc.n_neg else [], cfg)
     S = desc.S
     loss_means = _t(np.array([out.pos_intra_loss, out.pos_inter_loss]), feats)
-    saved_w = saved_mean = None
+    saved = None
     if need_grad:   # opaque to the host layer; keep what our corr_bwd below needs
-        saved_w = _t(np.zeros(1), feats)
-        saved_mean = _t(np.zeros(1), feats)
+        saved = (_t(np.zeros(1), feats), _t(np.zeros(1), feats), _t(np.zeros(1), feats))
         corr_fwd.stash = (_np(feats), _np(feats_pos))
     return (loss_means, _t(out.pos_intra_cd, feats), _t(out.pos_inter_cd, feats),
             _t(out.neg_inter_loss.reshape(-1, S, S, S, S), feats), _t(out.neg_inter_cd.reshape(-1, S, S, S, S), feats),
-            saved_w, saved_mean)
+            saved)
 
 
-def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved_w, saved_mean, intra_cd, inter_cd, neg_cd,
+def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, inter_cd, neg_cd,
              g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd):
     calls.append("corr_bwd")
     cfg = _cfg_from_desc(desc)
@@ -65,11 +64,10 @@ def helper_fwd(desc, f1, f2, c1, c2, need_grad):
     loss, cd, fd = O.helper(_np(f1).astype(np.float64), _np(f2).astype(np.float64), _np(c1).astype(np.float64),
                             _np(c2).astype(np.float64), desc.pos_intra_shift, cfg)
     helper_fwd.stash = (fd, cd)
-    return _t(loss, f1), _t(cd, f1), (_t(np.zeros(1), f1) if need_grad else None), \
-        (_t(np.zeros(1), f1) if need_grad else None)
+    return _t(loss, f1), _t(cd, f1), ((_t(np.zeros(1), f1),) * 3 if need_grad else None)
 
 
-def helper_bwd(desc, c1, c2, saved_w, saved_mean, cd, g_loss, g_cd):
+def helper_bwd(desc, c1, c2, saved, cd, g_loss, g_cd):
     calls.append("helper_bwd")
     cfg = _cfg_from_desc(desc)
     fd, cdv = helper_fwd.stash

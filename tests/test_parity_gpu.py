@@ -176,7 +176,7 @@ def test_cfg4_vitb_shape_against_oracle():
     dict(B=1, C=8, H=4, W=4, K=4, S=1, n_neg=1),        # single sample point, B=1 (perm = [0])
     dict(B=2, C=5, H=3, W=9, K=3, S=2, n_neg=3),        # odd channel counts -> scalar gather path
     dict(B=5, C=130, H=7, W=6, K=66, S=7, n_neg=2),     # C, K straddle the 64-wide chunk
-    dict(B=3, C=64, H=1, W=1, K=80, S=3, n_neg=1),      # 1x1 map (every tap clamps), K at the bwd limit
+    dict(B=3, C=64, H=1, W=1, K=72, S=3, n_neg=1),      # 1x1 map (every tap clamps), K at the limit
     dict(B=2, C=16, H=5, W=5, K=2, S=11, n_neg=0),      # no negatives
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])

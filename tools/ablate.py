@@ -27,24 +27,28 @@ def main():
         os.environ["STEGO_FWD_VARIANT"] = str(variant)
         os.environ["STEGO_DEBUG"] = str(debug)
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
-        tm = tf = 0.0
+        ts = tm = tf = 0.0
         n = 0
         for r in range(4):
             for d in sets:
-                m, f = capi.corr_fwd_profile(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"],
-                                             d["coords2"], d["perms"], True, 1)
+                k0, m, f = capi.corr_fwd_profile(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"],
+                                                 d["coords2"], d["perms"], True, 1)
                 if r > 0:
-                    tm += m; tf += f; n += 1
-        return tm / n * 1e3, tf / n * 1e3
+                    ts += k0; tm += m; tf += f; n += 1
+        return ts / n * 1e3, tm / n * 1e3, tf / n * 1e3
 
     for prec, pname in ((capi.PREC_F32, "f32"), (capi.PREC_BF16X3, "bf16x3")):
         for variant in (0, 1):
             if variant == 0 and prec != capi.PREC_F32:
                 continue
-            for debug, dname in ((0, "full"), (1, "no-mfma"), (2, "no-gather"), (3, "epilogue-only")):
+            abl = ((0, "full"), (1, "no-mfma"), (2, "no-loads"), (3, "epilogue-only"))
+            if variant == 1:
+                abl = abl + ((4, "full-no-stores"), (8, "no elementwise pass"), (3 + 8, "park+rowmean only"))
+            for debug, dname in abl:
                 try:
-                    m, f = fwd_time(prec, variant, debug)
-                    rec = dict(prec=pname, variant=variant, ablation=dname, main_us=round(m, 2), finalize_us=round(f, 2))
+                    k0, m, f = fwd_time(prec, variant, debug)
+                    rec = dict(prec=pname, variant=variant, ablation=dname, sample_us=round(k0, 2), main_us=round(m, 2),
+                               finalize_us=round(f, 2))
                 except Exception as e:  # noqa: BLE001
                     rec = dict(prec=pname, variant=variant, ablation=dname, error=str(e))
                 out["fwd"].append(rec)
@@ -66,10 +70,10 @@ def main():
         ts = []
         for r in range(4):
             for d, o in zip(sets, fw):
-                lm, icd, ecd, nl, ncd, sw, sm = o
+                lm, icd, ecd, nl, ncd, saved = o
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], sw, sm, icd, ecd,
+                capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved, icd, ecd,
                               ncd, g_intra, g_inter, g_neg, None, None, None)
                 e1.record()
                 torch.cuda.synchronize()
