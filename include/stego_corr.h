@@ -86,10 +86,12 @@ const char* stego_error_string(int code);
  *   saved_ctx : what the forward leaves for the backward of the CODE side (normalised sampled codes,
  *               their norms and the bilinear tap tables); pass NULL to the forward when no backward
  *               will follow (the data then lives in the workspace). */
-size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc);
-size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc);
+size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc);          /* forward scratch  */
+size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc);          /* forward -> backward context */
+size_t stego_corr_bwd_workspace_bytes(const StegoCorrDesc* desc);      /* backward scratch */
 size_t stego_corr_helper_workspace_bytes(const StegoCorrDesc* desc);
 size_t stego_corr_helper_saved_ctx_bytes(const StegoCorrDesc* desc);
+size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
 
 /*
  * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws made by the
@@ -144,19 +146,21 @@ int stego_corr_fwd_profile(const StegoCorrDesc* desc,
 
 /*
  * Backward of the above w.r.t. orig_code / orig_code_pos (what autograd derives through
- * modules.py:335-347,369-391: clamp mask, the two code GEMM adjoints, normalize backward,
- * bilinear scatter-add incl. the orig_code[perm] gather of :385).
+ * modules.py:335-347,369-391: clamp mask, the two code GEMM adjoints, normalize backward, the
+ * adjoint of the bilinear sampling incl. the orig_code[perm] gather of :385).  Two launches, no
+ * global atomics.  Everything about the inputs comes from the forward's saved_w / saved_mean /
+ * saved_ctx and the forward's cd outputs; only perms is passed again.
  *
- *   g_intra, g_inter : device scalars, upstream of loss_means[0], loss_means[1]
+ *   g_intra, g_inter : device scalars, upstream of loss_means[0], loss_means[1] (NULL -> 0)
  *   g_neg_loss       : upstream of neg_inter_loss; g_neg_loss_stride = 1 -> dense
  *                      [n_neg*B,S^4], 0 -> one broadcast device scalar (what .mean() feeds);
  *                      NULL -> zero
  *   g_intra_cd, g_inter_cd, g_neg_cd : optional dense upstreams of the cd outputs (NULL -> 0)
  *   d_code, d_code_pos : OUT, channels-last dense [B,H,W,K] (i.e. grad.permute(0,2,3,1)), overwritten.
+ *   workspace        : stego_corr_bwd_workspace_bytes()
  */
 int stego_corr_bwd(const StegoCorrDesc* desc,
-                   const StegoMap* code, const StegoMap* code_pos,
-                   const float* coords1, const float* coords2, const int64_t* perms,
+                   const int64_t* perms,
                    const float* saved_w, const float* saved_mean, const void* saved_ctx,
                    const float* pos_intra_cd, const float* pos_inter_cd, const float* neg_inter_cd,
                    const float* g_intra, const float* g_inter,
@@ -181,7 +185,6 @@ int stego_corr_helper_fwd(const StegoCorrDesc* desc,
 /* Backward of helper w.r.t. c1, c2 (dense upstreams g_loss / g_cd, either may be NULL).
  * d_c1, d_c2: OUT channels-last dense [N,S1,S2,K], overwritten. */
 int stego_corr_helper_bwd(const StegoCorrDesc* desc,
-                          const StegoMap* c1, const StegoMap* c2,
                           const float* saved_w, const float* saved_mean, const void* saved_ctx, const float* cd,
                           const float* g_loss, const float* g_cd,
                           float* d_c1, float* d_c2,

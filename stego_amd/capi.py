@@ -42,10 +42,12 @@ SIGNATURES = {
     "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
                                + [c_int32, POINTER(c_float)]),
-    "stego_corr_bwd": (c_int32, [_D] + [_M] * 2 + [_P] * 3 + [_P] * 3 + [_P] * 3 + [_P, _P, _P, c_int32] + [_P] * 3
+    "stego_corr_bwd_workspace_bytes": (c_size_t, [_D]),
+    "stego_corr_helper_bwd_workspace_bytes": (c_size_t, [_D]),
+    "stego_corr_bwd": (c_int32, [_D] + [_P] + [_P] * 3 + [_P] * 3 + [_P, _P, _P, c_int32] + [_P] * 3
                        + [_P, _P] + [_P, c_size_t, _P]),
     "stego_corr_helper_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 5 + [_P, c_size_t, _P]),
-    "stego_corr_helper_bwd": (c_int32, [_D] + [_M] * 2 + [_P] * 6 + [_P, _P] + [_P, c_size_t, _P]),
+    "stego_corr_helper_bwd": (c_int32, [_D] + [_P] * 6 + [_P, _P] + [_P, c_size_t, _P]),
 }
 
 _lib = None
@@ -184,8 +186,6 @@ def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, int
     lib = load()
     dev = code.device
     B, K, H, W = desc.B, desc.K, desc.H, desc.W
-    coords1 = _dense(coords1, torch.float32)
-    coords2 = _dense(coords2, torch.float32)
     perms = _dense(perms, torch.int64) if desc.n_neg else None
     stride = 1
     if g_neg_loss is not None and g_neg_loss.numel() > 0:
@@ -202,14 +202,14 @@ def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, int
     g_neg_cd = None if (g_neg_cd is None or g_neg_cd.numel() == 0) else _dense(g_neg_cd, torch.float32)
     d_code = torch.empty(B, H, W, K, dtype=torch.float32, device=dev)
     d_code_pos = torch.empty(B, H, W, K, dtype=torch.float32, device=dev)
-    mc, mcp = _map(code), _map(code_pos)
+    ws = _empty_bytes(lib.stego_corr_bwd_workspace_bytes(byref(desc)), dev)
     with torch.cuda.device(dev):
-        _check(lib.stego_corr_bwd(byref(desc), byref(mc), byref(mcp), _ptr(coords1), _ptr(coords2), _ptr(perms),
+        _check(lib.stego_corr_bwd(byref(desc), _ptr(perms),
                                   _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx),
                                   _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_cd),
                                   _ptr(g_intra), _ptr(g_inter), _ptr(g_neg_loss), stride,
                                   _ptr(g_intra_cd), _ptr(g_inter_cd), _ptr(g_neg_cd),
-                                  _ptr(d_code), _ptr(d_code_pos), None, 0, _stream()))
+                                  _ptr(d_code), _ptr(d_code_pos), _ptr(ws), ws.numel(), _stream()))
     return d_code.permute(0, 3, 1, 2), d_code_pos.permute(0, 3, 1, 2)
 
 
@@ -243,9 +243,9 @@ def helper_bwd(desc, c1, c2, saved, cd, g_loss, g_cd):
     g_cd = None if g_cd is None else _dense(g_cd, torch.float32)
     d1 = torch.empty(N, S1, S2, K, dtype=torch.float32, device=dev)
     d2 = torch.empty(N, S1, S2, K, dtype=torch.float32, device=dev)
-    m1, m2 = _map(c1), _map(c2)
+    ws = _empty_bytes(lib.stego_corr_helper_bwd_workspace_bytes(byref(desc)), dev)
     with torch.cuda.device(dev):
-        _check(lib.stego_corr_helper_bwd(byref(desc), byref(m1), byref(m2), _ptr(saved_w), _ptr(saved_mean),
+        _check(lib.stego_corr_helper_bwd(byref(desc), _ptr(saved_w), _ptr(saved_mean),
                                          _ptr(saved_ctx), _ptr(cd), _ptr(g_loss), _ptr(g_cd), _ptr(d1), _ptr(d2),
-                                         None, 0, _stream()))
+                                         _ptr(ws), ws.numel(), _stream()))
     return d1.permute(0, 3, 1, 2), d2.permute(0, 3, 1, 2)

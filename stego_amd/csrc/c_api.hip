@@ -58,7 +58,7 @@ int check_desc(const StegoCorrDesc* d, bool helper)
 // ---- buffer geometry (all derived from the descriptor)
 struct Geometry {
     int n_roles, nset, NCH, KQ, LDK;
-    size_t stats_bytes, fs_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes;
+    size_t stats_bytes, fs_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
 };
 
 Geometry geometry(const StegoCorrDesc* d, bool helper)
@@ -78,6 +78,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     g.ws_bytes = g.stats_bytes + g.fs_bytes + g.ctx_bytes;
+    g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 4096;
     return g;
 }
 
@@ -90,6 +91,25 @@ int env_int(const char* name, int dflt)
 {
     const char* v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
+}
+
+int fill_bwd_ctx(const StegoCorrDesc* d, bool helper, const void* saved_ctx, void* workspace, size_t workspace_bytes,
+                 BwdParams* prm)
+{
+    const Geometry g = geometry(d, helper);
+    if (!saved_ctx || !workspace) return STEGO_ERR_NULL;
+    if (workspace_bytes < g.bwd_ws_bytes) return STEGO_ERR_WORKSPACE;
+    if ((size_t)d->W * d->K * 4 > 96 * 1024) return STEGO_ERR_UNSUPPORTED;      // one image row must fit the LDS band
+    if (!helper && (size_t)d->n_neg * d->B + d->n_neg + 2 > 1024) return STEGO_ERR_UNSUPPORTED; // unsample contribution table
+    const unsigned char* ctx = static_cast<const unsigned char*>(saved_ctx);
+    prm->cs = reinterpret_cast<const float*>(ctx);
+    prm->nrm = reinterpret_cast<const float*>(ctx + g.cs_bytes);
+    prm->tapyx = reinterpret_cast<const int4*>(ctx + g.cs_bytes + g.nrm_bytes);
+    prm->tapw = reinterpret_cast<const float4*>(ctx + g.cs_bytes + g.nrm_bytes + g.tap_bytes);
+    prm->dt = static_cast<float*>(workspace);
+    prm->KQ = g.KQ;
+    prm->LDK = g.LDK;
+    return STEGO_OK;
 }
 
 struct FwdPlan {
@@ -159,6 +179,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     sp.tapw = reinterpret_cast<float4*>(ctx + g.cs_bytes + g.nrm_bytes + g.tap_bytes);
     sp.B = d->B; sp.C = d->C; sp.K = d->K; sp.H = d->H; sp.W = d->W; sp.S = prm.S; sp.P = prm.P;
     sp.n_roles = g.n_roles; sp.NCH = g.NCH; sp.KQ = g.KQ; sp.LDK = g.LDK; sp.mode = prm.mode;
+    sp.debug = env_int("STEGO_DEBUG_SAMPLE", 0);
 
     out->tile = prm;
     out->samp = sp;
@@ -214,6 +235,18 @@ size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc)
 {
     if (check_desc(desc, false) != STEGO_OK) return 0;
     return geometry(desc, false).ctx_bytes;
+}
+
+size_t stego_corr_bwd_workspace_bytes(const StegoCorrDesc* desc)
+{
+    if (check_desc(desc, false) != STEGO_OK) return 0;
+    return geometry(desc, false).bwd_ws_bytes;
+}
+
+size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc)
+{
+    if (check_desc(desc, true) != STEGO_OK) return 0;
+    return geometry(desc, true).bwd_ws_bytes;
 }
 
 size_t stego_corr_helper_workspace_bytes(const StegoCorrDesc* desc)
@@ -275,25 +308,21 @@ int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const 
     return hip_rc(e);
 }
 
-int stego_corr_bwd(const StegoCorrDesc* d, const StegoMap* code, const StegoMap* code_pos, const float* coords1,
-                   const float* coords2, const int64_t* perms, const float* saved_w, const float* saved_mean,
+int stego_corr_bwd(const StegoCorrDesc* d, const int64_t* perms, const float* saved_w, const float* saved_mean,
                    const void* saved_ctx, const float* pos_intra_cd, const float* pos_inter_cd,
                    const float* neg_inter_cd, const float* g_intra, const float* g_inter, const float* g_neg_loss,
                    int32_t g_neg_loss_stride, const float* g_intra_cd, const float* g_inter_cd, const float* g_neg_cd,
                    float* d_code, float* d_code_pos, void* workspace, size_t workspace_bytes, stego_stream_t stream)
 {
-    (void)workspace; (void)workspace_bytes; (void)saved_ctx;
     (void)hipGetLastError();
     int rc = check_desc(d, false);
     if (rc) return rc;
-    if (!coords1 || !coords2 || !saved_w || !saved_mean || !pos_intra_cd || !pos_inter_cd || !d_code || !d_code_pos)
-        return STEGO_ERR_NULL;
+    if (!saved_w || !saved_mean || !pos_intra_cd || !pos_inter_cd || !d_code || !d_code_pos) return STEGO_ERR_NULL;
     if (d->n_neg > 0 && (!perms || !neg_inter_cd)) return STEGO_ERR_NULL;
     if (g_neg_loss_stride != 0 && g_neg_loss_stride != 1) return STEGO_ERR_SHAPE;
     BwdParams prm{};
-    if ((rc = to_mapv(code, d->K, d->H, d->W, &prm.code))) return rc;
-    if ((rc = to_mapv(code_pos, d->K, d->H, d->W, &prm.code_pos))) return rc;
-    prm.coords1 = coords1; prm.coords2 = coords2; prm.perms = reinterpret_cast<const long long*>(perms);
+    if ((rc = fill_bwd_ctx(d, false, saved_ctx, workspace, workspace_bytes, &prm))) return rc;
+    prm.perms = reinterpret_cast<const long long*>(perms);
     prm.saved_w = saved_w; prm.saved_mean = saved_mean;
     prm.intra_cd = pos_intra_cd; prm.inter_cd = pos_inter_cd; prm.neg_cd = neg_inter_cd;
     prm.g_intra = g_intra; prm.g_inter = g_inter; prm.g_neg_loss = g_neg_loss;
@@ -305,13 +334,7 @@ int stego_corr_bwd(const StegoCorrDesc* d, const StegoMap* code, const StegoMap*
     prm.debug = env_int("STEGO_DEBUG_BWD", 0);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = (size_t)d->B * d->H * d->W * d->K * sizeof(float);
-    hipError_t e = hipMemsetAsync(d_code, 0, bytes, s);
-    if (e != hipSuccess) return hip_rc(e);
-    e = hipMemsetAsync(d_code_pos, 0, bytes, s);
-    if (e != hipSuccess) return hip_rc(e);
-    return hip_rc(launch_corr_bwd(prm, s));
+    return hip_rc(launch_corr_bwd(prm, static_cast<hipStream_t>(stream)));
 }
 
 int stego_corr_helper_fwd(const StegoCorrDesc* d, const StegoMap* f1, const StegoMap* f2, const StegoMap* c1,
@@ -325,19 +348,16 @@ int stego_corr_helper_fwd(const StegoCorrDesc* d, const StegoMap* f1, const Steg
     return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr));
 }
 
-int stego_corr_helper_bwd(const StegoCorrDesc* d, const StegoMap* c1, const StegoMap* c2, const float* saved_w,
-                          const float* saved_mean, const void* saved_ctx, const float* cd, const float* g_loss,
-                          const float* g_cd, float* d_c1, float* d_c2, void* workspace, size_t workspace_bytes,
-                          stego_stream_t stream)
+int stego_corr_helper_bwd(const StegoCorrDesc* d, const float* saved_w, const float* saved_mean,
+                          const void* saved_ctx, const float* cd, const float* g_loss, const float* g_cd, float* d_c1,
+                          float* d_c2, void* workspace, size_t workspace_bytes, stego_stream_t stream)
 {
-    (void)workspace; (void)workspace_bytes; (void)saved_ctx;
     (void)hipGetLastError();
     int rc = check_desc(d, true);
     if (rc) return rc;
     if (!saved_w || !saved_mean || !cd || !d_c1 || !d_c2) return STEGO_ERR_NULL;
     BwdParams prm{};
-    if ((rc = to_mapv(c1, d->K, d->H, d->W, &prm.code))) return rc;
-    if ((rc = to_mapv(c2, d->K, d->H, d->W, &prm.code_pos))) return rc;
+    if ((rc = fill_bwd_ctx(d, true, saved_ctx, workspace, workspace_bytes, &prm))) return rc;
     prm.saved_w = saved_w; prm.saved_mean = saved_mean; prm.neg_cd = cd;
     prm.g_neg_loss = g_loss; prm.g_neg_loss_stride = 1; prm.g_neg_cd = g_cd;
     prm.d_code = d_c1; prm.d_code_pos = d_c2;
@@ -346,13 +366,7 @@ int stego_corr_helper_bwd(const StegoCorrDesc* d, const StegoMap* c1, const Steg
     prm.debug = env_int("STEGO_DEBUG_BWD", 0);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = (size_t)d->B * d->H * d->W * d->K * sizeof(float);
-    hipError_t e = hipMemsetAsync(d_c1, 0, bytes, s);
-    if (e != hipSuccess) return hip_rc(e);
-    e = hipMemsetAsync(d_c2, 0, bytes, s);
-    if (e != hipSuccess) return hip_rc(e);
-    return hip_rc(launch_corr_bwd(prm, s));
+    return hip_rc(launch_corr_bwd(prm, static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

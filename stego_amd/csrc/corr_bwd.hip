@@ -1,38 +1,38 @@
 // Backward of STEGO's ContrastiveCorrelationLoss w.r.t. orig_code / orig_code_pos (gfx950).
 //
-// One workgroup per (pair-set p, image b) tile, same tiling as the forward:
-//   G[hw][ij]  = dL/dcd = g_cd + g_loss * (-(fd_final - shift)) * 1[cmin <= cd <= cmax]   (clamp/mul backward)
-//   dAn = G . Bn          dBn = G^T . An          (the two bmm adjoints; An/Bn = normalised sampled codes)
-//   dA  = (dAn - An <An,dAn>) / ||a||             (F.normalize backward), likewise dB
-//   scatter-add dA/dB through the 4 bilinear taps into d_code (grid_sampler_2d_backward;
-//   negatives land in d_code[perm[b]] = the index_put of orig_code[perm], modules.py:385)
-// GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32).  Scatter uses hardware fp32 atomics into a
-// channels-last gradient buffer (a point's K channels are one contiguous 4*K-byte run).
+// Two launches, no global atomics, no memsets:
+//
+// 1. corr_bwd_tile_kernel - one workgroup per (pair-set p, image b) tile, same tiling as the forward:
+//      G[hw][ij]  = dL/dcd = g_cd + g_loss * (-(fd_final - shift)) * 1[cmin <= cd <= cmax]   (clamp/mul backward)
+//      dAn = G . Bn          dBn = G^T . An          (the two bmm adjoints; An/Bn = normalised sampled codes,
+//                                                      re-used from the forward's saved context: no re-gather)
+//      dA  = (dAn - An <An,dAn>) / ||a||             (F.normalize backward), likewise dB
+//    GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32).  Output: per (tile, side) the gradient w.r.t. the RAW
+//    sampled codes, DT[tile][side][128][LDK].
+//
+// 2. corr_unsample_kernel - the adjoint of the bilinear sampling (grid_sampler_2d_backward) and of the
+//    orig_code[perm] gather (index_put, modules.py:385) written as a GATHER: one workgroup owns a band of
+//    rows of one destination image, walks every sample set that reads that image (anchor role: all
+//    pair-sets of the image; negative roles: the (i,b) with perm_i[b] == image), and accumulates the
+//    4-tap contributions in an LDS copy of the band with ds_add_f32; the band is then stored once.
+//
+// The first version of this backward scattered with 15 M global fp32 atomics (93 of its 136 us).
 //
 // Reference: autograd through src/modules.py:335-347, 369-391.
 #include "corr_common.h"
 
 namespace stego {
 
-constexpr int LDC = 80;    // code tile row stride (K <= 80)
-constexpr int LDG = 130;   // G row stride
-constexpr int SMB_NRM = 0;                         // float nrm[2][128]
-constexpr int SMB_RED = SMB_NRM + 2 * TP * 4;      // float red[64]
-constexpr int SMB_TAPYX = SMB_RED + 64 * 4;        // int4 [256] packed pixel coords
-constexpr int SMB_TAPW = SMB_TAPYX + 256 * 16;     // float4 [256]
-constexpr int SMB_CA = SMB_TAPW + 256 * 16;        // float [128][80]
-constexpr int SMB_CB = SMB_CA + TP * LDC * 4;      // float [128][80]
-constexpr int SMB_G = SMB_CB + TP * LDC * 4;       // float [128][130]; first 4 KB doubles as gather offsets
-constexpr int SMB_TOTAL = SMB_G + TP * LDG * 4;
-static_assert(SMB_TOTAL <= 160 * 1024, "LDS budget");
+constexpr int LDG = 130;   // G row stride (floats)
+constexpr int SMB_NRM = 0;                          // float nrm[2][128]
+constexpr int SMB_AN = SMB_NRM + 2 * TP * 4;        // float An[128][LDK], then Bn[128][LDK], then G[128][LDG]
 
-// normalize-backward + bilinear scatter of one side's gradient held in MFMA 16x16 C/D layout:
+// normalize-backward of one side's gradient held in MFMA 16x16 C/D layout and store to DT:
 // d[mt][nt][reg] <-> point 32*wave + 16*mt + 4*(lane>>4) + reg, channel 16*nt + (lane&15).
 template <int NT>
-__device__ __forceinline__ void normalize_bwd_scatter(f32x4 (&d)[2][NT], const float* __restrict__ Cn,
-                                                      const float* __restrict__ nrm, const int4* __restrict__ tapyx,
-                                                      const float4* __restrict__ tapw, float* __restrict__ dst_img,
-                                                      int W, int K, int P, int lane, int wave)
+__device__ __forceinline__ void normalize_bwd_store(f32x4 (&d)[2][NT], const float* __restrict__ Cn, int ldk,
+                                                    const float* __restrict__ nrm, float* __restrict__ dt_out,
+                                                    int K, int KQ, int lane, int wave)
 {
     const int cl = lane & 15, rg = lane >> 4;
 #pragma unroll
@@ -40,109 +40,72 @@ __device__ __forceinline__ void normalize_bwd_scatter(f32x4 (&d)[2][NT], const f
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int pt = 32 * wave + 16 * mt + 4 * rg + reg;
+            float cn[NT];
             float dot = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) dot += Cn[pt * LDC + 16 * nt + cl] * d[mt][nt][reg];
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ch = 16 * nt + cl;
+                cn[nt] = ch < K ? Cn[pt * ldk + ch] : 0.f;       // columns >= K hold padding / neighbours
+                dot += cn[nt] * (ch < K ? d[mt][nt][reg] : 0.f);
+            }
 #pragma unroll
             for (int m = 8; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
             const float nr = nrm[pt];
             const bool big = nr > 1e-10f;
             const float inv = 1.f / fmaxf(nr, 1e-10f);
-            if (pt < P) {
-                const int4 yx = tapyx[pt];
-                const float4 w = tapw[pt];
-                const int pix0 = (yx.x >> 16) * W + (yx.x & 0xffff), pix1 = (yx.y >> 16) * W + (yx.y & 0xffff);
-                const int pix2 = (yx.z >> 16) * W + (yx.z & 0xffff), pix3 = (yx.w >> 16) * W + (yx.w & 0xffff);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int ch = 16 * nt + cl;
-                    if (ch < K) {
-                        const float dn = d[mt][nt][reg];
-                        const float dt = big ? (dn - Cn[pt * LDC + ch] * dot) * inv : dn * inv;
-                        if (w.x != 0.f) atomicAdd(dst_img + (size_t)pix0 * K + ch, w.x * dt);
-                        if (w.y != 0.f) atomicAdd(dst_img + (size_t)pix1 * K + ch, w.y * dt);
-                        if (w.z != 0.f) atomicAdd(dst_img + (size_t)pix2 * K + ch, w.z * dt);
-                        if (w.w != 0.f) atomicAdd(dst_img + (size_t)pix3 * K + ch, w.w * dt);
-                    }
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ch = 16 * nt + cl;
+                if (ch < KQ) {
+                    const float dn = d[mt][nt][reg];
+                    float v = big ? (dn - cn[nt] * dot) * inv : dn * inv;
+                    if (ch >= K) v = 0.f;
+                    dt_out[pt * ldk + ch] = v;
                 }
             }
         }
     }
 }
 
-template <int VC, int NT>
-__global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
+template <int NT>
+__global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ldk = prm.LDK;
+    const int cside = TP * ldk * 4;
     float* nrm = reinterpret_cast<float*>(smem + SMB_NRM);
-    int4* tapyx = reinterpret_cast<int4*>(smem + SMB_TAPYX);
-    float4* tapw = reinterpret_cast<float4*>(smem + SMB_TAPW);
-    float* CA = reinterpret_cast<float*>(smem + SMB_CA);
-    float* CB = reinterpret_cast<float*>(smem + SMB_CB);
-    float* G = reinterpret_cast<float*>(smem + SMB_G);
-    int4* tapo = reinterpret_cast<int4*>(smem + SMB_G);     // gather offsets, dead before G is filled
+    unsigned char* An_b = smem + SMB_AN;
+    unsigned char* Bn_b = An_b + cside;
+    float* An = reinterpret_cast<float*>(An_b);
+    float* G = reinterpret_cast<float*>(Bn_b + cside);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int B = prm.B, P = prm.P, K = prm.K;
     const int tile = blockIdx.x;
     const int b = tile % B, p = tile / B;
     const bool direct = prm.mode == 1;
-
-    const bool usePos = direct || p == 1;
     const bool sameAB = !direct && p == 0;
-    const MapV mcA = prm.code;
-    MapV mcB;
-    mcB.p = usePos ? prm.code_pos.p : prm.code.p;
-    mcB.sn = usePos ? prm.code_pos.sn : prm.code.sn;
-    mcB.sc = usePos ? prm.code_pos.sc : prm.code.sc;
-    mcB.sh = usePos ? prm.code_pos.sh : prm.code.sh;
-    mcB.sw = usePos ? prm.code_pos.sw : prm.code.sw;
-    const float* coordsB = (!direct && p >= 1) ? prm.coords2 : prm.coords1;
-    float* dstB = usePos ? prm.d_code_pos : prm.d_code;
-    int imgB = b;
-    if (!direct && p >= 2) imgB = (int)prm.perms[(size_t)(p - 2) * B + b];
+    const int sA = b;
+    const int sB = direct ? B + b : (p == 0 ? b : p * B + b);
+    const float* Bn = sameAB ? An : reinterpret_cast<const float*>(Bn_b);
 
+    // ---- async copies of the normalised sampled codes (saved by the forward) + their norms
     {
-        const int side = tid >> 7, q = tid & (TP - 1);
-        const float* cimg = direct ? nullptr
-                                   : (side == 0 ? prm.coords1 + (size_t)b * P * 2 : coordsB + (size_t)b * P * 2);
-        int4 yx; float4 w;
-        tap_for_point(q, P, prm.S, prm.H, prm.W, direct, cimg, yx, w);
-        tapyx[tid] = yx;
-        tapw[tid] = w;
-        tapo[tid] = taps_to_offsets(yx, side == 0 ? mcA.sh : mcB.sh, side == 0 ? mcA.sw : mcB.sw);
-    }
-    __syncthreads();
-
-    // ---- gather raw sampled codes (K <= 80: one 64-wide chunk + one 16-wide chunk), norms
-    {
-        float ssA[TP * (KC / VC) / NTHREADS], ssB[TP * (KC / VC) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
-        const float* imgA = mcA.p + (long long)b * mcA.sn;
-        const float* imgBp = mcB.p + (long long)imgB * mcB.sn;
-        constexpr int BC = VC == 1 ? 8 : 4;
-        gather_chunk<VC, LDC, PREC_F32, BC>(imgA, mcA.sc, tapo, tapw, 0, K, 64, CA, ssA, tid);
-        gather_chunk<VC, LDC, PREC_F32, BC>(imgA, mcA.sc, tapo, tapw, 64, K, 16, CA + 64, ssA, tid);
-        if (!sameAB) {
-            gather_chunk<VC, LDC, PREC_F32, BC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 0, K, 64, CB, ssB, tid);
-            gather_chunk<VC, LDC, PREC_F32, BC>(imgBp, mcB.sc, tapo + TP, tapw + TP, 64, K, 16, CB + 64, ssB, tid);
+        const unsigned char* srcA = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sA * cside;
+        const unsigned char* srcB = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sB * cside;
+        const int npieces = cside / 1024;
+        for (int pc = wave; pc < npieces; pc += 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + (size_t)pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(An_b + pc * 1024), 16, 0, 0);
+            if (!sameAB)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB + (size_t)pc * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Bn_b + pc * 1024), 16, 0, 0);
         }
-        publish_norms<VC>(ssA, nrm, tid);
-        if (!sameAB) publish_norms<VC>(ssB, nrm + TP, tid);
+        nrm[tid] = prm.nrm[(size_t)(tid < TP ? sA : sB) * TP + (tid & (TP - 1))];
     }
-    __syncthreads();
-    // normalise in place: Cn = raw / max(||raw||, eps)
-    for (int e = tid; e < TP * LDC; e += NTHREADS) {
-        const int r = e / LDC;
-        CA[e] *= 1.f / fmaxf(nrm[r], 1e-10f);
-        if (!sameAB) CB[e] *= 1.f / fmaxf(nrm[TP + r], 1e-10f);
-    }
-    const float* CBn = sameAB ? CA : CB;
-    const float* nrmB = sameAB ? nrm : nrm + TP;
-    __syncthreads();    // tapo (aliased on G) is dead from here
 
-    // ---- G tile: row-wise, branch-free, 8 loads x up to 4 arrays in flight per lane.
+    // ---- G tile: row-wise, branch-free, many loads in flight per lane.
     // Upstreams are folded into (pointer, index multiplier, scale) triples so that absent / broadcast
     // gradients need no branches: g = -(w + old_mean) * gl * 1[cmin<=cd<=cmax] + gc.
     {
@@ -179,7 +142,6 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
                 for (int h = 0; h < 2; ++h) {
                     const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
                     const int idx = min(r, P - 1) * P + min(c, P - 1);
-                    if (prm.debug & 4) { cdv[j][h] = 0.5f; wv[j][h] = 0.1f; glv[j][h] = 1.f; gcv[j][h] = 0.f; continue; }
                     cdv[j][h] = cdp[idx];
                     wv[j][h] = wp[idx];
                     glv[j][h] = glp[idx * gl_mul];
@@ -197,7 +159,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
                 }
         }
     }
-    __syncthreads();
+    __syncthreads();       // (vmcnt(0)) An/Bn landed, G complete
 
     // ---- dAn = G . Bn  and  dBn = G^T . An   on v_mfma_f32_16x16x4_f32
     // operand lane map: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
@@ -218,8 +180,8 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
             gt[1] = G[k * LDG + row0 + 16];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                bn[nt] = CBn[k * LDC + 16 * nt + cl];
-                an[nt] = CA[k * LDC + 16 * nt + cl];
+                bn[nt] = Bn[k * ldk + 16 * nt + cl];
+                an[nt] = An[k * ldk + 16 * nt + cl];
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -231,72 +193,236 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_kernel(const BwdParams prm)
         }
     }
 
-    // ---- normalize backward + scatter
-    const size_t img_elems = (size_t)prm.H * prm.W * K;
+    // ---- normalize backward -> DT[tile][side]
     if (sameAB) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dA[mt][nt] += dB[mt][nt];   // c1 is c2: both adjoints hit the same samples
     }
-    if (prm.debug & 2) {       // measurement ablation: keep the GEMM results alive, skip the scatter
-        float keep = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) keep += dA[mt][nt][0] + dB[mt][nt][1];
-        if (keep == 123.456f) prm.d_code[0] = keep;
-        return;
-    }
-    normalize_bwd_scatter<NT>(dA, CA, nrm, tapyx, tapw, prm.d_code + (size_t)b * img_elems, prm.W, K, P, lane, wave);
+    float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
+    normalize_bwd_store<NT>(dA, An, ldk, nrm, dtA, K, prm.KQ, lane, wave);
     if (!sameAB)
-        normalize_bwd_scatter<NT>(dB, CBn, nrmB, tapyx + TP, tapw + TP, dstB + (size_t)imgB * img_elems, prm.W, K, P,
-                                  lane, wave);
+        normalize_bwd_store<NT>(dB, Bn, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
 }
 
-template <int VC>
-static hipError_t launch_bwd_nt(const BwdParams& prm, int nt, dim3 grid, hipStream_t stream)
+// ------------------------------------------------------------------------------- unsample
+// grid = n_dest(2) * B * n_bands ; block = 512 (8 waves); a band has RT <= 8 pixel rows and WAVE r OWNS ROW r.
+// LDS: float acc[RT][W][K] | contribution table | per-row worklists | counters.
+// Per round, 4 contributions x 128 points are tested lane-parallel; every tap row that falls in the band
+// appends a 16-byte row-entry {DT row, x0|x1, w0, w1} to the list of that pixel row.  The owning wave then
+// drains its list: 16 DT rows in flight per lane, plain LDS read-modify-write (LDS fp32 atomics measured
+// ~1000 cycles per wave-instruction on gfx950, so they are used only on worklist overflow).
+constexpr int UNS_THREADS = 512;
+constexpr int UNS_SETS_PER_ROUND = UNS_THREADS / TP;      // 4
+constexpr int UNS_MAX_RT = 8;
+constexpr int UNS_ROW_CAP = 192;                          // row-entries per pixel row per round (expected ~35)
+constexpr int UNS_MAX_CONTRIB = 1024;
+
+struct UnsRowEntry {        // 16 bytes
+    int dtoff;              // float offset of the DT row
+    int x01;                // x0 | x1 << 16
+    float wa, wb;           // tap weights at (row, x0), (row, x1)
+};
+
+__global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdParams prm, const int RT, const int n_bands,
+                                                                   const int acc_bytes)
 {
-#define STEGO_BWD_CASE(N)                                                                                         \
-    case N: {                                                                                                     \
-        static bool done = false;                                                                                 \
-        if (!done) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_kernel<VC, N>),            \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMB_TOTAL);            \
-            if (e != hipSuccess) return e;                                                                        \
-            done = true;                                                                                          \
-        }                                                                                                         \
-        hipLaunchKernelGGL((corr_bwd_kernel<VC, N>), grid, dim3(NTHREADS), SMB_TOTAL, stream, prm);               \
-        break;                                                                                                    \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* acc = reinterpret_cast<float*>(smem);
+    int* ctab = reinterpret_cast<int*>(smem + acc_bytes);                               // [UNS_MAX_CONTRIB]
+    UnsRowEntry* wl = reinterpret_cast<UnsRowEntry*>(smem + acc_bytes + UNS_MAX_CONTRIB * 4);   // [UNS_MAX_RT][UNS_ROW_CAP]
+    int* cnt = reinterpret_cast<int*>(smem + acc_bytes + UNS_MAX_CONTRIB * 4 + UNS_MAX_RT * UNS_ROW_CAP * (int)sizeof(UnsRowEntry));
+    int& s_nc = cnt[UNS_MAX_RT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int B = prm.B, P = prm.P, K = prm.K, W = prm.W, H = prm.H, ldk = prm.LDK;
+    const bool direct = prm.mode == 1;
+    int bid = blockIdx.x;
+    const int band = bid % n_bands; bid /= n_bands;
+    const int j = bid % B;
+    const int dest = bid / B;                        // 0: d_code (d_c1), 1: d_code_pos (d_c2)
+    const int r0 = band * RT, r1 = min(H, r0 + RT);
+    const int band_elems = (r1 - r0) * W * K;
+    const int side_elems = TP * ldk;
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * side_elems);
+    const bool stamp_on = (prm.debug & 8) && blockIdx.x == 5 && tid == 0;
+    int sti = 0;
+    if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
+    for (int e = tid; e < band_elems; e += UNS_THREADS) acc[e] = 0.f;
+
+    // ---- contribution table: every contribution is (taps of sample set s, DT matrix (tile, side)).
+    //   own role of image j, entries [0, n_own):
+    //       dest 0: anchor set j with the A side of EVERY pair-set tile (p, j)      -> n_own = n_sets
+    //       dest 1: positive set B+j with the B side of tile (1, j); helper: set dest*B+j, tile j, side dest
+    //   then (dest 0 only) the negative sets (2+i)*B+b with perm_i[b] == j, B side of their own tile
+    //   (the index_put of orig_code[perm], modules.py:385).   ctab[c] holds the set id of entry c >= n_own.
+    const int n_own = (!direct && dest == 0) ? prm.n_sets : 1;
+    if (wave == 0) {
+        int nc = n_own;
+        if (!direct && dest == 0) {
+            for (int i = 0; i < prm.n_neg; ++i)
+                for (int b0 = 0; b0 < B; b0 += 64) {
+                    const int bb = b0 + lane;
+                    const bool m = bb < B && (int)prm.perms[(size_t)i * B + bb] == j;
+                    const unsigned long long mask = __ballot(m);
+                    const int pre = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (m && nc + pre < UNS_MAX_CONTRIB) ctab[nc + pre] = (2 + i) * B + bb;
+                    nc += __builtin_popcountll(mask);
+                }
+            if (nc > UNS_MAX_CONTRIB) nc = UNS_MAX_CONTRIB;        // (cannot happen: host checks n_sets + n_neg*B <= 1024)
+        }
+        if (lane == 0) s_nc = nc;
     }
-    switch (nt) {
-        STEGO_BWD_CASE(1)
-        STEGO_BWD_CASE(2)
-        STEGO_BWD_CASE(3)
-        STEGO_BWD_CASE(4)
-        default:
-        STEGO_BWD_CASE(5)
+    __syncthreads();
+    const int NC = s_nc;
+    if (stamp_on) { ts[sti++] = __builtin_amdgcn_s_memtime(); ts[30] = NC; }
+
+    for (int c0 = 0; c0 < NC; c0 += UNS_SETS_PER_ROUND) {
+        if (tid < UNS_MAX_RT) cnt[tid] = 0;
+        __syncthreads();
+        // ---- phase 1: thread -> (contribution c0 + tid/128, point tid%128): band test, append row-entries
+        {
+            const int c = c0 + (tid >> 7), q = tid & (TP - 1);
+            if (c < NC && q < P && !(prm.debug & 2)) {
+                int s, tile0, side;
+                if (c < n_own) {
+                    if (direct) { s = dest * B + j; tile0 = j; side = dest; }
+                    else if (dest == 1) { s = B + j; tile0 = B + j; side = 1; }
+                    else { s = j; tile0 = c * B + j; side = 0; }
+                } else { s = ctab[c]; tile0 = s; side = 1; }
+                const int4 yx = prm.tapyx[(size_t)s * TP + q];
+                const float4 w = prm.tapw[(size_t)s * TP + q];
+                const int dtoff = (tile0 * 2 + side) * side_elems + q * ldk;
+#pragma unroll
+                for (int hrow = 0; hrow < 2; ++hrow) {
+                    const int y = (hrow ? yx.z : yx.x) >> 16;
+                    const float wa = hrow ? w.z : w.x, wb = hrow ? w.w : w.y;
+                    if (y < r0 || y >= r1 || (wa == 0.f && wb == 0.f)) continue;
+                    if (hrow == 1 && y == (yx.x >> 16)) continue;          // clamped second row: weights are 0 anyway
+                    const int xa = (hrow ? yx.z : yx.x) & 0xffff, xb = (hrow ? yx.w : yx.y) & 0xffff;
+                    const int row = y - r0;
+                    const int slot = atomicAdd(&cnt[row], 1);
+                    if (slot < UNS_ROW_CAP) {
+                        UnsRowEntry e;
+                        e.dtoff = dtoff; e.x01 = xa | (xb << 16); e.wa = wa; e.wb = wb;
+                        wl[row * UNS_ROW_CAP + slot] = e;
+                    } else {
+                        // overflow (pathological coords, e.g. every point on one row): slow but correct path
+                        for (int ch = 0; ch < K; ++ch) {
+                            const float v = prm.dt[dtoff + ch];
+                            if (wa != 0.f) atomicAdd(&acc[(row * W + xa) * K + ch], wa * v);
+                            if (wb != 0.f) atomicAdd(&acc[(row * W + xb) * K + ch], wb * v);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (stamp_on) { ts[sti++] = __builtin_amdgcn_s_memtime(); ts[24 + (c0 >> 2)] = cnt[0]; }
+        // ---- phase 2: wave r drains the list of pixel row r (lanes = channels, second pass for channels >= 64)
+        if (wave < r1 - r0) {
+            const int count = min(cnt[wave], UNS_ROW_CAP);
+            const UnsRowEntry* list = wl + wave * UNS_ROW_CAP;
+            float* arow = acc + wave * W * K;
+            constexpr int UB = 16;
+            // branch-free: lanes without a channel (and clamped second taps) are redirected to a per-lane
+            // dummy cell behind the band, so every load / read-modify-write is unconditional
+            const int cA = min(lane, K - 1), cB = min(64 + lane, K - 1);
+            const bool hasA = lane < K, hasB = 64 + lane < K;
+            float* dummy = acc + (acc_bytes >> 2) - 4 * 64 + lane;
+            for (int e0 = 0; e0 < count; e0 += UB) {
+                float v0[UB], v1[UB], wa[UB], wb[UB];
+                int x01[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const UnsRowEntry en = list[min(e0 + u, count - 1)];
+                    const bool on = e0 + u < count;
+                    x01[u] = en.x01; wa[u] = on ? en.wa : 0.f; wb[u] = on ? en.wb : 0.f;
+                    v0[u] = prm.dt[en.dtoff + cA];
+                    v1[u] = prm.dt[en.dtoff + cB];
+                }
+                if (!(prm.debug & 16)) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        // the (up to) 4 cells of one row-entry are distinct: read all, then write all
+                        const int xa = x01[u] & 0xffff, xb = x01[u] >> 16;
+                        const bool two = xb != xa;                 // clamped tap (xb == xa) carries weight 0
+                        float* pa0 = hasA ? arow + xa * K + lane : dummy;
+                        float* pb0 = (hasA && two) ? arow + xb * K + lane : dummy + 64;
+                        float* pa1 = hasB ? arow + xa * K + 64 + lane : dummy + 128;
+                        float* pb1 = (hasB && two) ? arow + xb * K + 64 + lane : dummy + 192;
+                        const float a0 = *pa0, b0 = *pb0, a1 = *pa1, b1 = *pb1;
+                        *pa0 = a0 + wa[u] * v0[u];
+                        *pb0 = b0 + wb[u] * v0[u];
+                        *pa1 = a1 + wa[u] * v1[u];
+                        *pb1 = b1 + wb[u] * v1[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
     }
-#undef STEGO_BWD_CASE
-    return hipGetLastError();
+    float* out = (dest == 0 ? prm.d_code : prm.d_code_pos) + ((size_t)j * H + r0) * W * K;
+    for (int e = tid; e < band_elems; e += UNS_THREADS) out[e] = acc[e];
+    if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
 }
 
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
 {
-    auto ok = [&](const MapV& m, int v) {
-        return m.sc == 1 && prm.K % v == 0 && (m.sn % v) == 0 && (m.sh % v) == 0 && (m.sw % v) == 0 &&
-               (reinterpret_cast<uintptr_t>(m.p) % (4 * v)) == 0;
-    };
-    int vc = 1;
-    if (ok(prm.code, 4) && ok(prm.code_pos, 4)) vc = 4;
-    else if (ok(prm.code, 2) && ok(prm.code_pos, 2)) vc = 2;
-    const int nt = (prm.K + 15) / 16;
-    const dim3 grid(prm.n_sets * prm.B);
-    switch (vc) {
-        case 4: return launch_bwd_nt<4>(prm, nt, grid, stream);
-        case 2: return launch_bwd_nt<2>(prm, nt, grid, stream);
-        default: return launch_bwd_nt<1>(prm, nt, grid, stream);
+    // ---- tile kernel
+    {
+        const int cside = TP * prm.LDK * 4;
+        const int lds = SMB_AN + 2 * cside + TP * LDG * 4;
+        const int nt = (prm.KQ + 15) / 16;
+        const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
+#define STEGO_BWD_CASE(N)                                                                                         \
+    case N: {                                                                                                     \
+        static int have = 0;                                                                                      \
+        if (have < lds) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+            if (e != hipSuccess) return e;                                                                        \
+            have = lds;                                                                                           \
+        }                                                                                                         \
+        hipLaunchKernelGGL((corr_bwd_tile_kernel<N>), grid, block, lds, stream, prm);                             \
+        break;                                                                                                    \
     }
+        switch (nt) {
+            STEGO_BWD_CASE(1)
+            STEGO_BWD_CASE(2)
+            STEGO_BWD_CASE(3)
+            STEGO_BWD_CASE(4)
+            default:
+            STEGO_BWD_CASE(5)
+        }
+#undef STEGO_BWD_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // ---- unsample kernel: bands of RT <= 8 rows (one per wave) with RT*W*K floats <= ~96 KB of LDS
+    {
+        const int row_bytes = prm.W * prm.K * 4;
+        int RT = (96 * 1024) / row_bytes;
+        if (RT > UNS_MAX_RT) RT = UNS_MAX_RT;
+        if (RT < 1) RT = 1;
+        if (RT > prm.H) RT = prm.H;
+        const int n_bands = (prm.H + RT - 1) / RT;
+        RT = (prm.H + n_bands - 1) / n_bands;                 // even bands
+        const int acc_bytes = ((RT * row_bytes + 15) & ~15) + 4 * 64 * 4 + 256;     // band + per-lane dummy cells
+        const int lds = acc_bytes + UNS_MAX_CONTRIB * 4 + UNS_MAX_RT * UNS_ROW_CAP * (int)sizeof(UnsRowEntry) + 64;
+        static int have = 0;
+        if (have < lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_unsample_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            have = lds;
+        }
+        const dim3 grid(2 * prm.B * n_bands), block(UNS_THREADS);
+        hipLaunchKernelGGL(corr_unsample_kernel, grid, block, lds, stream, prm, RT, n_bands, acc_bytes);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace stego

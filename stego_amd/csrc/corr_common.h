@@ -68,6 +68,8 @@ struct SampleParams {
     int NCH;                                   // ceil(C/64)
     int KQ, LDK;                               // round_up(K,8), KQ+4
     int mode;                                  // 0 forward(), 1 helper() (pixel-for-pixel)
+    int div_by, div_magic;                     // q -> (q / div_by) by multiply-shift (set by the launcher)
+    int debug;                                 // STEGO_DEBUG_SAMPLE: 1 skip stores, 2 skip feature loads, 4 skip code path
 };
 
 struct BwdParams {
@@ -88,6 +90,12 @@ struct BwdParams {
     const float* g_neg_cd;                     // mode 1: g_cd
     float* d_code;                             // [B][H][W][K] channels-last dense (mode 1: d_c1)
     float* d_code_pos;                         //                                  (mode 1: d_c2)
+    const float* cs;                           // forward's saved context: normalised sampled codes [nset][128][LDK]
+    const float* nrm;                          //                          code norms [nset][128]
+    const int4* tapyx;                         //                          bilinear tap pixels [nset][128]
+    const float4* tapw;                        //                          bilinear tap weights [nset][128]
+    float* dt;                                 // workspace: raw-sample gradients [n_tiles][2][128][LDK]
+    int KQ, LDK;
     int g_neg_loss_stride;                     // 1 dense, 0 broadcast scalar
     int B, K, H, W, S, P, n_neg, n_sets;
     int mode;

@@ -68,7 +68,7 @@ __device__ __forceinline__ float half_wave_sum(float v)
 
 // NJ > 0: channels-last, 16-byte aligned, C == 128*NJ: everything stays in registers.
 // NJ == 0: any strides / any C: two gather passes (norm, then normalised write).
-template <int NJ, int PREC>
+template <int NJ, int PREC, bool CCL>
 __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParams prm)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,11 +97,11 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
             while (mask) {
                 const int b = b0 + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                if (next_mine >= ordinal + 4) { ordinal += 4; continue; }      // none of this set's 4 units is mine
-                for (int qt = 0; qt < 4; ++qt, ++ordinal) {
+                if (next_mine >= ordinal + 8) { ordinal += 8; continue; }      // none of this set's 8 units is mine
+                for (int qt = 0; qt < 8; ++qt, ++ordinal) {
                     if (ordinal != next_mine) continue;
                     next_mine += nslots;
-                    // ---------------- one unit: set s = role*B + b, points [32*qt, 32*qt+32)
+                    // ---------------- one unit: set s = role*B + b, points [16*qt, 16*qt+16)
                     const int s = role * B + b;
                     const int src = (!direct && role >= 2) ? (int)prm.perms[(size_t)(role - 2) * B + b] : b;
                     const bool pos = role == 1;
@@ -111,14 +111,28 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
                     const float* cimg = mc.p + (long long)src * mc.sn;
                     const float* coords = direct ? nullptr : ((role == 0 ? prm.coords1 : prm.coords2) + (size_t)b * P * 2);
                 // the 4 points this half-wave owns in the unit: fetch their coords up front
-                int4 yxs[4];
-                float4 ws[4];
+                int4 yxs[2];
+                float4 ws[2];
 #pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    tap_for_point(32 * qt + 8 * it + 2 * wave + hw, P, prm.S, prm.H, prm.W, direct, coords, yxs[it], ws[it]);
+                for (int it = 0; it < 2; ++it) {
+                    const int q = 16 * qt + 8 * it + 2 * wave + hw;
+                    yxs[it] = make_int4(0, 0, 0, 0);
+                    ws[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < P) {
+                        const int hh = (q * prm.div_magic) >> 16, ww = q - hh * prm.div_by;   // q / S (or q / W), q < 128
+                        if (direct) {
+                            const int v = (hh << 16) | ww;
+                            yxs[it] = make_int4(v, v, v, v);
+                            ws[it] = make_float4(1.f, 0.f, 0.f, 0.f);
+                        } else {
+                            const f32x2 cxy = *reinterpret_cast<const f32x2*>(coords + (ww * prm.S + hh) * 2);
+                            make_taps(cxy[0], cxy[1], prm.H, prm.W, yxs[it], ws[it]);
+                        }
+                    }
+                }
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int q = 32 * qt + 8 * it + 2 * wave + hw;
+                for (int it = 0; it < 2; ++it) {
+                    const int q = 16 * qt + 8 * it + 2 * wave + hw;
                     const int4 yx = yxs[it];
                     const float4 w = ws[it];
                     const bool valid = q < P;
@@ -131,28 +145,32 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
                     if constexpr (NJ > 0) {
                         f32x4 v[NJ];
                         f32x4 t[NJ][4];
+                        const char* fb = reinterpret_cast<const char*>(fimg);     // uniform base + 32-bit lane offset
+                        const f32x4* p0 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.x + 4 * hl) * 4));
+                        const f32x4* p1 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.y + 4 * hl) * 4));
+                        const f32x4* p2 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.z + 4 * hl) * 4));
+                        const f32x4* p3 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.w + 4 * hl) * 4));
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const float* base = fimg + 128 * j + 4 * hl;
-                            t[j][0] = *reinterpret_cast<const f32x4*>(base + of.x);
-                            t[j][1] = *reinterpret_cast<const f32x4*>(base + of.y);
-                            t[j][2] = *reinterpret_cast<const f32x4*>(base + of.z);
-                            t[j][3] = *reinterpret_cast<const f32x4*>(base + of.w);
+                        for (int j = 0; j < NJ; ++j) {       // +512 B per j: immediate offsets
+                            if (prm.debug & 2) { t[j][0] = t[j][1] = t[j][2] = t[j][3] = f32x4{1.f, 2.f, 3.f, (float)hl}; continue; }
+                            t[j][0] = p0[32 * j]; t[j][1] = p1[32 * j]; t[j][2] = p2[32 * j]; t[j][3] = p3[32 * j];
                         }
                         float ss = 0.f;
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                float r = w.x * t[j][0][e] + w.y * t[j][1][e] + w.z * t[j][2][e] + w.w * t[j][3][e];
-                                r = valid ? r : 0.f;
+                                const float r = w.x * t[j][0][e] + w.y * t[j][1][e] + w.z * t[j][2][e] + w.w * t[j][3][e];
                                 v[j][e] = r;
                                 ss += r * r;
                             }
                         ss = half_wave_sum(ss);
-                        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-10f);       // F.normalize eps (modules.py:276)
+                        // F.normalize eps (modules.py:276); padding points (zero taps) are written as zeros
+                        const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(sqrtf(ss), 1e-10f)) : 0.f;
+                        if (!(prm.debug & 1)) {
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) store_feat4<PREC>(prm, s, q, 128 * j + 4 * hl, v[j] * inv);
+                            for (int j = 0; j < NJ; ++j) store_feat4<PREC>(prm, s, q, 128 * j + 4 * hl, v[j] * inv);
+                        } else if (v[0][0] * inv == 123.456f) prm.nrm[0] = 1.f;
                     } else {
                         const int cpad = prm.NCH * 64;
                         float ss = 0.f;
@@ -172,77 +190,112 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
                             store_feat1<PREC>(prm, s, q, c, r);
                         }
                     }
-                    // ---- code: lane hl holds channels hl + 32*m
-                    {
+                    // ---- code
+                    if (!(prm.debug & 4)) {
                         const int4 oc = taps_to_offsets(yx, mc.sh, mc.sw);
-                        constexpr int MK = 5;           // K <= 144 (host-checked)
-                        float cv[MK];
-                        float ss = 0.f;
-                        float ct[MK][4];
-#pragma unroll
-                        for (int m = 0; m < MK; ++m) {          // branch-free: out-of-range channels re-read channel 0
-                            const int c = hl + 32 * m;
-                            const float* base = cimg + (long long)(c < prm.K ? c : 0) * mc.sc;
-                            if (32 * m < prm.K) {               // (wave-uniform) skip whole groups beyond K
-                                ct[m][0] = base[oc.x]; ct[m][1] = base[oc.y]; ct[m][2] = base[oc.z]; ct[m][3] = base[oc.w];
-                            } else {
-                                ct[m][0] = ct[m][1] = ct[m][2] = ct[m][3] = 0.f;
-                            }
-                        }
-#pragma unroll
-                        for (int m = 0; m < MK; ++m) {
-                            const int c = hl + 32 * m;
-                            float r = w.x * ct[m][0] + w.y * ct[m][1] + w.z * ct[m][2] + w.w * ct[m][3];
-                            r = (valid && c < prm.K) ? r : 0.f;
-                            cv[m] = r;
-                            ss += r * r;
-                        }
-                        ss = half_wave_sum(ss);
-                        const float nr = sqrtf(ss);
-                        const float inv = 1.f / fmaxf(nr, 1e-10f);
                         float* crow = prm.cs + ((size_t)s * TP + q) * prm.LDK;
+                        if constexpr (CCL) {
+                            // channels-last, K even: lane hl holds channels 2*hl,2*hl+1 (+64 for the second group)
+                            const bool g1 = 64 + 2 * hl < prm.KQ;                 // second group needed (K > 64)
+                            const int c1 = (64 + 2 * hl < prm.K) ? 64 + 2 * hl : 0;
+                            const int c0 = (2 * hl < prm.K) ? 2 * hl : 0;
+                            f32x2 a[4], b2[4];
+                            a[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c0);
+                            a[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c0);
+                            a[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c0);
+                            a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
+                            if (prm.K > 64) {
+                                b2[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c1);
+                                b2[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c1);
+                                b2[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c1);
+                                b2[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c1);
+                            } else {
+                                b2[0] = b2[1] = b2[2] = b2[3] = f32x2{0.f, 0.f};
+                            }
+                            f32x2 r0 = w.x * a[0] + w.y * a[1] + w.z * a[2] + w.w * a[3];
+                            f32x2 r1 = w.x * b2[0] + w.y * b2[1] + w.z * b2[2] + w.w * b2[3];
+                            if (2 * hl >= prm.K) r0 = f32x2{0.f, 0.f};
+                            if (64 + 2 * hl >= prm.K) r1 = f32x2{0.f, 0.f};
+                            float ss = r0[0] * r0[0] + r0[1] * r0[1] + r1[0] * r1[0] + r1[1] * r1[1];
+                            ss = half_wave_sum(ss);
+                            const float nr = valid ? sqrtf(ss) : 0.f;
+                            const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
+                            if (2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(crow + 2 * hl) = r0 * inv;
+                            if (g1) *reinterpret_cast<f32x2*>(crow + 64 + 2 * hl) = r1 * inv;
+                            if (hl == 0) prm.nrm[(size_t)s * TP + q] = nr;
+                        } else {
+                            // generic strides: lane hl holds channels hl + 32*m
+                            constexpr int MK = 3;           // K <= 72 (host-checked)
+                            float cv[MK];
+                            float ct[MK][4];
 #pragma unroll
-                        for (int m = 0; m < MK; ++m) {
-                            const int c = hl + 32 * m;
-                            if (c < prm.KQ) crow[c] = cv[m] * inv;
+                            for (int m = 0; m < MK; ++m) {          // branch-free: out-of-range channels re-read channel 0
+                                const int c = hl + 32 * m;
+                                const float* base = cimg + (long long)(c < prm.K ? c : 0) * mc.sc;
+                                if (32 * m < prm.K) {               // (wave-uniform) skip whole groups beyond K
+                                    ct[m][0] = base[oc.x]; ct[m][1] = base[oc.y]; ct[m][2] = base[oc.z]; ct[m][3] = base[oc.w];
+                                } else {
+                                    ct[m][0] = ct[m][1] = ct[m][2] = ct[m][3] = 0.f;
+                                }
+                            }
+                            float ss = 0.f;
+#pragma unroll
+                            for (int m = 0; m < MK; ++m) {
+                                const int c = hl + 32 * m;
+                                float r = w.x * ct[m][0] + w.y * ct[m][1] + w.z * ct[m][2] + w.w * ct[m][3];
+                                r = (valid && c < prm.K) ? r : 0.f;
+                                cv[m] = r;
+                                ss += r * r;
+                            }
+                            ss = half_wave_sum(ss);
+                            const float nr = sqrtf(ss);
+                            const float inv = 1.f / fmaxf(nr, 1e-10f);
+#pragma unroll
+                            for (int m = 0; m < MK; ++m) {
+                                const int c = hl + 32 * m;
+                                if (c < prm.KQ) crow[c] = cv[m] * inv;
+                            }
+                            if (hl == 0) prm.nrm[(size_t)s * TP + q] = nr;
                         }
-                        if (hl == 0) prm.nrm[(size_t)s * TP + q] = nr;
                     }
-                    }
-                }
-            }
-        }
-    }
+                    }      // it
+                    }      // qt
+                }          // sets of this ballot
+            }              // b0
+        }                  // role
 }
 
-hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream)
+hipError_t launch_corr_sample(const SampleParams& prm_in, int precision, hipStream_t stream)
 {
-    auto cl4 = [&](const MapV& m) {
-        return m.sc == 1 && (m.sn % 4) == 0 && (m.sh % 4) == 0 && (m.sw % 4) == 0 &&
-               (reinterpret_cast<uintptr_t>(m.p) % 16) == 0;
+    SampleParams prm = prm_in;
+    auto cl = [&](const MapV& m, int v) {
+        return m.sc == 1 && (m.sn % v) == 0 && (m.sh % v) == 0 && (m.sw % v) == 0 &&
+               (reinterpret_cast<uintptr_t>(m.p) % (4 * v)) == 0;
     };
     int nj = 0;
-    if (prm.C % 128 == 0 && prm.C <= 768 && cl4(prm.feats) && cl4(prm.feats_pos)) nj = prm.C / 128;
-    const int units = prm.n_roles * prm.B * 4;
+    if (prm.C % 128 == 0 && prm.C <= 768 && cl(prm.feats, 4) && cl(prm.feats_pos, 4)) nj = prm.C / 128;
+    const bool ccl = prm.K % 2 == 0 && cl(prm.code, 2) && cl(prm.code_pos, 2);
+    prm.div_by = prm.mode == 1 ? prm.W : prm.S;
+    prm.div_magic = 65536 / prm.div_by + 1;             // (q * magic) >> 16 == q / div_by for q < 128
+    const int units = prm.n_roles * prm.B * 8;
     int nslots = (units + 7) / 8;
-    if (nslots > 256) nslots = 256;
+    if (nslots > 512) nslots = 512;
     if (nslots < 1) nslots = 1;
     const dim3 grid(8 * nslots), block(NTHREADS);
-#define STEGO_SAMPLE_CASE(N)                                                                                       \
-    case N:                                                                                                        \
-        if (precision == PREC_BF16X3) hipLaunchKernelGGL((sample_norm_kernel<N, PREC_BF16X3>), grid, block, 0, stream, prm); \
-        else hipLaunchKernelGGL((sample_norm_kernel<N, PREC_F32>), grid, block, 0, stream, prm);                   \
+#define STEGO_SAMPLE_LAUNCH(N, PR, CC) hipLaunchKernelGGL((sample_norm_kernel<N, PR, CC>), grid, block, 0, stream, prm)
+#define STEGO_SAMPLE_CASE(N)                                                                        \
+    case N:                                                                                         \
+        if (precision == PREC_BF16X3) { if (ccl) STEGO_SAMPLE_LAUNCH(N, PREC_BF16X3, true); else STEGO_SAMPLE_LAUNCH(N, PREC_BF16X3, false); } \
+        else { if (ccl) STEGO_SAMPLE_LAUNCH(N, PREC_F32, true); else STEGO_SAMPLE_LAUNCH(N, PREC_F32, false); } \
         break;
     switch (nj) {
-        STEGO_SAMPLE_CASE(1)
-        STEGO_SAMPLE_CASE(2)
         STEGO_SAMPLE_CASE(3)
-        STEGO_SAMPLE_CASE(4)
         STEGO_SAMPLE_CASE(6)
         default:
         STEGO_SAMPLE_CASE(0)
     }
 #undef STEGO_SAMPLE_CASE
+#undef STEGO_SAMPLE_LAUNCH
     return hipGetLastError();
 }
 

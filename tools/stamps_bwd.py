@@ -1,0 +1,30 @@
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from stego_amd import capi
+from ctypes import byref
+dev = torch.device("cuda:0")
+cfg = bench.Cfg()
+C, H, W, K = bench.WORKLOADS["vits8_224"]
+B, S, n_neg = 32, 11, 5
+d = bench.make_inputs(B, C, H, W, K, S, n_neg, 1000, dev)
+desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F32)
+lib = capi.load()
+out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+lm, icd, ecd, nl, ncd, saved = out
+sw, sm, sctx = saved
+g_intra = torch.tensor(0.67, device=dev); g_inter = torch.tensor(0.25, device=dev)
+g_neg = torch.full((1,), 0.63 / (n_neg * B * S ** 4), device=dev)
+os.environ["STEGO_DEBUG_BWD"] = sys.argv[1] if len(sys.argv) > 1 else "8"
+nws = lib.stego_corr_bwd_workspace_bytes(byref(desc))
+ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+dc = torch.empty(B, H, W, K, device=dev); dcp = torch.empty(B, H, W, K, device=dev)
+for rep in range(3):
+    rc = lib.stego_corr_bwd(byref(desc), d["perms"].data_ptr(), sw.data_ptr(), sm.data_ptr(), sctx.data_ptr(), icd.data_ptr(), ecd.data_ptr(),
+                            ncd.data_ptr(), g_intra.data_ptr(), g_inter.data_ptr(), g_neg.data_ptr(), 0, None, None, None,
+                            dc.data_ptr(), dcp.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+ts = ws[nws - 4096: nws - 4096 + 256].view(torch.int64).cpu().tolist()
+print("stamps (cycles rel):", [t - ts[0] for t in ts[:12] if t > 0], "NC", ts[30], "row0 counts per round", ts[24:28])
