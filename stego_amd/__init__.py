@@ -3,8 +3,10 @@ distillation hot path (reference: mhamilton723/STEGO, src/modules.py:275-398), b
 reference's own Python API.  Compute = hand-written HIP kernels in ``csrc/`` reached through
 the C ABI of ``include/stego_corr.h``; PyTorch-ROCm supplies device memory, streams, autograd
 plumbing and torch.distributed (RCCL)."""
-from .modules import (ContrastiveCorrelationLoss, average_norm, norm, sample,  # noqa: F401
-                      sample_nonzero_locations, super_perm, tensor_correlation)
+from .modules import (ClusterLookup, ContrastiveCorrelationLoss, ContrastiveCRFLoss, DinoFeaturizer,  # noqa: F401
+                      FeaturePyramidNet, LambdaLayer, average_norm, norm, sample, sample_nonzero_locations,
+                      super_perm, tensor_correlation)
 
-__all__ = ["ContrastiveCorrelationLoss", "norm", "average_norm", "tensor_correlation", "sample",
-           "super_perm", "sample_nonzero_locations"]
+__all__ = ["ContrastiveCorrelationLoss", "DinoFeaturizer", "FeaturePyramidNet", "ClusterLookup", "ContrastiveCRFLoss",
+           "LambdaLayer", "norm", "average_norm", "tensor_correlation", "sample", "super_perm",
+           "sample_nonzero_locations"]

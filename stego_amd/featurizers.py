@@ -1,0 +1,265 @@
+"""Featurizers, probes and the optional CRF loss: the rest of the reference's ``src/modules.py``
+surface (``from modules import *`` is how its scripts get them).  Stock PyTorch-ROCm: these
+produce/consume the hot path's tensors but are not on it.
+
+Same constructor signatures, attribute names and state-dict keys as the reference so that its
+checkpoints (``net.cluster1.0.*``, ``net.cluster2.{0,2}.*``, ``cluster_probe.clusters`` ...)
+load unchanged:
+  LambdaLayer :8-14, DinoFeaturizer :17-118, ResizeAndClassify :121-131, ClusterLookup :134-161,
+  FeaturePyramidNet :164-252, DoubleConv :255-272, Decoder :401-413, NetWithActivations :416-434,
+  ContrastiveCRFLoss :437-469.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dino_vit
+
+
+class LambdaLayer(nn.Module):
+    def __init__(self, lambd):
+        super().__init__()
+        self.lambd = lambd
+
+    def forward(self, x):
+        return self.lambd(x)
+
+
+class DinoFeaturizer(nn.Module):
+    """Frozen DINO ViT + trainable 1x1-conv segmentation head.  forward(img) -> (feats, code) with
+    feats a channels-last strided VIEW [B,C,h,w] of the tokens - the layout the loss kernels want."""
+
+    _N_FEATS = {"vit_tiny": 192, "vit_small": 384, "vit_base": 768}
+
+    def __init__(self, dim, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.dim = dim
+        self.patch_size = cfg.dino_patch_size
+        self.feat_type = cfg.dino_feat_type
+        arch = cfg.model_type
+        if arch not in self._N_FEATS or self.patch_size not in (8, 16):
+            raise ValueError("Unknown arch and patch size")
+        self.model = dino_vit.ARCHS[arch](patch_size=self.patch_size, num_classes=0)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.model.eval()
+        if torch.cuda.is_available():
+            self.model.cuda()
+        self.dropout = nn.Dropout2d(p=.1)
+
+        weights = getattr(cfg, "pretrained_weights", None)
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu")
+            sd = sd.get("teacher", sd)
+            sd = {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}
+            msg = self.model.load_state_dict(sd, strict=False)
+            print("Pretrained weights found at {} and loaded with msg: {}".format(weights, msg))
+        else:
+            # the reference downloads the public DINO checkpoint here (modules.py:59-62); this build is
+            # offline, so the backbone stays randomly initialised (benchmarks / tests use synthetic data)
+            warnings.warn("DinoFeaturizer: no cfg.pretrained_weights and no network: DINO backbone is randomly initialised")
+
+        self.n_feats = self._N_FEATS[arch]
+        self.cluster1 = self.make_clusterer(self.n_feats)
+        self.proj_type = cfg.projection_type
+        if self.proj_type == "nonlinear":
+            self.cluster2 = self.make_nonlinear_clusterer(self.n_feats)
+
+    def make_clusterer(self, in_channels):
+        return nn.Sequential(nn.Conv2d(in_channels, self.dim, (1, 1)))
+
+    def make_nonlinear_clusterer(self, in_channels):
+        return nn.Sequential(nn.Conv2d(in_channels, in_channels, (1, 1)), nn.ReLU(),
+                             nn.Conv2d(in_channels, self.dim, (1, 1)))
+
+    def forward(self, img, n=1, return_class_feat=False):
+        self.model.eval()
+        with torch.no_grad():
+            assert img.shape[2] % self.patch_size == 0 and img.shape[3] % self.patch_size == 0
+            feat, _, qkv = self.model.get_intermediate_feat(img, n=n)
+            feat, qkv = feat[0], qkv[0]
+            fh, fw = img.shape[2] // self.patch_size, img.shape[3] // self.patch_size
+            if return_class_feat:
+                return feat[:, :1, :].reshape(feat.shape[0], 1, 1, -1).permute(0, 3, 1, 2)
+            if self.feat_type == "feat":
+                image_feat = feat[:, 1:, :].reshape(feat.shape[0], fh, fw, -1).permute(0, 3, 1, 2)
+            elif self.feat_type == "KK":
+                k = qkv[1, :, :, 1:, :]
+                Bn, heads, _, d = k.shape
+                image_feat = k.reshape(Bn, heads, fh, fw, d).permute(0, 1, 4, 2, 3).reshape(Bn, heads * d, fh, fw)
+            else:
+                raise ValueError("Unknown feat type:{}".format(self.feat_type))
+
+        if self.proj_type is not None:
+            code = self.cluster1(self.dropout(image_feat))
+            if self.proj_type == "nonlinear":
+                code = code + self.cluster2(self.dropout(image_feat))
+        else:
+            code = image_feat
+        return (self.dropout(image_feat) if self.cfg.dropout else image_feat), code
+
+
+class ResizeAndClassify(nn.Module):
+    def __init__(self, dim: int, size: int, n_classes: int):
+        super().__init__()
+        self.size = size
+        self.predictor = nn.Sequential(nn.Conv2d(dim, n_classes, (1, 1)), nn.LogSoftmax(1))
+
+    def forward(self, x):
+        return F.interpolate(self.predictor(x), self.size, mode="bilinear", align_corners=False)
+
+
+class ClusterLookup(nn.Module):
+    """Cosine k-means probe on the code (trained on detached codes)."""
+
+    def __init__(self, dim: int, n_classes: int):
+        super().__init__()
+        self.n_classes = n_classes
+        self.dim = dim
+        self.clusters = nn.Parameter(torch.randn(n_classes, dim))
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.clusters.copy_(torch.randn(self.n_classes, self.dim))
+
+    def forward(self, x, alpha, log_probs=False):
+        inner = torch.einsum("bchw,nc->bnhw", F.normalize(x, dim=1), F.normalize(self.clusters, dim=1))
+        if alpha is None:
+            probs = F.one_hot(torch.argmax(inner, dim=1), self.clusters.shape[0]).permute(0, 3, 1, 2).to(torch.float32)
+        else:
+            probs = F.softmax(inner * alpha, dim=1)
+        if log_probs:
+            return F.log_softmax(inner * alpha, dim=1)
+        return -(probs * inner).sum(1).mean(), probs
+
+
+class DoubleConv(nn.Module):
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        mid = mid_channels or out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid, kernel_size=3, padding=1), nn.BatchNorm2d(mid), nn.ReLU(),
+            nn.Conv2d(mid, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, x):
+        return self.double_conv(x)
+
+
+class NetWithActivations(nn.Module):
+    """Runs the children of `model` in order and keeps the activations of `layer_nums`."""
+
+    def __init__(self, model, layer_nums):
+        super().__init__()
+        self.layers = nn.ModuleList(model.children())
+        self.layer_nums = {(len(self.layers) + l) if l < 0 else l for l in layer_nums}
+
+    def forward(self, x):
+        acts = {}
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i in self.layer_nums:
+                acts[i] = x
+        return acts
+
+
+class FeaturePyramidNet(nn.Module):
+    """ResNet-trunk alternative featurizer (cfg.arch == 'feature-pyramid'); `cut_model` is the trunk whose
+    children 5,6,7 give the 28/14/7-resolution activations.  forward(x) -> (low_res_feats, clusters)."""
+
+    @staticmethod
+    def _helper(x):
+        return F.interpolate(x, 56, mode="bilinear", align_corners=False).unsqueeze(-1)
+
+    def make_clusterer(self, in_channels):
+        return nn.Sequential(nn.Conv2d(in_channels, self.dim, (1, 1)), LambdaLayer(FeaturePyramidNet._helper))
+
+    def make_nonlinear_clusterer(self, in_channels):
+        return nn.Sequential(nn.Conv2d(in_channels, in_channels, (1, 1)), nn.ReLU(),
+                             nn.Conv2d(in_channels, in_channels, (1, 1)), nn.ReLU(),
+                             nn.Conv2d(in_channels, self.dim, (1, 1)), LambdaLayer(FeaturePyramidNet._helper))
+
+    def __init__(self, granularity, cut_model, dim, continuous):
+        super().__init__()
+        assert granularity in {1, 2, 3, 4}
+        self.layer_nums = [5, 6, 7]
+        self.spatial_resolutions = [7, 14, 28, 56]
+        self.feat_channels = [2048, 1024, 512, 3]
+        self.extra_channels = [128, 64, 32, 32]
+        self.granularity = granularity
+        self.encoder = NetWithActivations(cut_model, self.layer_nums)
+        self.dim = dim
+        self.continuous = continuous
+        self.n_feats = self.dim
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)
+        fc, ec = self.feat_channels, self.extra_channels
+        self.cluster1 = self.make_clusterer(fc[0])
+        self.cluster1_nl = self.make_nonlinear_clusterer(fc[0])
+        if granularity >= 2:
+            self.conv2 = DoubleConv(fc[0] + fc[1], ec[1])
+            self.cluster2 = self.make_clusterer(ec[1])
+        if granularity >= 3:
+            self.conv3 = DoubleConv(ec[1] + fc[2], ec[2])
+            self.cluster3 = self.make_clusterer(ec[2])
+        if granularity >= 4:
+            self.conv4 = DoubleConv(ec[2] + fc[3], ec[3])
+            self.cluster4 = self.make_clusterer(ec[3])
+
+    def c(self, x, y):
+        return torch.cat([x, y], dim=1)
+
+    def forward(self, x):
+        with torch.no_grad():
+            feats = self.encoder(x)
+        low = feats[self.layer_nums[-1]]
+        heads = [self.cluster1(low)]
+        f = low
+        if self.granularity >= 2:
+            f = self.conv2(self.c(self.up(f), feats[self.layer_nums[-2]]))
+            heads.append(self.cluster2(f))
+        if self.granularity >= 3:
+            f = self.conv3(self.c(self.up(f), feats[self.layer_nums[-3]]))
+            heads.append(self.cluster3(f))
+        if self.granularity >= 4:
+            size = self.spatial_resolutions[-1]
+            f = self.conv4(self.c(self.up(f), F.interpolate(x, (size, size), mode="bilinear", align_corners=False)))
+            heads.append(self.cluster4(f))
+        avg = torch.cat(heads, 4).mean(4)
+        return low, (avg if self.continuous else torch.log_softmax(avg, 1))
+
+
+class Decoder(nn.Module):
+    def __init__(self, code_channels, feat_channels):
+        super().__init__()
+        self.linear = nn.Conv2d(code_channels, feat_channels, (1, 1))
+        self.nonlinear = nn.Sequential(nn.Conv2d(code_channels, code_channels, (1, 1)), nn.ReLU(),
+                                       nn.Conv2d(code_channels, code_channels, (1, 1)), nn.ReLU(),
+                                       nn.Conv2d(code_channels, feat_channels, (1, 1)))
+
+    def forward(self, x):
+        return self.linear(x) + self.nonlinear(x)
+
+
+class ContrastiveCRFLoss(nn.Module):
+    """Optional CRF-style pairwise loss on randomly chosen pixels (cfg.crf_weight, 0 by default)."""
+
+    def __init__(self, n_samples, alpha, beta, gamma, w1, w2, shift):
+        super().__init__()
+        self.n_samples, self.alpha, self.beta, self.gamma = n_samples, alpha, beta, gamma
+        self.w1, self.w2, self.shift = w1, w2, shift
+
+    def forward(self, guidance, clusters):
+        dev = clusters.device
+        assert guidance.shape[0] == clusters.shape[0] and guidance.shape[2:] == clusters.shape[2:]
+        h, w = guidance.shape[2], guidance.shape[3]
+        coords = torch.cat([torch.randint(0, h, size=[1, self.n_samples], device=dev),
+                            torch.randint(0, w, size=[1, self.n_samples], device=dev)], 0)
+        g = guidance[:, :, coords[0], coords[1]]
+        d_xy = (coords.unsqueeze(-1) - coords.unsqueeze(1)).square().sum(0).unsqueeze(0)
+        d_g = (g.unsqueeze(-1) - g.unsqueeze(2)).square().sum(1)
+        kernel = self.w1 * torch.exp(-d_xy / (2 * self.alpha) - d_g / (2 * self.beta)) + \
+            self.w2 * torch.exp(-d_xy / (2 * self.gamma)) - self.shift
+        c = clusters[:, :, coords[0], coords[1]]
+        return -(torch.einsum("nka,nkb->nab", c, c) * kernel)

@@ -19,6 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import capi
+from .featurizers import (ClusterLookup, ContrastiveCRFLoss, Decoder, DinoFeaturizer, DoubleConv,  # noqa: F401
+                          FeaturePyramidNet, LambdaLayer, NetWithActivations, ResizeAndClassify)
 
 
 # ------------------------------------------------------------------ small named helpers

@@ -1,0 +1,291 @@
+"""PL-free mirror of the reference's ``src/train_segmentation.py``: ``LitUnsupervisedSegmenter`` with the same
+constructor, attributes, state-dict keys and ``training_step`` arithmetic (:53-245,373-383), a small
+``Trainer`` (the reference delegates to pytorch_lightning, which is not in this image), the yaml+override
+config loader (hydra is absent) and a synthetic stand-in for ``ContrastiveSegDataset`` (no datasets offline).
+
+The correspondence loss inside ``training_step`` is the HIP path (stego_amd.modules); everything else is stock
+PyTorch-ROCm.  Data parallelism: one process per GPU, batch sharded, ONE flat RCCL all-reduce of the
+trainable (head + probe) gradients per step (stego_amd.ddp) - the backbone is frozen, nothing inside the loss
+is synchronised.
+
+    python -m stego_amd.train_segmentation max_steps=20 batch_size=8            # synthetic data, 1 GPU
+    torchrun --standalone --nproc-per-node 8 -m stego_amd.train_segmentation max_steps=20
+"""
+import os
+import sys
+import types
+from os.path import dirname, join
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import yaml
+
+from . import ddp
+from .featurizers import ClusterLookup, ContrastiveCRFLoss, DinoFeaturizer, FeaturePyramidNet
+from .modules import ContrastiveCorrelationLoss, norm, sample
+from .utils import UnsupervisedMetrics, one_hot_feats, prep_args, resize
+
+
+def get_class_labels(dataset_name):
+    """n_classes per dataset as the reference sets them (train_segmentation.py:33-50, data.py)."""
+    if dataset_name.startswith("cityscapes"):
+        return 27
+    if dataset_name == "cocostuff27":
+        return 27
+    if dataset_name == "cocostuff3":
+        return 3
+    if dataset_name == "potsdam":
+        return 3
+    raise ValueError("Unknown Dataset {}".format(dataset_name))
+
+
+def load_config(path=None, overrides=()):
+    """yaml defaults + `key=value` overrides -> attribute-style cfg (what hydra/OmegaConf gives the reference)."""
+    path = path or join(dirname(__file__), "configs", "train_config.yml")
+    with open(path) as f:
+        d = yaml.safe_load(f)
+    for ov in overrides:
+        k, v = ov.split("=", 1)
+        d[k] = yaml.safe_load(v)
+    return types.SimpleNamespace(**d)
+
+
+class LitUnsupervisedSegmenter(nn.Module):
+    def __init__(self, n_classes, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.n_classes = n_classes
+        dim = cfg.dim if cfg.continuous else n_classes
+        if cfg.arch == "feature-pyramid":
+            raise ValueError("arch 'feature-pyramid' needs a torchvision ResNet trunk: build FeaturePyramidNet("
+                             "granularity, cut_model, dim, continuous) yourself and assign it to .net")
+        elif cfg.arch == "dino":
+            self.net = DinoFeaturizer(dim, cfg)
+        else:
+            raise ValueError("Unknown arch {}".format(cfg.arch))
+        self.train_cluster_probe = ClusterLookup(dim, n_classes)
+        self.cluster_probe = ClusterLookup(dim, n_classes + cfg.extra_clusters)
+        self.linear_probe = nn.Conv2d(dim, n_classes, (1, 1))
+        self.decoder = nn.Conv2d(dim, self.net.n_feats, (1, 1))
+        self.cluster_metrics = UnsupervisedMetrics("test/cluster/", n_classes, cfg.extra_clusters, True)
+        self.linear_metrics = UnsupervisedMetrics("test/linear/", n_classes, 0, False)
+        self.test_cluster_metrics = UnsupervisedMetrics("final/cluster/", n_classes, cfg.extra_clusters, True)
+        self.test_linear_metrics = UnsupervisedMetrics("final/linear/", n_classes, 0, False)
+        self.linear_probe_loss_fn = nn.CrossEntropyLoss()
+        self.crf_loss_fn = ContrastiveCRFLoss(cfg.crf_samples, cfg.alpha, cfg.beta, cfg.gamma, cfg.w1, cfg.w2, cfg.shift)
+        self.contrastive_corr_loss_fn = ContrastiveCorrelationLoss(cfg)
+        for p in self.contrastive_corr_loss_fn.parameters():
+            p.requires_grad = False
+        self.automatic_optimization = False
+        self.val_steps = 0
+        self.global_step = 0
+        self.logged = {}
+        self._optims = None
+        self._reducer = None
+
+    # ---- the slice of the LightningModule protocol the reference uses
+    def forward(self, x):
+        return self.net(x)[1]
+
+    def log(self, name, value, **_):
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    def configure_optimizers(self):
+        main_params = list(self.net.parameters())
+        if self.cfg.rec_weight > 0:
+            main_params.extend(self.decoder.parameters())
+        net_optim = torch.optim.Adam(main_params, lr=self.cfg.lr)
+        linear_probe_optim = torch.optim.Adam(list(self.linear_probe.parameters()), lr=5e-3)
+        cluster_probe_optim = torch.optim.Adam(list(self.cluster_probe.parameters()), lr=5e-3)
+        return net_optim, linear_probe_optim, cluster_probe_optim
+
+    def optimizers(self):
+        if self._optims is None:
+            self._optims = list(self.configure_optimizers())
+        return self._optims
+
+    def setup_distributed(self):
+        """Flat gradient bucket over every trainable parameter + startup broadcast (what DDP does on wrap)."""
+        self._reducer = ddp.FlatGradReducer([p for p in self.parameters() if p.requires_grad])
+        self._reducer.broadcast_params(0)
+        return self._reducer
+
+    def manual_backward(self, loss):
+        loss.backward()
+        if self._reducer is not None:
+            self._reducer.reattach()
+            self._reducer.allreduce_mean()
+
+    def training_step(self, batch, batch_idx):
+        net_optim, linear_probe_optim, cluster_probe_optim = self.optimizers()
+        if self._reducer is not None:
+            self._reducer.zero_grad()
+        else:
+            net_optim.zero_grad(); linear_probe_optim.zero_grad(); cluster_probe_optim.zero_grad()
+        cfg = self.cfg
+        with torch.no_grad():
+            img, img_pos, label = batch["img"], batch["img_pos"], batch["label"]
+        feats, code = self.net(img)
+        if cfg.correspondence_weight > 0:
+            feats_pos, code_pos = self.net(img_pos)
+        log_args = dict(sync_dist=False, rank_zero_only=True)
+        if cfg.use_true_labels:
+            signal = one_hot_feats(label + 1, self.n_classes + 1)
+            signal_pos = one_hot_feats(batch["label_pos"] + 1, self.n_classes + 1)
+        else:
+            signal, signal_pos = feats, feats_pos
+        loss = 0
+        if cfg.use_salience:
+            salience = batch["mask"].to(torch.float32).squeeze(1)
+            salience_pos = batch["mask_pos"].to(torch.float32).squeeze(1)
+        else:
+            salience = salience_pos = None
+
+        if cfg.correspondence_weight > 0:
+            (pos_intra_loss, pos_intra_cd, pos_inter_loss, pos_inter_cd, neg_inter_loss, neg_inter_cd,
+             ) = self.contrastive_corr_loss_fn(signal, signal_pos, salience, salience_pos, code, code_pos)
+            neg_inter_loss = neg_inter_loss.mean()
+            pos_intra_loss = pos_intra_loss.mean()
+            pos_inter_loss = pos_inter_loss.mean()
+            self.log('loss/pos_intra', pos_intra_loss, **log_args)
+            self.log('loss/pos_inter', pos_inter_loss, **log_args)
+            self.log('loss/neg_inter', neg_inter_loss, **log_args)
+            self.log('cd/pos_intra', pos_intra_cd.mean(), **log_args)
+            self.log('cd/pos_inter', pos_inter_cd.mean(), **log_args)
+            self.log('cd/neg_inter', neg_inter_cd.mean(), **log_args)
+            loss += (cfg.pos_inter_weight * pos_inter_loss + cfg.pos_intra_weight * pos_intra_loss +
+                     cfg.neg_inter_weight * neg_inter_loss) * cfg.correspondence_weight
+
+        if cfg.rec_weight > 0:
+            rec_loss = -(norm(self.decoder(code)) * norm(feats)).sum(1).mean()
+            self.log('loss/rec', rec_loss, **log_args)
+            loss += cfg.rec_weight * rec_loss
+
+        if cfg.aug_alignment_weight > 0:
+            _, code_aug = self.net(batch["img_aug"])
+            coord = resize(batch["coord_aug"].permute(0, 3, 1, 2), code_aug.shape[2]).permute(0, 2, 3, 1)
+            aug_alignment = -torch.einsum("bkhw,bkhw->bhw", norm(sample(code, coord)), norm(code_aug)).mean()
+            self.log('loss/aug_alignment', aug_alignment, **log_args)
+            loss += cfg.aug_alignment_weight * aug_alignment
+
+        if cfg.crf_weight > 0:
+            crf = self.crf_loss_fn(resize(img, 56), norm(resize(code, 56))).mean()
+            self.log('loss/crf', crf, **log_args)
+            loss += cfg.crf_weight * crf
+
+        flat_label = label.reshape(-1)
+        mask = (flat_label >= 0) & (flat_label < self.n_classes)
+        detached_code = torch.clone(code.detach())
+        linear_logits = self.linear_probe(detached_code)
+        linear_logits = F.interpolate(linear_logits, label.shape[-2:], mode='bilinear', align_corners=False)
+        linear_logits = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.n_classes)
+        linear_loss = self.linear_probe_loss_fn(linear_logits[mask], flat_label[mask]).mean()
+        loss += linear_loss
+        self.log('loss/linear', linear_loss, **log_args)
+        cluster_loss, _ = self.cluster_probe(detached_code, None)
+        loss += cluster_loss
+        self.log('loss/cluster', cluster_loss, **log_args)
+        self.log('loss/total', loss, **log_args)
+
+        self.manual_backward(loss)
+        net_optim.step()
+        cluster_probe_optim.step()
+        linear_probe_optim.step()
+
+        if cfg.reset_probe_steps is not None and self.global_step == cfg.reset_probe_steps:
+            print("RESETTING PROBES")
+            self.linear_probe.reset_parameters()
+            self.cluster_probe.reset_parameters()
+            self._optims[1] = torch.optim.Adam(list(self.linear_probe.parameters()), lr=5e-3)
+            self._optims[2] = torch.optim.Adam(list(self.cluster_probe.parameters()), lr=5e-3)
+        self.global_step += 1
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        img, label = batch["img"], batch["label"]
+        self.net.eval()
+        with torch.no_grad():
+            _, code = self.net(img)
+            code = F.interpolate(code, label.shape[-2:], mode='bilinear', align_corners=False)
+            linear_preds = self.linear_probe(code).argmax(1)
+            self.linear_metrics.update(linear_preds, label)
+            _, cluster_preds = self.cluster_probe(code, None)
+            cluster_preds = cluster_preds.argmax(1)
+            self.cluster_metrics.update(cluster_preds, label)
+            n = self.cfg.n_images
+            return {'img': img[:n].detach().cpu(), 'linear_preds': linear_preds[:n].detach().cpu(),
+                    "cluster_preds": cluster_preds[:n].detach().cpu(), "label": label[:n].detach().cpu()}
+
+    def validation_epoch_end(self, outputs):
+        with torch.no_grad():
+            metrics = {**self.linear_metrics.compute(), **self.cluster_metrics.compute()}
+            self.linear_metrics.reset()
+            self.cluster_metrics.reset()
+        self.val_steps += 1
+        for k, v in metrics.items():
+            self.log(k, v)
+        return metrics
+
+
+class SyntheticContrastiveDataset(torch.utils.data.Dataset):
+    """Offline stand-in for ContrastiveSegDataset (data.py:419-565): same batch keys, seeded random content.
+    The 'KNN positive' of image i is a noisy copy of it so that the positive pair is actually related."""
+
+    def __init__(self, n, res, n_classes, seed=0):
+        self.n, self.res, self.n_classes, self.seed = n, res, n_classes, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, ind):
+        g = torch.Generator().manual_seed(self.seed * 100003 + ind)
+        img = torch.randn(3, self.res, self.res, generator=g)
+        img_pos = img + 0.3 * torch.randn(3, self.res, self.res, generator=g)
+        label = torch.randint(0, self.n_classes, (self.res, self.res), generator=g)
+        return dict(ind=ind, img=img, label=label, img_pos=img_pos, ind_pos=ind, label_pos=label,
+                    mask=torch.ones(1, self.res, self.res), mask_pos=torch.ones(1, self.res, self.res))
+
+
+class Trainer:
+    """Minimal stand-in for the Lightning Trainer the reference builds at train_segmentation.py:476-497."""
+
+    def __init__(self, max_steps, device=None, log_every=10):
+        self.max_steps, self.log_every = max_steps, log_every
+        self.rank, self.world, self.local_rank = ddp.init_from_env()
+        self.device = device or (torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu"))
+
+    def fit(self, model, loader):
+        model.to(self.device)
+        model.train()
+        if self.world > 1:
+            model.setup_distributed()
+        step = 0
+        history = []
+        while step < self.max_steps:
+            for batch in loader:
+                batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                loss = model.training_step(batch, step)
+                history.append(float(loss.detach()))
+                if self.rank == 0 and step % self.log_every == 0:
+                    print("step %5d  loss %.5f  " % (step, history[-1]) +
+                          "  ".join("%s %.5f" % (k, float(v)) for k, v in model.logged.items() if k.startswith("loss/pos") or k.startswith("loss/neg")))
+                step += 1
+                if step >= self.max_steps:
+                    break
+        return history
+
+
+def my_app(cfg):
+    torch.manual_seed(0)            # seed_everything(0), train_segmentation.py:403
+    n_classes = get_class_labels(cfg.dataset_name)
+    trainer = Trainer(cfg.max_steps)
+    ds = SyntheticContrastiveDataset(max(cfg.batch_size * 8, 64), cfg.res, n_classes, seed=trainer.rank)
+    loader = torch.utils.data.DataLoader(ds, cfg.batch_size, shuffle=True, num_workers=0, drop_last=True)
+    model = LitUnsupervisedSegmenter(n_classes, cfg)
+    return trainer.fit(model, loader)
+
+
+if __name__ == "__main__":
+    prep_args()
+    my_app(load_config(overrides=sys.argv[1:]))

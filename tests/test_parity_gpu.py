@@ -314,3 +314,50 @@ def test_unsupported_configs_fail_loudly():
     c = torch.randn(2, 4, 8, 8, device=DEV)
     with pytest.raises(RuntimeError, match="unsupported"):
         M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+
+
+def test_training_loop_on_device_matches_cpu_oracle_step():
+    """The drop-in surface end to end on the MI355X: LitUnsupervisedSegmenter.training_step (reference
+    train_segmentation.py:112-245) with the HIP loss inside, against the same step computed on CPU with the
+    oracle-backed backend double (same weights, same batch, same RNG draws fed explicitly)."""
+    import warnings
+    import oracle_backend
+    from stego_amd.train_segmentation import LitUnsupervisedSegmenter, SyntheticContrastiveDataset, load_config
+    warnings.filterwarnings("ignore", message="DinoFeaturizer")
+    ov = ["model_type=vit_tiny", "dino_patch_size=16", "res=64", "batch_size=4", "feature_samples=5", "neg_samples=2",
+          "dim=10", "dropout=False"]
+    cfg = load_config(overrides=ov)
+    torch.manual_seed(0)
+    ref = LitUnsupervisedSegmenter(27, cfg)
+    ref.net.dropout.p = 0.0                                   # no dropout noise: CPU and GPU RNG streams differ
+    dev_model = LitUnsupervisedSegmenter(27, cfg)
+    dev_model.net.dropout.p = 0.0
+    dev_model.load_state_dict(ref.state_dict())
+    dev_model.to(DEV)
+    ds = SyntheticContrastiveDataset(4, cfg.res, 27)
+    batch = torch.utils.data.default_collate([ds[i] for i in range(4)])
+    # identical RNG draws on both sides
+    g = torch.Generator().manual_seed(5)
+    coords1 = torch.rand(4, 5, 5, 2, generator=g) * 2 - 1
+    coords2 = torch.rand(4, 5, 5, 2, generator=g) * 2 - 1
+    perms = torch.tensor([[1, 2, 3, 0], [2, 3, 0, 1]])
+
+    def patched_forward(loss_mod, dev):
+        def fwd(of, ofp, s1, s2, oc, ocp):
+            return loss_mod.forward_explicit(of, ofp, oc, ocp, coords1.to(dev), coords2.to(dev), perms.to(dev))
+        return fwd
+
+    ref.contrastive_corr_loss_fn.forward = patched_forward(ref.contrastive_corr_loss_fn, "cpu")
+    dev_model.contrastive_corr_loss_fn.forward = patched_forward(dev_model.contrastive_corr_loss_fn, DEV)
+    try:
+        M._backend = oracle_backend
+        loss_ref = ref.training_step(batch, 0)
+    finally:
+        M._backend = capi
+    loss_dev = dev_model.training_step({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
+    assert abs(float(loss_dev) - float(loss_ref)) < 2e-3 * max(1.0, abs(float(loss_ref)))
+    for k in ("loss/pos_intra", "loss/pos_inter", "loss/neg_inter"):
+        assert abs(float(dev_model.logged[k]) - float(ref.logged[k])) < 1e-3 * max(0.05, abs(float(ref.logged[k]))), k
+    w_ref = ref.net.cluster1[0].weight.detach()
+    w_dev = dev_model.net.cluster1[0].weight.detach().cpu()
+    assert torch.allclose(w_dev, w_ref, rtol=1e-3, atol=2e-4)          # one Adam step on the head, same direction

@@ -1,0 +1,194 @@
+"""CPU tests of the training-loop surface (reference train_segmentation.py:53-245) and of the data-parallel
+gradient exchange (gloo, world_size 2 - the no-GPU stand-in for RCCL).  The loss inside training_step runs on
+the oracle-backed double of the C-ABI backend (tests/oracle_backend.py); the product has no CPU path."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_backend
+from stego_amd import ddp
+from stego_amd import modules as M
+from stego_amd.train_segmentation import (LitUnsupervisedSegmenter, SyntheticContrastiveDataset, Trainer,
+                                          get_class_labels, load_config)
+from stego_amd.utils import UnsupervisedMetrics, prep_args
+
+warnings.filterwarnings("ignore", message="DinoFeaturizer")
+
+TINY = ["model_type=vit_tiny", "dino_patch_size=16", "res=32", "batch_size=3", "feature_samples=3", "neg_samples=2",
+        "dim=6", "max_steps=2"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_config_keys_and_prep_args():
+    cfg = load_config()
+    for k in ("feature_samples", "neg_samples", "pointwise", "zero_clamp", "stabalize", "use_salience",
+              "pos_intra_shift", "pos_inter_shift", "neg_inter_shift", "pos_intra_weight", "dim", "model_type"):
+        assert hasattr(cfg, k), k
+    assert (cfg.feature_samples, cfg.neg_samples, cfg.dim, cfg.batch_size) == (11, 5, 70, 16)
+    assert (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift) == (0.18, 0.12, 0.46)
+    assert prep_args(["prog", "--batch_size", "8", "res=64"]) == ["prog", "batch_size=8", "res=64"]
+    assert load_config(overrides=["batch_size=8", "pretrained_weights=~"]).batch_size == 8
+    assert get_class_labels("cocostuff27") == 27
+
+
+def test_module_surface_and_state_dict_keys():
+    cfg = load_config(overrides=TINY)
+    m = LitUnsupervisedSegmenter(27, cfg)
+    keys = set(m.state_dict().keys())
+    for k in ("net.cluster1.0.weight", "net.cluster1.0.bias", "net.cluster2.0.weight", "net.cluster2.2.bias",
+              "train_cluster_probe.clusters", "cluster_probe.clusters", "linear_probe.weight", "decoder.bias",
+              "net.model.cls_token", "net.model.pos_embed", "net.model.patch_embed.proj.weight",
+              "net.model.blocks.0.attn.qkv.weight", "net.model.blocks.11.mlp.fc2.bias", "net.model.norm.weight"):
+        assert k in keys, k
+    assert not any(p.requires_grad for p in m.net.model.parameters())           # frozen backbone (modules.py:30-31)
+    x = torch.randn(2, 3, 32, 32)
+    feats, code = m.net(x)
+    assert tuple(feats.shape) == (2, 192, 2, 2) and tuple(code.shape) == (2, 6, 2, 2)
+    assert feats.stride(1) == 1                                                  # channels-last view, as the kernels like it
+    assert tuple(m(x).shape) == (2, 6, 2, 2)
+    # every name the reference scripts import from modules
+    for name in ("LambdaLayer", "DinoFeaturizer", "ResizeAndClassify", "ClusterLookup", "FeaturePyramidNet", "DoubleConv",
+                 "norm", "average_norm", "tensor_correlation", "sample", "super_perm", "sample_nonzero_locations",
+                 "ContrastiveCorrelationLoss", "Decoder", "NetWithActivations", "ContrastiveCRFLoss"):
+        assert hasattr(M, name), name
+
+
+def test_unsupervised_metrics_hungarian():
+    m = UnsupervisedMetrics("t/", 3, 0, True)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 2])
+    preds = torch.tensor([2, 2, 0, 0, 1, 1, 0])        # a relabelling of target with one error
+    m.update(preds, target)
+    out = m.compute()
+    assert abs(out["t/Accuracy"] - 100 * 6 / 7) < 1e-6
+
+
+def _one_step(monkeypatch_backend=True, overrides=TINY, seed=0):
+    if monkeypatch_backend:
+        M._backend = oracle_backend
+    cfg = load_config(overrides=overrides)
+    torch.manual_seed(seed)
+    m = LitUnsupervisedSegmenter(27, cfg)
+    ds = SyntheticContrastiveDataset(6, cfg.res, 27, seed=seed)
+    batch = torch.utils.data.default_collate([ds[i] for i in range(cfg.batch_size)])
+    return m, batch
+
+
+def test_training_step_runs_and_updates_only_trainables():
+    try:
+        m, batch = _one_step()
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        loss = m.training_step(batch, 0)
+        assert torch.isfinite(loss)
+        for k in ("loss/pos_intra", "loss/pos_inter", "loss/neg_inter", "cd/pos_intra", "loss/linear", "loss/cluster",
+                  "loss/total"):
+            assert k in m.logged
+        after = m.state_dict()
+        assert not torch.equal(before["net.cluster1.0.weight"], after["net.cluster1.0.weight"])
+        assert not torch.equal(before["linear_probe.weight"], after["linear_probe.weight"])
+        assert torch.equal(before["net.model.blocks.0.attn.qkv.weight"], after["net.model.blocks.0.attn.qkv.weight"])
+        assert m.global_step == 1
+    finally:
+        from stego_amd import capi
+        M._backend = capi
+
+
+def test_flat_grad_reducer_single_process():
+    lin = torch.nn.Linear(4, 3)
+    red = ddp.FlatGradReducer(lin.parameters())
+    assert red.numel == 15 and lin.weight.grad.data_ptr() == red.flat.data_ptr()
+    lin(torch.ones(2, 4)).sum().backward()
+    assert torch.allclose(red.flat[:12], torch.full((12,), 2.0))
+    red.allreduce_mean()                     # no process group: no-op
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    opt.zero_grad(set_to_none=True)
+    red.reattach()
+    assert lin.weight.grad is not None and lin.weight.grad.data_ptr() == red.flat.data_ptr()
+    assert float(red.flat.abs().sum()) == 0.0
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    warnings.filterwarnings("ignore", message="DinoFeaturizer")
+    r, w, _ = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    M._backend = oracle_backend
+    cfg = load_config(overrides=TINY)
+    torch.manual_seed(123 + rank)            # ranks start from DIFFERENT heads: broadcast must fix that
+    model = LitUnsupervisedSegmenter(27, cfg)
+    reducer = model.setup_distributed()
+    ds = SyntheticContrastiveDataset(6, cfg.res, 27, seed=rank)          # per-rank shard
+    batch = torch.utils.data.default_collate([ds[i] for i in range(cfg.batch_size)])
+
+    # local gradient of this rank (no collective) for the reference value
+    torch.manual_seed(7 + rank)
+    rng = torch.get_rng_state()
+    model._reducer = None
+    for p in model.parameters():
+        p.grad = None
+    opt_state = [o.state_dict() for o in model.optimizers()]
+    params0 = [p.detach().clone() for p in model.parameters()]
+    model.training_step(batch, 0)
+    local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                       for p in model.parameters() if p.requires_grad]).clone()
+    with torch.no_grad():                    # rewind parameters / optimizers / RNG
+        for p, p0 in zip(model.parameters(), params0):
+            p.copy_(p0)
+    model._optims = None
+    model.global_step = 0
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = torch.stack(gathered).mean(0)
+
+    # the real path: flat bucket + one all-reduce inside manual_backward
+    model._reducer = reducer
+    for p in reducer.params:
+        p.grad = None
+    reducer.reattach()
+    torch.set_rng_state(rng)
+    model.training_step(batch, 0)
+    np.save(os.path.join(out_dir, "grad_%d.npy" % rank), reducer.flat.numpy())
+    np.save(os.path.join(out_dir, "expect_%d.npy" % rank), expect.numpy())
+    np.save(os.path.join(out_dir, "head_%d.npy" % rank), model.net.cluster1[0].weight.detach().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce(tmp_path):
+    """world_size 2 on CPU: after one step every rank holds the MEAN of the per-rank gradients (what Lightning DDP
+    gives the reference, per-rank loss statistics included - SURVEY.md 8(e)) and identical parameters."""
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "grad_0.npy"), np.load(tmp_path / "grad_1.npy")
+    e0 = np.load(tmp_path / "expect_0.npy")
+    np.testing.assert_allclose(g0, g1, rtol=0, atol=0)
+    np.testing.assert_allclose(g0, e0, rtol=1e-5, atol=1e-8)
+    assert np.abs(e0).sum() > 0
+    np.testing.assert_array_equal(np.load(tmp_path / "head_0.npy"), np.load(tmp_path / "head_1.npy"))
+
+
+def test_trainer_fit_history_cpu():
+    try:
+        M._backend = oracle_backend
+        cfg = load_config(overrides=TINY)
+        torch.manual_seed(0)
+        model = LitUnsupervisedSegmenter(27, cfg)
+        ds = SyntheticContrastiveDataset(6, cfg.res, 27)
+        loader = torch.utils.data.DataLoader(ds, cfg.batch_size, shuffle=False, drop_last=True)
+        hist = Trainer(cfg.max_steps, device=torch.device("cpu"), log_every=100).fit(model, loader)
+        assert len(hist) == cfg.max_steps and all(np.isfinite(hist))
+    finally:
+        from stego_amd import capi
+        M._backend = capi
