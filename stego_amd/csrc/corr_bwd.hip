@@ -369,6 +369,183 @@ __global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdPar
     if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
 }
 
+
+// ------------------------------------------------------------------------------- unsample, row-owned
+// The fast path (W <= 64): ONE WAVE OWNS ONE PIXEL ROW of one destination image and keeps it in REGISTERS as
+// MFMA accumulators.  The bilinear adjoint of a row is a tiny sparse GEMM
+//        row[x][ch] += sum_e  onehot_e[x] * DT_e[ch],      onehot_e[x] = wa_e (x == x0_e), wb_e (x == x0_e+1), 0
+// and it is issued exactly like that on v_mfma_f32_16x16x4_f32 (M = 16 pixels, N = 16 channels, K = 4
+// row-entries): no dynamic register indexing, no branches, no LDS read-modify-write chain (the LDS-band
+// version measured ~500 cycles per entry; a wave-uniform switch over register accumulators made the
+// structurizer emit 15 k accumulator copies).  Waves are fully independent: no block barriers, no atomics.
+//   items   : the DT matrices that touch this image (anchor role: A side of every pair-set tile of the
+//             image; negatives: the (i,b) with perm_i[b] == image, found with ballots)  -> per-wave LDS table
+//   scan    : 4 items x 128 points per step, taps loaded 16 at a time per lane; taps on MY row are
+//             compacted (ballot + mbcnt, deterministic order) into a per-wave LDS list of row-entries
+//   drain   : 16 entries per step: entry k = lane/16 of each group of 4 feeds the A operand (one-hot
+//             weights for pixel lane%16) and the B operand (channel lane%16 of its DT row), 20 loads in flight
+//   store   : the row is written once, straight from the accumulators.
+constexpr int UR_WAVES = 4;
+constexpr int UR_GROUP = 4;          // items scanned per step; a point hits a row at most once -> <= 4*128 entries
+constexpr int UR_CAP = 768;          // row-entries per wave between drains (>= 512 + typical fill)
+constexpr int UR_ITEMCAP = 256;
+constexpr int UR_NT = 5;             // 16-channel tiles (K <= 72)
+constexpr int UR_EG = 4;             // groups of 4 entries per drain step
+
+__device__ __forceinline__ int lane_prefix(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <int MT>        // 16-pixel tiles per row: W <= 16 * MT
+__global__ void __launch_bounds__(UR_WAVES * 64) corr_unsample_row_kernel(const BwdParams prm)
+{
+    __shared__ __attribute__((aligned(16))) UnsRowEntry wl_s[UR_WAVES][UR_CAP];
+    __shared__ __attribute__((aligned(8))) int2 items_s[UR_WAVES][UR_ITEMCAP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = prm.B, P = prm.P, K = prm.K, W = prm.W, H = prm.H, ldk = prm.LDK;
+    const bool direct = prm.mode == 1;
+    const int unit = blockIdx.x * UR_WAVES + wave;          // (dest, image j, row r); heavy dest 0 first
+    if (unit >= 2 * B * H) return;
+    const int r = unit % H;
+    const int j = (unit / H) % B;
+    const int dest = unit / (H * B);
+    UnsRowEntry* wl = wl_s[wave];
+    int2* items = items_s[wave];
+    const int side_elems = TP * ldk;
+    const int n_own = (!direct && dest == 0) ? prm.n_sets : 1;
+    const int n_cand = n_own + ((!direct && dest == 0) ? prm.n_neg * B : 0);
+    const int l16 = lane & 15, k4 = lane >> 4;
+    int cch[UR_NT];                                          // channel of this lane in each N tile, kept inside the DT row
+#pragma unroll
+    for (int nt = 0; nt < UR_NT; ++nt) cch[nt] = min(16 * nt + l16, ldk - 1);
+
+    f32x4 acc[MT][UR_NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < UR_NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int u0 = 0; u0 < n_cand; u0 += 256) {
+        // ---- item table from the next 256 candidates (loads issued together)
+        int n_items = 0;
+        {
+            long long pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = u0 + k * 64 + lane - n_own;
+                pv[k] = (t >= 0 && t < n_cand - n_own) ? prm.perms[t] : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * 64 + lane;
+                bool m = false;
+                int s = 0, tile0 = 0, side = 0;
+                if (u < n_own) {
+                    m = true;
+                    if (direct) { s = dest * B + j; tile0 = j; side = dest; }
+                    else if (dest == 1) { s = B + j; tile0 = B + j; side = 1; }
+                    else { s = j; tile0 = u * B + j; side = 0; }
+                } else if (u < n_cand) {
+                    m = (int)pv[k] == j;                     // the index_put of orig_code[perm], modules.py:385
+                    s = 2 * B + (u - n_own); tile0 = s; side = 1;
+                }
+                const unsigned long long mask = __ballot(m);
+                if (m) items[n_items + lane_prefix(mask)] = make_int2(s, (tile0 * 2 + side) * side_elems);
+                n_items += __builtin_popcountll(mask);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler
+
+        for (int it_pos = 0; it_pos < n_items;) {
+            // ---- scan groups of items while the worst case still fits: which taps land on row r?
+            int count = 0;
+            while (it_pos < n_items && count + UR_GROUP * TP <= UR_CAP) {
+                int4 yx[UR_GROUP][2];
+                float4 tw[UR_GROUP][2];
+                int dtb[UR_GROUP];
+#pragma unroll
+                for (int g = 0; g < UR_GROUP; ++g) {
+                    const int2 it = items[min(it_pos + g, n_items - 1)];
+                    dtb[g] = it.y;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        yx[g][h] = prm.tapyx[(size_t)it.x * TP + h * 64 + lane];
+                        tw[g][h] = prm.tapw[(size_t)it.x * TP + h * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < UR_GROUP; ++g) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = h * 64 + lane;
+                        const int y0 = yx[g][h].x >> 16, y1 = yx[g][h].z >> 16;
+                        // a point touches row r through its upper OR its lower tap pair (a clamped lower row,
+                        // y1 == y0, carries zero weights)
+                        const bool low = y0 != r;
+                        const float wa = low ? tw[g][h].z : tw[g][h].x, wb = low ? tw[g][h].w : tw[g][h].y;
+                        const bool hit = it_pos + g < n_items && q < P && (y0 == r || y1 == r) && (wa != 0.f || wb != 0.f);
+                        const unsigned long long mask = __ballot(hit);
+                        if (hit) {
+                            UnsRowEntry e;
+                            e.dtoff = dtb[g] + q * ldk;
+                            e.x01 = yx[g][h].x & 0xffff;
+                            e.wa = wa; e.wb = wb;
+                            wl[count + lane_prefix(mask)] = e;
+                        }
+                        count += __builtin_popcountll(mask);
+                    }
+                }
+                it_pos += UR_GROUP;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- drain: 4 groups of 4 entries per step, entry k = lane / 16 of each group
+            for (int e0 = 0; e0 < count; e0 += 4 * UR_EG) {
+                UnsRowEntry E[UR_EG];
+                float bv[UR_EG][UR_NT];
+#pragma unroll
+                for (int g = 0; g < UR_EG; ++g) {
+                    const int e = e0 + 4 * g + k4;
+                    E[g] = wl[min(e, count - 1)];
+                    if (e >= count) { E[g].wa = 0.f; E[g].wb = 0.f; }
+#pragma unroll
+                    for (int nt = 0; nt < UR_NT; ++nt) bv[g][nt] = prm.dt[E[g].dtoff + cch[nt]];
+                }
+                __builtin_amdgcn_sched_barrier(0);          // all 20 loads are in flight before the first MFMA waits
+#pragma unroll
+                for (int g = 0; g < UR_EG; ++g) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int dx = 16 * mt + l16 - E[g].x01;
+                        const float a = dx == 0 ? E[g].wa : (dx == 1 ? E[g].wb : 0.f);
+#pragma unroll
+                        for (int nt = 0; nt < UR_NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- the row, once, from the accumulators: acc[mt][nt][reg] is pixel 16 mt + 4 (lane / 16) + reg,
+    //      channel 16 nt + lane % 16
+    float* out = (dest == 0 ? prm.d_code : prm.d_code_pos) + ((size_t)j * H + r) * W * K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int x = 16 * mt + 4 * k4 + reg;
+#pragma unroll
+            for (int nt = 0; nt < UR_NT; ++nt) {
+                const int ch = 16 * nt + l16;
+                if (x < W && ch < K) out[(size_t)x * K + ch] = acc[mt][nt][reg];
+            }
+        }
+}
+
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
 {
     // ---- tile kernel
@@ -400,6 +577,13 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
 #undef STEGO_BWD_CASE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    // ---- unsample: row-owned register kernel for W <= 64, LDS band kernel beyond
+    if (prm.W <= 64 && !(prm.debug & 32)) {
+        const dim3 grid((2 * prm.B * prm.H + UR_WAVES - 1) / UR_WAVES), block(UR_WAVES * 64);
+        if (prm.W <= 32) hipLaunchKernelGGL((corr_unsample_row_kernel<2>), grid, block, 0, stream, prm);
+        else hipLaunchKernelGGL((corr_unsample_row_kernel<4>), grid, block, 0, stream, prm);
+        return hipGetLastError();
     }
     // ---- unsample kernel: bands of RT <= 8 rows (one per wave) with RT*W*K floats <= ~96 KB of LDS
     {

@@ -328,7 +328,7 @@ def test_training_loop_on_device_matches_cpu_oracle_step():
           "dim=10", "dropout=False"]
     cfg = load_config(overrides=ov)
     torch.manual_seed(0)
-    ref = LitUnsupervisedSegmenter(27, cfg)
+    ref = LitUnsupervisedSegmenter(27, cfg).cpu()            # DinoFeaturizer puts its backbone on the GPU when one exists (modules.py:32)
     ref.net.dropout.p = 0.0                                   # no dropout noise: CPU and GPU RNG streams differ
     dev_model = LitUnsupervisedSegmenter(27, cfg)
     dev_model.net.dropout.p = 0.0
