@@ -78,7 +78,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     g.ws_bytes = g.stats_bytes + g.fs_bytes + g.ctx_bytes;
-    g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 4096;
+    g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
     return g;
 }
 

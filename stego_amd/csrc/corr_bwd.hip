@@ -245,10 +245,6 @@ __global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdPar
     const int r0 = band * RT, r1 = min(H, r0 + RT);
     const int band_elems = (r1 - r0) * W * K;
     const int side_elems = TP * ldk;
-    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * side_elems);
-    const bool stamp_on = (prm.debug & 8) && blockIdx.x == 5 && tid == 0;
-    int sti = 0;
-    if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
     for (int e = tid; e < band_elems; e += UNS_THREADS) acc[e] = 0.f;
 
     // ---- contribution table: every contribution is (taps of sample set s, DT matrix (tile, side)).
@@ -276,7 +272,7 @@ __global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdPar
     }
     __syncthreads();
     const int NC = s_nc;
-    if (stamp_on) { ts[sti++] = __builtin_amdgcn_s_memtime(); ts[30] = NC; }
+    
 
     for (int c0 = 0; c0 < NC; c0 += UNS_SETS_PER_ROUND) {
         if (tid < UNS_MAX_RT) cnt[tid] = 0;
@@ -319,7 +315,6 @@ __global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdPar
             }
         }
         __syncthreads();
-        if (stamp_on) { ts[sti++] = __builtin_amdgcn_s_memtime(); ts[24 + (c0 >> 2)] = cnt[0]; }
         // ---- phase 2: wave r drains the list of pixel row r (lanes = channels, second pass for channels >= 64)
         if (wave < r1 - r0) {
             const int count = min(cnt[wave], UNS_ROW_CAP);
@@ -362,35 +357,40 @@ __global__ void __launch_bounds__(UNS_THREADS) corr_unsample_kernel(const BwdPar
             }
         }
         __syncthreads();
-        if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
     }
     float* out = (dest == 0 ? prm.d_code : prm.d_code_pos) + ((size_t)j * H + r0) * W * K;
     for (int e = tid; e < band_elems; e += UNS_THREADS) out[e] = acc[e];
-    if (stamp_on) ts[sti++] = __builtin_amdgcn_s_memtime();
 }
 
 
 // ------------------------------------------------------------------------------- unsample, row-owned
-// The fast path (W <= 64): ONE WAVE OWNS ONE PIXEL ROW of one destination image and keeps it in REGISTERS as
-// MFMA accumulators.  The bilinear adjoint of a row is a tiny sparse GEMM
+// The fast path (W <= 64): ONE PIXEL ROW of one destination image is owned by a wave (or by the 3 waves of a
+// workgroup) and lives in REGISTERS as MFMA accumulators.  The bilinear adjoint of a row is a tiny sparse GEMM
 //        row[x][ch] += sum_e  onehot_e[x] * DT_e[ch],      onehot_e[x] = wa_e (x == x0_e), wb_e (x == x0_e+1), 0
 // and it is issued exactly like that on v_mfma_f32_16x16x4_f32 (M = 16 pixels, N = 16 channels, K = 4
 // row-entries): no dynamic register indexing, no branches, no LDS read-modify-write chain (the LDS-band
 // version measured ~500 cycles per entry; a wave-uniform switch over register accumulators made the
-// structurizer emit 15 k accumulator copies).  Waves are fully independent: no block barriers, no atomics.
-//   items   : the DT matrices that touch this image (anchor role: A side of every pair-set tile of the
-//             image; negatives: the (i,b) with perm_i[b] == image, found with ballots)  -> per-wave LDS table
-//   scan    : 4 items x 128 points per step, taps loaded 16 at a time per lane; taps on MY row are
-//             compacted (ballot + mbcnt, deterministic order) into a per-wave LDS list of row-entries
-//   drain   : 16 entries per step: entry k = lane/16 of each group of 4 feeds the A operand (one-hot
-//             weights for pixel lane%16) and the B operand (channel lane%16 of its DT row), 20 loads in flight
-//   store   : the row is written once, straight from the accumulators.
-constexpr int UR_WAVES = 4;
-constexpr int UR_GROUP = 4;          // items scanned per step; a point hits a row at most once -> <= 4*128 entries
-constexpr int UR_CAP = 768;          // row-entries per wave between drains (>= 512 + typical fill)
-constexpr int UR_ITEMCAP = 256;
+// structurizer emit 15 k accumulator copies).  No atomics, deterministic summation order.
+//
+// The kernel is bound by DEPENDENT LOAD ROUND TRIPS (~2 us each with 4 k waves in flight, measured with
+// s_memrealtime stamps), neither by bytes nor by flops, so it is shaped to need three of them:
+//   1. perms  -> items : the DT matrices that touch this image (anchor role: A side of every pair-set tile of
+//                        the image; negatives: the (i,b) with perm_i[b] == image, found with ballots)
+//   2. scan           : the (y0 << 16 | x0) word of every point of <= 6 items; points whose upper or lower
+//                        tap row is MY row are compacted (ballot + mbcnt) into a 4-byte worklist in LDS
+//   3. drain          : 40 entries per step; the 16 lanes of entry k = lane / 16 load its DT row (B operand,
+//                        5 dwords per lane) AND its 32-byte tap record (one dword per lane, spread to the group
+//                        with ds_bpermute) in the same round; the A operand is the one-hot weight of pixel lane % 16
+// and every row has to be in flight at once (register budget: 128 VGPRs -> 4 waves per SIMD -> 4096 waves).
+// Rows of the anchor image (forward mode, dest 0) collect ~12 items, the others one: a HEAVY row gets a
+// workgroup whose 3 waves take every 3rd item and reduce-scatter their partial rows through LDS at the end;
+// light rows are one wave each.
+constexpr int UR_WAVES = 3;
+constexpr int UR_GROUP = 6;          // items scanned per step; a point hits a row at most once -> <= 6*128 entries
+constexpr int UR_CAP = UR_GROUP * TP;
+constexpr int UR_ITEMCAP = 96;       // a pass looks at 256 candidates; only heavy rows have > 1, split over 3 waves
 constexpr int UR_NT = 5;             // 16-channel tiles (K <= 72)
-constexpr int UR_EG = 4;             // groups of 4 entries per drain step
+constexpr int UR_EG = 9;             // groups of 4 entries per drain step (54 loads in flight per lane; 10 spills)
 
 __device__ __forceinline__ int lane_prefix(unsigned long long mask)
 {
@@ -398,20 +398,25 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask)
 }
 
 template <int MT>        // 16-pixel tiles per row: W <= 16 * MT
-__global__ void __launch_bounds__(UR_WAVES * 64) corr_unsample_row_kernel(const BwdParams prm)
+__global__ void __launch_bounds__(UR_WAVES * 64, MT <= 2 ? 4 : 2) corr_unsample_row_kernel(const BwdParams prm)
 {
-    __shared__ __attribute__((aligned(16))) UnsRowEntry wl_s[UR_WAVES][UR_CAP];
+    constexpr int RED_BYTES = UR_WAVES * UR_NT * 64 * (int)sizeof(f32x4);          // reduction buffer, aliases the worklists
+    constexpr int WL_BYTES = UR_WAVES * MT * UR_CAP * 4;      // one worklist per 16-pixel tile
+    __shared__ __attribute__((aligned(16))) unsigned char wl_raw[RED_BYTES > WL_BYTES ? RED_BYTES : WL_BYTES];
     __shared__ __attribute__((aligned(8))) int2 items_s[UR_WAVES][UR_ITEMCAP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = prm.B, P = prm.P, K = prm.K, W = prm.W, H = prm.H, ldk = prm.LDK;
     const bool direct = prm.mode == 1;
-    const int unit = blockIdx.x * UR_WAVES + wave;          // (dest, image j, row r); heavy dest 0 first
+    const int n_heavy = direct ? 0 : B * H;                 // units are (dest, image j, row r); heavy dest 0 first
+    const bool heavy = (int)blockIdx.x < n_heavy;
+    const int unit = heavy ? (int)blockIdx.x : n_heavy + ((int)blockIdx.x - n_heavy) * UR_WAVES + wave;
+    const int sub = heavy ? wave : 0, nsub = heavy ? UR_WAVES : 1;
     if (unit >= 2 * B * H) return;
     const int r = unit % H;
     const int j = (unit / H) % B;
     const int dest = unit / (H * B);
-    UnsRowEntry* wl = wl_s[wave];
+    int* wl = reinterpret_cast<int*>(wl_raw) + wave * MT * UR_CAP;
     int2* items = items_s[wave];
     const int side_elems = TP * ldk;
     const int n_own = (!direct && dest == 0) ? prm.n_sets : 1;
@@ -420,16 +425,29 @@ __global__ void __launch_bounds__(UR_WAVES * 64) corr_unsample_row_kernel(const 
     int cch[UR_NT];                                          // channel of this lane in each N tile, kept inside the DT row
 #pragma unroll
     for (int nt = 0; nt < UR_NT; ++nt) cch[nt] = min(16 * nt + l16, ldk - 1);
+    // word of the 32-byte tap record this lane fetches for its entry: lanes 0-3 the pixel words, 4-7 the weights
+    // (32-bit offsets from uniform bases: one address VGPR per load instead of two)
+    const int* tap_words = reinterpret_cast<const int*>(prm.tapyx);
+    const unsigned meta_off = l16 < 4 ? (unsigned)l16
+                                      : (unsigned)(reinterpret_cast<const int*>(prm.tapw) - tap_words) + (unsigned)(l16 & 3);
+    const int grp_lane0 = lane & 48;
 
     f32x4 acc[MT][UR_NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < UR_NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // debug bit 8: start / end of every workgroup on the 100 MHz global clock (tools/stamps_bwd.py)
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * side_elems);
+    const bool stamp_on = (prm.debug & 8) && threadIdx.x == 0 && blockIdx.x < 4000;
+    if (stamp_on) ts[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
+    int n_seen = 0;
+    static_assert(UR_ITEMCAP * UR_WAVES >= 256 && UR_ITEMCAP <= 128, "item table vs candidate pass / 7-bit item index");
     for (int u0 = 0; u0 < n_cand; u0 += 256) {
         // ---- item table from the next 256 candidates (loads issued together)
         int n_items = 0;
+        const int n_before = (n_seen + nsub - 1 - sub) / nsub;      // items this wave took in earlier passes
         {
             long long pv[4];
 #pragma unroll
@@ -452,77 +470,118 @@ __global__ void __launch_bounds__(UR_WAVES * 64) corr_unsample_row_kernel(const 
                     s = 2 * B + (u - n_own); tile0 = s; side = 1;
                 }
                 const unsigned long long mask = __ballot(m);
-                if (m) items[n_items + lane_prefix(mask)] = make_int2(s, (tile0 * 2 + side) * side_elems);
-                n_items += __builtin_popcountll(mask);
+                const int ord = n_seen + lane_prefix(mask);          // this wave takes every nsub-th item
+                if (m && ord % nsub == sub) items[ord / nsub - n_before] = make_int2(s, (tile0 * 2 + side) * side_elems);
+                n_seen += __builtin_popcountll(mask);
             }
+            n_items = (n_seen + nsub - 1 - sub) / nsub - n_before;
         }
         __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler
 
-        for (int it_pos = 0; it_pos < n_items;) {
-            // ---- scan groups of items while the worst case still fits: which taps land on row r?
-            int count = 0;
-            while (it_pos < n_items && count + UR_GROUP * TP <= UR_CAP) {
-                int4 yx[UR_GROUP][2];
-                float4 tw[UR_GROUP][2];
-                int dtb[UR_GROUP];
+        for (int it_pos = 0; it_pos < n_items; it_pos += UR_GROUP) {
+            // ---- scan a group of items: which points have a tap row on row r?  Only the (y0 << 16 | x0) word
+            // of the tap record is read here; the lower row is y0 + 1 (a clamped lower row has zero weights).
+            // An entry only feeds the 16-pixel tile(s) its two taps fall in, so entries are binned per tile
+            // (x0 % 16 == 15 goes to two bins) and a group of 4 entries costs 5 MFMAs instead of 5 * MT: the
+            // MFMA pipe is what this kernel saturates first (ablation: scan 7.6 us, + loads 12.5 us, + MFMA 25 us
+            // before binning).
+            int cnt[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) cnt[m] = 0;
+            {
+                int yx0[UR_GROUP][2];
 #pragma unroll
                 for (int g = 0; g < UR_GROUP; ++g) {
                     const int2 it = items[min(it_pos + g, n_items - 1)];
-                    dtb[g] = it.y;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        yx[g][h] = prm.tapyx[(size_t)it.x * TP + h * 64 + lane];
-                        tw[g][h] = prm.tapw[(size_t)it.x * TP + h * 64 + lane];
-                    }
+                    for (int h = 0; h < 2; ++h)
+                        yx0[g][h] = reinterpret_cast<const int*>(prm.tapyx + (size_t)it.x * TP + h * 64 + lane)[0];
                 }
 #pragma unroll
                 for (int g = 0; g < UR_GROUP; ++g) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int q = h * 64 + lane;
-                        const int y0 = yx[g][h].x >> 16, y1 = yx[g][h].z >> 16;
-                        // a point touches row r through its upper OR its lower tap pair (a clamped lower row,
-                        // y1 == y0, carries zero weights)
-                        const bool low = y0 != r;
-                        const float wa = low ? tw[g][h].z : tw[g][h].x, wb = low ? tw[g][h].w : tw[g][h].y;
-                        const bool hit = it_pos + g < n_items && q < P && (y0 == r || y1 == r) && (wa != 0.f || wb != 0.f);
-                        const unsigned long long mask = __ballot(hit);
-                        if (hit) {
-                            UnsRowEntry e;
-                            e.dtoff = dtb[g] + q * ldk;
-                            e.x01 = yx[g][h].x & 0xffff;
-                            e.wa = wa; e.wb = wb;
-                            wl[count + lane_prefix(mask)] = e;
+                        const int y0 = yx0[g][h] >> 16, x0 = yx0[g][h] & 0xffff;
+                        const bool hit = it_pos + g < n_items && q < P && (y0 == r || y0 + 1 == r);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const bool mine = hit && ((x0 >> 4) == m || x0 == 16 * m - 1);
+                            const unsigned long long mask = __ballot(mine);
+                            if (mine) wl[m * UR_CAP + cnt[m] + lane_prefix(mask)] = (it_pos + g) << 7 | q;
+                            cnt[m] += __builtin_popcountll(mask);
                         }
-                        count += __builtin_popcountll(mask);
                     }
                 }
-                it_pos += UR_GROUP;
             }
             __builtin_amdgcn_wave_barrier();
+            // virtual entry order: bin 0, padded to a multiple of 4, then bin 1, ...  (every group of 4 is one bin)
+            int off[MT + 1];
+            off[0] = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) off[m + 1] = off[m] + ((cnt[m] + 3) & ~3);
+            int count = off[MT];
 
-            // ---- drain: 4 groups of 4 entries per step, entry k = lane / 16 of each group
+            // ---- drain: UR_EG groups of 4 entries per step, entry k = lane / 16 of each group
+            if (prm.debug & 128) count = 0;                // ablation: no drain at all
             for (int e0 = 0; e0 < count; e0 += 4 * UR_EG) {
-                UnsRowEntry E[UR_EG];
                 float bv[UR_EG][UR_NT];
+                int meta[UR_EG];
 #pragma unroll
                 for (int g = 0; g < UR_EG; ++g) {
-                    const int e = e0 + 4 * g + k4;
-                    E[g] = wl[min(e, count - 1)];
-                    if (e >= count) { E[g].wa = 0.f; E[g].wb = 0.f; }
+                    const int eg = min(e0 + 4 * g, count - 4);               // group start (uniform), clamped
+                    int m = 0;
 #pragma unroll
-                    for (int nt = 0; nt < UR_NT; ++nt) bv[g][nt] = prm.dt[E[g].dtoff + cch[nt]];
+                    for (int mm = 1; mm < MT; ++mm) m += eg >= off[mm] ? 1 : 0;
+                    int base = 0, n = cnt[0], o = 0;
+#pragma unroll
+                    for (int mm = 1; mm < MT; ++mm) if (m == mm) { base = mm * UR_CAP; n = cnt[mm]; o = off[mm]; }
+                    const int pk = wl[base + min(eg - o + k4, n - 1)];
+                    const int2 it = items[pk >> 7];
+                    const int q = pk & (TP - 1);
+                    const unsigned rowoff = (unsigned)(it.y + q * ldk);
+#pragma unroll
+                    for (int nt = 0; nt < UR_NT; ++nt) bv[g][nt] = prm.dt[rowoff + (unsigned)cch[nt]];
+                    meta[g] = tap_words[(unsigned)(it.x * TP + q) * 4u + meta_off];
                 }
-                __builtin_amdgcn_sched_barrier(0);          // all 20 loads are in flight before the first MFMA waits
+                __builtin_amdgcn_sched_barrier(0);          // every load is in flight before the first use waits
+                if (prm.debug & 64) {                        // ablation: loads only
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < UR_EG; ++g) {
+                        sum += __builtin_bit_cast(float, meta[g]);
+#pragma unroll
+                        for (int nt = 0; nt < UR_NT; ++nt) sum += bv[g][nt];
+                    }
+                    acc[0][0][0] += sum;
+                    continue;
+                }
 #pragma unroll
                 for (int g = 0; g < UR_EG; ++g) {
+                    const int eg = e0 + 4 * g;
+                    if (eg < count) {                                          // uniform: skip the tail groups
+                        int m = 0;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int dx = 16 * mt + l16 - E[g].x01;
-                        const float a = dx == 0 ? E[g].wa : (dx == 1 ? E[g].wb : 0.f);
+                        for (int mm = 1; mm < MT; ++mm) m += eg >= off[mm] ? 1 : 0;
+                        int n = cnt[0], o = 0;
 #pragma unroll
-                        for (int nt = 0; nt < UR_NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][nt], acc[mt][nt], 0, 0, 0);
+                        for (int mm = 1; mm < MT; ++mm) if (m == mm) { n = cnt[mm]; o = off[mm]; }
+                        const int yx = __shfl(meta[g], grp_lane0, 64);
+                        const int x0 = yx & 0xffff;
+                        const int low = (yx >> 16) != r ? 2 : 0;       // my row is the lower tap row of this point
+                        float wa = __builtin_bit_cast(float, __shfl(meta[g], grp_lane0 + 4 + low, 64));
+                        float wb = __builtin_bit_cast(float, __shfl(meta[g], grp_lane0 + 5 + low, 64));
+                        if (eg - o + k4 >= n) { wa = 0.f; wb = 0.f; }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (m == mt) {                                     // uniform
+                                const int dx = 16 * mt + l16 - x0;
+                                const float a = dx == 0 ? wa : (dx == 1 ? wb : 0.f);
+#pragma unroll
+                                for (int nt = 0; nt < UR_NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][nt], acc[mt][nt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -533,17 +592,46 @@ __global__ void __launch_bounds__(UR_WAVES * 64) corr_unsample_row_kernel(const 
     // ---- the row, once, from the accumulators: acc[mt][nt][reg] is pixel 16 mt + 4 (lane / 16) + reg,
     //      channel 16 nt + lane % 16
     float* out = (dest == 0 ? prm.d_code : prm.d_code_pos) + ((size_t)j * H + r) * W * K;
+    if (!heavy) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int x = 16 * mt + 4 * k4 + reg;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int x = 16 * mt + 4 * k4 + reg;
 #pragma unroll
-            for (int nt = 0; nt < UR_NT; ++nt) {
+                for (int nt = 0; nt < UR_NT; ++nt) {
+                    const int ch = 16 * nt + l16;
+                    if (x < W && ch < K) out[(size_t)x * K + ch] = acc[mt][nt][reg];
+                }
+            }
+        return;
+    }
+    // heavy row: reduce-scatter the partial rows, one pixel tile (5 accumulator tiles) per round; wave w sums
+    // and stores tiles w, w + 3.  The buffer aliases the (now idle) worklists.
+    f32x4* red = reinterpret_cast<f32x4*>(wl_raw);             // [wave][5 tiles][64 lanes]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < UR_NT; ++nt) red[(wave * UR_NT + nt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < (UR_NT + UR_WAVES - 1) / UR_WAVES; ++t) {
+            const int nt = wave + UR_WAVES * t;                // wave-uniform
+            if (nt < UR_NT) {
+                f32x4 v = red[nt * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < UR_WAVES; ++w2) v += red[(w2 * UR_NT + nt) * 64 + lane];
                 const int ch = 16 * nt + l16;
-                if (x < W && ch < K) out[(size_t)x * K + ch] = acc[mt][nt][reg];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int x = 16 * mt + 4 * k4 + reg;
+                    if (x < W && ch < K) out[(size_t)x * K + ch] = v[reg];
+                }
             }
         }
+    }
+    if (stamp_on) ts[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
@@ -579,8 +667,9 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     // ---- unsample: row-owned register kernel for W <= 64, LDS band kernel beyond
-    if (prm.W <= 64 && !(prm.debug & 32)) {
-        const dim3 grid((2 * prm.B * prm.H + UR_WAVES - 1) / UR_WAVES), block(UR_WAVES * 64);
+    if (prm.W <= 64 && (size_t)prm.n_sets * prm.B * 2 * TP * prm.LDK < ((size_t)1 << 31) && !(prm.debug & 32)) {
+        const int n_heavy = prm.mode == 1 ? 0 : prm.B * prm.H;
+        const dim3 grid(n_heavy + (2 * prm.B * prm.H - n_heavy + UR_WAVES - 1) / UR_WAVES), block(UR_WAVES * 64);
         if (prm.W <= 32) hipLaunchKernelGGL((corr_unsample_row_kernel<2>), grid, block, 0, stream, prm);
         else hipLaunchKernelGGL((corr_unsample_row_kernel<4>), grid, block, 0, stream, prm);
         return hipGetLastError();

@@ -26,5 +26,13 @@ for rep in range(3):
                             dc.data_ptr(), dcp.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
     torch.cuda.synchronize()
-ts = ws[nws - 4096: nws - 4096 + 256].view(torch.int64).cpu().tolist()
-print("stamps (cycles rel):", [t - ts[0] for t in ts[:12] if t > 0], "NC", ts[30], "row0 counts per round", ts[24:28])
+import numpy as np
+nblk = B * H + (B * H + 2) // 3
+ts = ws[nws - 65536: nws - 65536 + 16 * nblk].view(torch.int64).cpu().numpy().reshape(nblk, 2)
+t0 = ts[:, 0].min()
+st, en = (ts[:, 0] - t0) / 100.0, (ts[:, 1] - t0) / 100.0
+print("blocks", nblk, "span us", en.max())
+for name, sl in (("heavy", slice(0, B * H)), ("light", slice(B * H, nblk))):
+    print(name, "start p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile(st[sl], [0, 50, 100])),
+          "end p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile(en[sl], [0, 50, 100])),
+          "dur p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile((en - st)[sl], [0, 50, 100])))
