@@ -90,6 +90,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     const int sB = direct ? B + b : (p == 0 ? b : p * B + b);
     const float* Bn = sameAB ? An : reinterpret_cast<const float*>(Bn_b);
 
+    // debug bit 8: phase stamps (100 MHz global clock), 4 per tile, second half of the workspace tail
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)blockIdx.x * 4;
+    const bool stamp_on = (prm.debug & 8) && tid == 0 && blockIdx.x < 1024;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
     // ---- async copies of the normalised sampled codes (saved by the forward) + their norms
     {
         const unsigned char* srcA = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sA * cside;
@@ -160,6 +164,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         }
     }
     __syncthreads();       // (vmcnt(0)) An/Bn landed, G complete
+    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- dAn = G . Bn  and  dBn = G^T . An   on v_mfma_f32_16x16x4_f32
     // operand lane map: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         }
     }
 
+    if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
     // ---- normalize backward -> DT[tile][side]
     if (sameAB) {
 #pragma unroll
@@ -204,6 +210,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     normalize_bwd_store<NT>(dA, An, ldk, nrm, dtA, K, prm.KQ, lane, wave);
     if (!sameAB)
         normalize_bwd_store<NT>(dB, Bn, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
+    if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------- unsample

@@ -380,60 +380,92 @@ __device__ __forceinline__ void park_plain(const f32x16 (&acc)[2][2], float* __r
     }
 }
 
-// Epilogue of the dense kernel (4 waves): row means by one lane per row (121 independent LDS reads,
-// no cross-lane traffic), row-wise coalesced stores, one 3-value block reduction at the end.
-__device__ __forceinline__ void tile_epilogue_dense(const CorrParams& prm, const float* __restrict__ Tfd,
-                                                    const float* __restrict__ Tcd, float* __restrict__ rowmean,
-                                                    float* __restrict__ red, int p, int b, bool direct)
+// Result tiles are parked in LDS in the FLAT layout of the outputs, T[a + row * P + col], so that the epilogue
+// is a linear sweep: 16-byte LDS reads, 16-byte global stores.  `a` = the output tile's start address / 4 mod 4
+// (tiles are P*P floats apart and P*P is odd, so they are only 4-byte aligned): with the same shift in LDS
+// both sides of the copy are 16-byte aligned at the same time.
+__device__ __forceinline__ void park_flat(const f32x16 (&acc)[2][2], float* __restrict__ T, int P, int lane, int wr, int wc)
+{
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = 64 * wc + 32 * ni + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < P && col < P) T[row * P + col] = acc[mi][ni][r];
+            }
+    }
+}
+
+// Epilogue of the dense kernel (4 waves): row means by two lanes per row, then a flat sweep over the tile
+// (the first version looped rows with 4-byte stores: 186 store instructions per wave, ~24 us of the kernel).
+__device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const float* __restrict__ Tfd,
+                                                   const float* __restrict__ Tcd, float* __restrict__ rowmean,
+                                                   float* __restrict__ red, int p, int b, bool direct, int a,
+                                                   float* cd_out, float* loss_out, float* w_out, float shift, bool vec_ok)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = prm.B, P = prm.P;
     float fd_part = 0.f;
-    if (tid < TP) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (tid < P) {
-            const float* row = Tfd + tid * LDT;
-            int c = 0;
-            for (; c + 4 <= P; c += 4) { s0 += row[c]; s1 += row[c + 1]; s2 += row[c + 2]; s3 += row[c + 3]; }
-            for (; c < P; ++c) s0 += row[c];
+    {
+        const int row = tid >> 1, half = tid & 1;
+        const int hl = (P + 1) >> 1;
+        float s0 = 0.f, s1 = 0.f;
+        if (row < P) {
+            const float* src = Tfd + a + row * P;
+            const int c1 = half ? P : hl;
+            int c = half ? hl : 0;
+            for (; c + 2 <= c1; c += 2) { s0 += src[c]; s1 += src[c + 1]; }
+            if (c < c1) s0 += src[c];
         }
-        fd_part = (s0 + s1) + (s2 + s3);
-        rowmean[tid] = prm.pointwise ? fd_part / (float)P : 0.f;    // fd.mean([3,4]) (modules.py:332)
+        float sfull = s0 + s1;
+        sfull += __shfl_xor(sfull, 1, 64);
+        if (half == 0) {
+            fd_part = sfull;
+            if (row < TP) rowmean[row] = prm.pointwise ? sfull / (float)P : 0.f;    // fd.mean([3,4]) (modules.py:332)
+        }
     }
     __syncthreads();
 
     const int P2 = P * P;
-    float* cd_out;
-    float* loss_out = nullptr;
-    float shift;
-    if (direct) { cd_out = prm.neg_cd + (size_t)b * P2; loss_out = prm.neg_loss + (size_t)b * P2; shift = prm.shift[0]; }
-    else if (p == 0) { cd_out = prm.intra_cd + (size_t)b * P2; shift = prm.shift[0]; }
-    else if (p == 1) { cd_out = prm.inter_cd + (size_t)b * P2; shift = prm.shift[1]; }
-    else {
-        cd_out = prm.neg_cd + ((size_t)(p - 2) * B + b) * P2;
-        loss_out = prm.neg_loss + ((size_t)(p - 2) * B + b) * P2;
-        shift = prm.shift[2];
-    }
-    float* w_out = prm.saved_w ? prm.saved_w + ((size_t)p * B + b) * P2 : nullptr;
     const float cmin = prm.cmin, cmax = prm.cmax;
+    const float invP = 1.f / (float)P;
     float loss_part = 0.f, clamp_part = 0.f;
     if (!(prm.debug & 8)) {
-        for (int r = wave; r < P; r += 4) {
-            const float rm = rowmean[r] + shift;
-#pragma unroll 2
-            for (int c = lane; c < P; c += 64) {
-                const int idx = r * P + c;
-                const float w = Tfd[r * LDT + c] - rm;                     // fd_centred - shift
-                const float cdv = Tcd[r * LDT + c];
-                const float cl = fminf(fmaxf(cdv, cmin), cmax);
-                const float lp = -cl * w;                                  // loss without the old_mean term
-                if (!(prm.debug & 4)) {
-                    cd_out[idx] = cdv;
-                    if (loss_out) loss_out[idx] = lp;
-                    if (w_out) w_out[idx] = w;
-                }
-                loss_part += lp;
-                clamp_part += cl;
+        const int nvec = (a + P2 + 3) >> 2;
+        for (int v = tid; v < nvec; v += NTHREADS) {
+            const int f0 = 4 * v;
+            const f32x4 fd4 = *reinterpret_cast<const f32x4*>(Tfd + f0);
+            const f32x4 cd4 = *reinterpret_cast<const f32x4*>(Tcd + f0);
+            f32x4 w4, lp4;
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = f0 + k - a;
+                ok[k] = e >= 0 && e < P2;
+                const int r = min(max((int)(((float)e + 0.5f) * invP), 0), P - 1);
+                const float w = fd4[k] - (rowmean[r] + shift);                 // fd_centred - shift
+                const float cl = fminf(fmaxf(cd4[k], cmin), cmax);
+                const float lp = -cl * w;                                      // loss without the old_mean term
+                w4[k] = w; lp4[k] = lp;
+                if (ok[k]) { loss_part += lp; clamp_part += cl; }
+            }
+            if (prm.debug & 4) continue;
+            const int e0 = f0 - a;
+            if (vec_ok && ok[0] && ok[3]) {
+                *reinterpret_cast<f32x4*>(cd_out + e0) = cd4;
+                if (loss_out) *reinterpret_cast<f32x4*>(loss_out + e0) = lp4;
+                if (w_out) *reinterpret_cast<f32x4*>(w_out + e0) = w4;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ok[k]) {
+                        cd_out[e0 + k] = cd4[k];
+                        if (loss_out) loss_out[e0 + k] = lp4[k];
+                        if (w_out) w_out[e0 + k] = w4[k];
+                    }
             }
         }
     }
@@ -493,6 +525,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
         }
     };
 
+    // debug bit 256: phase stamps of every workgroup on the 100 MHz global clock (tools/stamps.py)
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.stats + (size_t)prm.n_sets * B * 4 + 256) + (size_t)blockIdx.x * 8;
+    const bool stamp_on = (prm.debug & 256) && tid == 0;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
     f32x16 accf[2][2], accc[2][2];
     zero_acc(accf);
     zero_acc(accc);
@@ -515,11 +551,31 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
             mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
         }
     }
+    // ---- where this tile's outputs go
+    const int P = prm.P, P2 = P * P;
+    float* cd_out;
+    float* loss_out = nullptr;
+    float shift;
+    if (direct) { cd_out = prm.neg_cd + (size_t)b * P2; loss_out = prm.neg_loss + (size_t)b * P2; shift = prm.shift[0]; }
+    else if (p == 0) { cd_out = prm.intra_cd + (size_t)b * P2; shift = prm.shift[0]; }
+    else if (p == 1) { cd_out = prm.inter_cd + (size_t)b * P2; shift = prm.shift[1]; }
+    else {
+        cd_out = prm.neg_cd + ((size_t)(p - 2) * B + b) * P2;
+        loss_out = prm.neg_loss + ((size_t)(p - 2) * B + b) * P2;
+        shift = prm.shift[2];
+    }
+    float* w_out = prm.saved_w ? prm.saved_w + ((size_t)p * B + b) * P2 : nullptr;
+    const int a = (int)((reinterpret_cast<uintptr_t>(cd_out) >> 2) & 3);
+    const bool vec_ok = (!loss_out || (int)((reinterpret_cast<uintptr_t>(loss_out) >> 2) & 3) == a) &&
+                        (!w_out || (int)((reinterpret_cast<uintptr_t>(w_out) >> 2) & 3) == a);
     __syncthreads();                             // stage buffers are dead: park the result tiles over them
-    park_plain(accf, Tfd, lane, wr, wc);
-    park_plain(accc, Tcd, lane, wr, wc);
+    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
+    park_flat(accf, Tfd + a, P, lane, wr, wc);
+    park_flat(accc, Tcd + a, P, lane, wr, wc);
     __syncthreads();
-    tile_epilogue_dense(prm, Tfd, Tcd, rowmean, red, p, b, direct);
+    if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
+    tile_epilogue_flat(prm, Tfd, Tcd, rowmean, red, p, b, direct, a, cd_out, loss_out, w_out, shift, vec_ok);
+    if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
 }
 
 // Applies the batch-global mean of each pair-set:  old_mean_p = mean_{b,hw,ij} fd  (modules.py:331),

@@ -36,3 +36,10 @@ for name, sl in (("heavy", slice(0, B * H)), ("light", slice(B * H, nblk))):
     print(name, "start p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile(st[sl], [0, 50, 100])),
           "end p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile(en[sl], [0, 50, 100])),
           "dur p0/p50/p100 %.2f %.2f %.2f" % tuple(np.percentile((en - st)[sl], [0, 50, 100])))
+
+nt = (2 + n_neg) * B
+tt = ws[nws - 65536 + 32768: nws - 65536 + 32768 + 32 * nt].view(torch.int64).cpu().numpy().reshape(nt, 4)
+t0 = tt[:, 0].min()
+rel = (tt - t0) / 100.0
+for k, n in enumerate(["start", "G + copies", "mfma", "end"]):
+    print("tile kernel %-11s p0/p50/p100 %.2f %.2f %.2f us" % ((n,) + tuple(np.percentile(rel[:, k], [0, 50, 100]))))
