@@ -9,7 +9,6 @@
 namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
-hipError_t launch_corr_fwd_simple(const CorrParams& prm, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream);
 }  // namespace stego
@@ -72,7 +71,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     const size_t n_tiles = (size_t)(helper ? 1 : 2 + d->n_neg) * d->B;
     g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * 64, 256);      // tail: debug stamps (8 per tile)
     const size_t fside = d->precision == STEGO_PREC_BF16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
-    g.fs_bytes = round_up((size_t)g.nset * g.NCH * fside + 1024, 256);
+    g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only
     g.cs_bytes = round_up((size_t)g.nset * TP * g.LDK * sizeof(float) + 1024, 256);
     g.nrm_bytes = round_up((size_t)g.nset * TP * sizeof(float), 256);
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
@@ -116,7 +115,6 @@ struct FwdPlan {
     CorrParams tile;
     SampleParams samp;
     int precision;
-    bool simple;
 };
 
 int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code,
@@ -178,13 +176,13 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     sp.tapyx = reinterpret_cast<int4*>(ctx + g.cs_bytes + g.nrm_bytes);
     sp.tapw = reinterpret_cast<float4*>(ctx + g.cs_bytes + g.nrm_bytes + g.tap_bytes);
     sp.B = d->B; sp.C = d->C; sp.K = d->K; sp.H = d->H; sp.W = d->W; sp.S = prm.S; sp.P = prm.P;
-    sp.n_roles = g.n_roles; sp.NCH = g.NCH; sp.KQ = g.KQ; sp.LDK = g.LDK; sp.mode = prm.mode;
+    sp.n_roles = g.n_roles; sp.feat_roles = 1; sp.NCH = g.NCH; sp.KQ = g.KQ; sp.LDK = g.LDK; sp.mode = prm.mode;
     sp.debug = env_int("STEGO_DEBUG_SAMPLE", 0);
 
+    prm.tapyx = sp.tapyx; prm.tapw = sp.tapw;
     out->tile = prm;
     out->samp = sp;
     out->precision = d->precision;
-    out->simple = env_int("STEGO_FWD_VARIANT", 1) == 0 && d->precision == STEGO_PREC_F32;
     return STEGO_OK;
 }
 
@@ -192,14 +190,9 @@ hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [
 {
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (pl.simple) {
-        if (ev) (void)hipEventRecord(ev[1], s);
-        if ((e = launch_corr_fwd_simple(pl.tile, s)) != hipSuccess) return e;
-    } else {
-        if ((e = launch_corr_sample(pl.samp, pl.precision, s)) != hipSuccess) return e;
-        if (ev) (void)hipEventRecord(ev[1], s);
-        if ((e = launch_corr_tile(pl.tile, pl.precision, s)) != hipSuccess) return e;
-    }
+    if ((e = launch_corr_sample(pl.samp, pl.precision, s)) != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if ((e = launch_corr_tile(pl.tile, pl.precision, s)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[2], s);
     if ((e = launch_corr_finalize(pl.tile, s)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[3], s);

@@ -41,8 +41,10 @@ struct CorrParams {
     float* saved_mean;                         // [n_sets] or null
     float* loss_means;                         // [2] or null (mode 1)
     float* stats;                              // workspace [n_sets*B][4]
-    const void* fs;                            // stage-1 outputs (dense kernel): sampled normalised features
-    const float* cs;                           //                                 sampled normalised codes
+    const void* fs;                            // sampler outputs: normalised ANCHOR features as LDS images [B][NCH][..]
+    const float* cs;                           //                  normalised sampled codes of every set [nset][128][LDK]
+    const int4* tapyx;                         //                  bilinear tap pixels  [nset][128]
+    const float4* tapw;                        //                  bilinear tap weights [nset][128]
     int NCH, KQ, LDK;
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int mode;                                  // 0 = forward() semantics, 1 = helper() on pre-sampled maps
@@ -58,13 +60,14 @@ struct SampleParams {
     const float* coords1;
     const float* coords2;
     const long long* perms;                    // [n_neg][B]
-    void* fs;                                  // f32: [nset][NCH][128][LDA] float; bf16x3: [nset][NCH][2][128][LDH] bf16
+    void* fs;                                  // f32: [B][NCH][128][LDA] float; bf16x3: [B][NCH][2][128][LDH] bf16 (roles < feat_roles)
     float* cs;                                 // [nset][128][LDK] normalised sampled codes
     float* nrm;                                // [nset][128] code norms before normalisation
     int4* tapyx;                               // optional [nset][128] packed tap pixels (for the backward)
     float4* tapw;                              // optional [nset][128] tap weights
     int B, C, K, H, W, S, P;
     int n_roles;                               // 2 + n_neg (helper: 2)
+    int feat_roles;                            // features are sampled for roles < feat_roles (1: anchors only)
     int NCH;                                   // ceil(C/64)
     int KQ, LDK;                               // round_up(K,8), KQ+4
     int mode;                                  // 0 forward(), 1 helper() (pixel-for-pixel)
@@ -166,127 +169,6 @@ __device__ __forceinline__ void split_bf16_pair(float x, float y, unsigned& hi, 
     const float hx = __builtin_bit_cast(float, hi << 16), hy = __builtin_bit_cast(float, hi & 0xffff0000u);
     const bf16x2 l = __builtin_convertvector(f32x2{x - hx, y - hy}, bf16x2);
     lo = __builtin_bit_cast(unsigned, l);
-}
-
-// Gather one chunk of channels [c0, c0+ncols) of 128 sampled points into an LDS tile, blending
-// the 4 bilinear taps on the fly and accumulating each point's sum of squares (for the L2 norm).
-//   PREC_F32   : dst is float  [128][LD]          (LD in floats)
-//   PREC_BF16X3: dst is bf16 hi[128][LD] followed by lo[128][LD] (LD in bf16 elements; lo at +128*LD)
-// V = channels per lane-load (4/2 need channel stride 1 and 16/8-byte aligned pixels; 1 is generic).
-// Thread mapping (team of 256 threads, index t): SLOTS=KC/V lanes cover one point's chunk -> one
-// contiguous KC*4-byte read per tap per point.  The loop is branch-free and loads are issued
-// BATCH items (4*BATCH loads) at a time so that many loads are in flight per lane.
-template <int V, int LD, int PREC, int BATCH>
-__device__ __forceinline__ void gather_chunk(const float* __restrict__ img, int sc, const int4* __restrict__ tapo,
-                                             const float4* __restrict__ tapw, int c0, int Ctot, int ncols,
-                                             void* __restrict__ dst_, float (&ss)[TP * (KC / V) / NTHREADS], int t)
-{
-    typedef typename VecT<V>::type vec;
-    constexpr int SLOTS = KC / V;
-    constexpr int ITEMS = TP * SLOTS / NTHREADS;
-    constexpr int PPI = NTHREADS / SLOTS;
-    static_assert(ITEMS % BATCH == 0, "batch must divide the item count");
-    const int slot = t % SLOTS, prow = t / SLOTS;
-    const int col = slot * V;
-    if (col >= ncols) return;
-    const int ch = c0 + col;
-    const bool chok = ch < Ctot;                       // beyond the last channel: zero fill
-    const float* base = img + (long long)(chok ? ch : 0) * sc;
-#pragma unroll
-    for (int it0 = 0; it0 < ITEMS; it0 += BATCH) {
-        int4 o[BATCH];
-        float4 w[BATCH];
-        vec tv[BATCH][4];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            const int q = (it0 + j) * PPI + prow;
-            o[j] = tapo[q];
-            w[j] = tapw[q];
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            tv[j][0] = *reinterpret_cast<const vec*>(base + o[j].x);
-            tv[j][1] = *reinterpret_cast<const vec*>(base + o[j].y);
-            tv[j][2] = *reinterpret_cast<const vec*>(base + o[j].z);
-            tv[j][3] = *reinterpret_cast<const vec*>(base + o[j].w);
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            const int q = (it0 + j) * PPI + prow;
-            float v[V];
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                float t0, t1, t2, t3;
-                if constexpr (V == 1) { t0 = tv[j][0]; t1 = tv[j][1]; t2 = tv[j][2]; t3 = tv[j][3]; }
-                else { t0 = tv[j][0][e]; t1 = tv[j][1][e]; t2 = tv[j][2][e]; t3 = tv[j][3][e]; }
-                float r = w[j].x * t0 + w[j].y * t1 + w[j].z * t2 + w[j].w * t3;
-                r = chok ? r : 0.f;
-                v[e] = r;
-                s += r * r;
-            }
-            ss[it0 + j] += s;
-            if constexpr (PREC == PREC_F32) {
-                float* d = static_cast<float*>(dst_) + q * LD + col;
-                if constexpr (V == 4) *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-                else if constexpr (V == 2) *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
-                else d[0] = v[0];
-            } else {
-                __bf16* dh = static_cast<__bf16*>(dst_) + q * LD + col;
-                __bf16* dl = dh + TP * LD;
-                if constexpr (V == 4) {
-                    unsigned h0, l0, h1, l1;
-                    split_bf16_pair(v[0], v[1], h0, l0);
-                    split_bf16_pair(v[2], v[3], h1, l1);
-                    *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
-                    *reinterpret_cast<u32x2*>(dl) = u32x2{l0, l1};
-                } else if constexpr (V == 2) {
-                    unsigned h0, l0;
-                    split_bf16_pair(v[0], v[1], h0, l0);
-                    *reinterpret_cast<unsigned*>(dh) = h0;
-                    *reinterpret_cast<unsigned*>(dl) = l0;
-                } else {
-                    unsigned h0, l0;
-                    split_bf16_pair(v[0], 0.f, h0, l0);
-                    *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h0 & 0xffffu);
-                    *reinterpret_cast<unsigned short*>(dl) = (unsigned short)(l0 & 0xffffu);
-                }
-            }
-        }
-    }
-}
-
-// Reduce the per-thread sum-of-squares partials over the SLOTS lanes that share a point and
-// publish nrm (=||t||) for the points this thread group owns. t = index in the 256-thread team.
-template <int V>
-__device__ __forceinline__ void publish_norms(float (&ss)[TP * (KC / V) / NTHREADS], float* __restrict__ nrm_out, int t)
-{
-    constexpr int SLOTS = KC / V;
-    constexpr int ITEMS = TP * SLOTS / NTHREADS;
-    constexpr int PPI = NTHREADS / SLOTS;
-    const int slot = t % SLOTS, prow = t / SLOTS;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        float s = ss[it];
-#pragma unroll
-        for (int m = SLOTS / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (slot == 0) nrm_out[it * PPI + prow] = sqrtf(s);
-    }
-}
-
-// Sum over the whole workgroup (NW waves); red needs >= NW floats.  Two barriers inside.
-template <int NW>
-__device__ __forceinline__ float block_sum(float v, float* red)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) s += red[i];
-    return s;
 }
 
 }  // namespace stego

@@ -1,64 +1,66 @@
-// Fused forward of STEGO's ContrastiveCorrelationLoss for gfx950 (MI355X).
+// Forward of STEGO's ContrastiveCorrelationLoss for gfx950 (MI355X): the correlation / loss tile kernel.
 //
-// One workgroup = one (pair-set p, image b) tile:  A side = image b sampled at coords1[b],
-// B side = {same | feats_pos/code_pos[b] @ coords2[b] | feats/code[perm[b]] @ coords2[b]}.
-// Per tile:  bilinear gather (channels-last: one contiguous 256 B read per tap per 64-channel
-// chunk) -> LDS -> MFMA for fd = A_f.B_f^T (contraction C) and cd = A_c.B_c^T (contraction K) on
-// RAW sampled values; the L2 normalisation is applied in the epilogue as row/col scales
-// (fd[i][j] * invn_A[i] * invn_B[j]) - the norms are accumulated during the gather.
-// Epilogue: row-centring of fd (the reference's fd -= fd.mean([3,4]), modules.py:332),
-// clamp(cd)*(fd-shift), coalesced row stores, per-tile partial sums.  The batch-global
-// old_mean (modules.py:331) needs every tile of the pair-set, so it is applied by
-// corr_finalize_kernel from the per-tile sums (deterministic order, no atomics).
+// One workgroup (4 waves, one per SIMD) = one (pair-set p, image b) tile:  A side = anchor set b (image b
+// sampled at coords1[b]),  B side = {same | feats_pos/code_pos[b] @ coords2[b] | feats/code[perm[b]] @ coords2[b]}.
+//   fd = A_f . B_f^T (contraction C, no_grad side)      cd = A_c . B_c^T (contraction K)
+// followed by the reference's epilogue: row-centring of fd (fd -= fd.mean([3,4]), modules.py:332),
+// -clamp(cd) * (fd - shift), flat 16-byte stores, per-tile partial sums.  The batch-global old_mean (:331)
+// needs every tile of a pair-set, so corr_finalize_kernel applies it from the per-tile sums (fixed order).
 //
-// Production path (two launches + finalize):
-//   corr_sample.hip : sample_norm_kernel  - every (role, image) set sampled + L2-normalised ONCE, placed on
-//                     the XCD of its source image, written as ready-made LDS images;
-//   corr_tile_kernel (here) - one workgroup (4 waves, one per SIMD) per (pair-set, image) tile: both
-//                     operands are dense, so the MFMA waves themselves issue async global_load_lds copies
-//                     of chunk t+1 (no VGPRs, no VALU) and run the MFMAs of chunk t in their shadow
-//                     (an f32 MFMA stream starves any OTHER wave on its SIMD, so loader waves do not work).
+// Operands (hybrid staging, round 1 third design):
+//   * A features: the anchor set is used by all 2+n_neg tiles of its image, so sample_norm_kernel
+//     (corr_sample.hip) samples + normalises it ONCE into ready-made LDS images; the MFMA waves copy chunk t+1
+//     with global_load_lds (no VGPRs, no VALU) while they multiply chunk t;
+//   * B features: every B set is used by exactly one tile, so materialising it (52 MB written + 52 MB read
+//     per step in the second design, which made the sampler HBM-bound at 43 us) is pure overhead: the tile
+//     gathers its B operand straight from the source image.  The 4 bilinear taps of chunk t+1 are loaded into
+//     REGISTERS (32 x 16 B per lane) before the MFMAs of chunk t are issued and blended into LDS after them,
+//     so the gather latency hides in the MFMA shadow of the SAME wave (an f32 MFMA stream starves any OTHER
+//     wave on its SIMD, so loader waves do not work).  B is staged RAW; its L2 norm is accumulated during the
+//     gather and applied as a column scale of fd in the epilogue;
+//   * codes (K <= 72, both sides): normalised by the sampler (the backward needs them anyway), one
+//     global_load_lds stage at the end.
 // Contraction arithmetic: PREC_F32 = v_mfma_f32_32x32x2_f32 (exact fp32) for both correlations;
-// PREC_BF16X3 = the feature correlation fd (no_grad side, 85 % of the flops) on split-bf16
-// (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_bf16, fp32 accumulate, ~1e-6 abs error on a cosine); the code
-// correlation cd stays exact f32 because its sign decides the clamp mask of the backward.
-//
-// corr_fwd_kernel (fused gather, 4 waves, no overlap, f32) is the first version kept as a cross-check
-// (STEGO_FWD_VARIANT=0).
+// PREC_BF16X3 = the feature correlation on split-bf16 (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, ~1e-6 abs error on a cosine); the code correlation stays exact f32 because its sign decides the
+// clamp mask of the backward.
 //
 // Reference path: src/modules.py:275-398.
 #include "corr_common.h"
 
 namespace stego {
 
-// ------------------------------------------------------------------ simple kernel smem carve
-constexpr int SM_NRM = 0;                         // float nrm[4][128]: Af, Bf, Ac, Bc
-constexpr int SM_ROWMEAN = SM_NRM + 4 * TP * 4;   // float rowmean[128]
-constexpr int SM_RED = SM_ROWMEAN + TP * 4;       // float red[64]
-constexpr int SM_BIG = SM_RED + 64 * 4;           // 2816, 16-byte aligned
-constexpr int SM_STAGE_BYTES = 2 * TP * LDA * 4 + 3 * 256 * 16;
-constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;
-constexpr int SM_FWD_TOTAL = SM_BIG + (SM_TILES_BYTES > SM_STAGE_BYTES ? SM_TILES_BYTES : SM_STAGE_BYTES);
-
-// ------------------------------------------------------------------ dense tile kernel smem carve
+// ------------------------------------------------------------------ smem carve (dynamic LDS)
 constexpr int SD_ROWMEAN = 0;                     // float rowmean[128]
 constexpr int SD_RED = SD_ROWMEAN + TP * 4;       // float red[64]
-constexpr int SD_BIG = SD_RED + 64 * 4;           // 768: two stage buffers, aliased by the result tiles
+constexpr int SD_CSC = SD_RED + 64 * 4;           // float csc[128]: 1 / ||b_j|| of the gathered B points
+constexpr int SD_TAPO = SD_CSC + TP * 4;          // int4 tapo[128]: element offsets of the 4 taps in the B image
+constexpr int SD_TAPW = SD_TAPO + TP * 16;        // float4 tapw[128]
+constexpr int SD_BIG = SD_TAPW + TP * 16;         // 5376: two stage buffers, aliased by the result tiles
 constexpr int FEAT_SIDE_F32 = TP * LDA * 4;       // 34816 = 34 x 1 KB : one operand, one 64-channel chunk
 constexpr int FEAT_SIDE_BF16 = 2 * TP * LDH * 2;  // 36864 = 36 x 1 KB : hi + lo
+constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;  // epilogue: fd + cd tiles
 
 // One staged chunk of the contraction on v_mfma_f32_32x32x2_f32.  Wave (wr,wc) owns the
 // 64x64 quadrant; lanes 0-31 take k = kk..kk+3, lanes 32-63 k = kk+4..kk+7 of every 8-wide
 // k group via one ds_read_b128 per operand (any k permutation is fine as long as A and B agree).
-__device__ __forceinline__ void mma_chunk_f32(const float* __restrict__ As, const float* __restrict__ Bs, int kc8,
-                                              f32x16 (&acc)[2][2], int lane, int wr, int wc)
+// `pre(s)` is called before the MFMAs of 8-wide k group s: the caller issues a slice of the NEXT chunk's loads
+// there.  (Issuing all ~45 loads of a chunk back to back stalls the wave at issue until the first ones return -
+// the per-wave memory queue is shallow - which cost 8 us per tile; one slice per 16 MFMAs never fills it.)
+template <class F>
+__device__ __forceinline__ void mma_chunk_f32(const float* __restrict__ As, const float* __restrict__ Bs,
+                                              f32x16 (&acc)[2][2], int lane, int wr, int wc, F&& pre)
 {
     const int r = lane & 31, half = lane >> 5;
     const float* a0p = As + (64 * wr + r) * LDA + 4 * half;
     const float* a1p = a0p + 32 * LDA;
     const float* b0p = Bs + (64 * wc + r) * LDA + 4 * half;
     const float* b1p = b0p + 32 * LDA;
-    for (int kk = 0; kk < kc8; kk += 8) {
+#pragma unroll
+    for (int st = 0; st < KC / 8; ++st) {
+        pre(st);
+        __builtin_amdgcn_sched_barrier(0);        // keep each slice of loads in front of its own MFMA group
+        const int kk = 8 * st;             // always the full 64 channels: both operand images are zero-padded
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + kk);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + kk);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + kk);
@@ -100,8 +102,9 @@ __device__ __forceinline__ void mma_code_f32(const float* __restrict__ As, const
 // Split-bf16 contraction of one chunk: a.b ~= ah.bh + ah.bl + al.bh (the al.bl term is < 2^-16).
 // Stage layout: hi[128][LDH] then lo[128][LDH] (bf16).  Each lane reads 8 consecutive k
 // (lanes 0-31: kk..kk+7, lanes 32-63: kk+8..kk+15) per operand with one ds_read_b128.
-__device__ __forceinline__ void mma_chunk_bf16x3(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int kc16,
-                                                 f32x16 (&acc)[2][2], int lane, int wr, int wc)
+template <class F>
+__device__ __forceinline__ void mma_chunk_bf16x3(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs,
+                                                 f32x16 (&acc)[2][2], int lane, int wr, int wc, F&& pre)
 {
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
@@ -109,250 +112,33 @@ __device__ __forceinline__ void mma_chunk_bf16x3(const __bf16* __restrict__ As, 
     const __bf16* a1p = a0p + 32 * LDH;
     const __bf16* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
     const __bf16* b1p = b0p + 32 * LDH;
-    for (int kk = 0; kk < kc16; kk += 16) {
-        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0p + kk), al0 = *reinterpret_cast<const bf16x8*>(a0p + LO + kk);
-        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1p + kk), al1 = *reinterpret_cast<const bf16x8*>(a1p + LO + kk);
-        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b0p + kk), bl0 = *reinterpret_cast<const bf16x8*>(b0p + LO + kk);
-        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b1p + kk), bl1 = *reinterpret_cast<const bf16x8*>(b1p + LO + kk);
-        // small cross terms first, then the leading term; accumulators interleaved
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
-    }
-}
-
-// Scale the raw accumulators by the inverse norms and park the tile in LDS.
-// C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-__device__ __forceinline__ void park_tile(const f32x16 (&acc)[2][2], float* __restrict__ T,
-                                          const float* __restrict__ nrmA, const float* __restrict__ nrmB,
-                                          int lane, int wr, int wc)
-{
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = 64 * wc + 32 * ni + (lane & 31);
-        const float sB = 1.f / fmaxf(nrmB[col], 1e-10f);      // F.normalize eps (modules.py:276)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float sA = 1.f / fmaxf(nrmA[row], 1e-10f);
-                T[row * LDT + col] = acc[mi][ni][r] * sA * sB;
-            }
+    for (int st = 0; st < KC / 8; ++st) {         // 8 slots like the f32 version: MFMAs on the even ones
+        pre(st);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kk = 8 * st;
+        if ((st & 1) == 0) {
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0p + kk), al0 = *reinterpret_cast<const bf16x8*>(a0p + LO + kk);
+            const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1p + kk), al1 = *reinterpret_cast<const bf16x8*>(a1p + LO + kk);
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b0p + kk), bl0 = *reinterpret_cast<const bf16x8*>(b0p + LO + kk);
+            const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b1p + kk), bl1 = *reinterpret_cast<const bf16x8*>(b1p + LO + kk);
+            // small cross terms first, then the leading term; accumulators interleaved
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
         }
     }
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2])
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-}
-
-// Epilogue shared by both kernels (NW waves).  Tfd/Tcd hold the normalised correlation tiles.
-// A wave owns rows wave, wave+NW, ...; its lanes walk the columns, so LDS reads are conflict-free
-// and every global store instruction covers one contiguous run of a row.
-template <int NW>
-__device__ __forceinline__ void tile_epilogue(const CorrParams& prm, const float* __restrict__ Tfd,
-                                              const float* __restrict__ Tcd, float* __restrict__ rowmean,
-                                              float* __restrict__ red, int p, int b, bool direct)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = prm.B, P = prm.P;
-    // row means of fd over the B-side points (fd.mean([3,4]), modules.py:332)
-    float fdsum_part = 0.f;
-    for (int r = wave; r < TP; r += NW) {
-        float s = 0.f;
-        if (r < P)
-            for (int c = lane; c < P; c += 64) s += Tfd[r * LDT + c];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (lane == 0) {
-            rowmean[r] = prm.pointwise ? s / (float)P : 0.f;
-            fdsum_part += s;
-        }
-    }
-    const float fd_sum = block_sum<NW>(fdsum_part, red);   // (barriers inside: rowmean visible after)
-
-    const int P2 = P * P;
-    float* cd_out;
-    float* loss_out = nullptr;
-    float shift;
-    if (direct) { cd_out = prm.neg_cd + (size_t)b * P2; loss_out = prm.neg_loss + (size_t)b * P2; shift = prm.shift[0]; }
-    else if (p == 0) { cd_out = prm.intra_cd + (size_t)b * P2; shift = prm.shift[0]; }
-    else if (p == 1) { cd_out = prm.inter_cd + (size_t)b * P2; shift = prm.shift[1]; }
-    else {
-        cd_out = prm.neg_cd + ((size_t)(p - 2) * B + b) * P2;
-        loss_out = prm.neg_loss + ((size_t)(p - 2) * B + b) * P2;
-        shift = prm.shift[2];
-    }
-    float* w_out = prm.saved_w ? prm.saved_w + ((size_t)p * B + b) * P2 : nullptr;
-    const float cmin = prm.cmin, cmax = prm.cmax;
-    float loss_part = 0.f, clamp_part = 0.f;
-    for (int r = wave; r < P; r += NW) {
-        const float rm = rowmean[r] + shift;
-        for (int c = lane; c < P; c += 64) {
-            const int idx = r * P + c;
-            const float w = Tfd[r * LDT + c] - rm;                     // fd_centred - shift
-            const float cdv = Tcd[r * LDT + c];
-            const float cl = fminf(fmaxf(cdv, cmin), cmax);
-            const float lp = -cl * w;                                  // loss without the old_mean term
-            if (!(prm.debug & 4)) {
-                cd_out[idx] = cdv;
-                if (loss_out) loss_out[idx] = lp;
-                if (w_out) w_out[idx] = w;
-            }
-            loss_part += lp;
-            clamp_part += cl;
-        }
-    }
-    const float loss_sum = block_sum<NW>(loss_part, red);
-    const float clamp_sum = block_sum<NW>(clamp_part, red);
-    if (tid == 0) {
-        float* st = prm.stats + ((size_t)p * B + b) * 4;
-        st[0] = fd_sum; st[1] = loss_sum; st[2] = clamp_sum; st[3] = 0.f;
-    }
-}
-
-// Which maps feed the B side of tile (p, b) (modules.py:369-386).  Selected by value: a pointer
-// into the kernarg struct would force the whole struct into scratch.
-struct TileSel {
-    MapV mfB, mcB;
-    const float* coordsB;
-    int imgB;
-    bool sameAB, direct;
-};
-
-__device__ __forceinline__ TileSel select_tile(const CorrParams& prm, int p, int b)
-{
-    TileSel s;
-    s.direct = prm.mode == 1;
-    const bool usePos = s.direct || p == 1;
-    s.sameAB = !s.direct && p == 0;
-    s.mfB.p = usePos ? prm.feats_pos.p : prm.feats.p;     s.mcB.p = usePos ? prm.code_pos.p : prm.code.p;
-    s.mfB.sn = usePos ? prm.feats_pos.sn : prm.feats.sn;  s.mcB.sn = usePos ? prm.code_pos.sn : prm.code.sn;
-    s.mfB.sc = usePos ? prm.feats_pos.sc : prm.feats.sc;  s.mcB.sc = usePos ? prm.code_pos.sc : prm.code.sc;
-    s.mfB.sh = usePos ? prm.feats_pos.sh : prm.feats.sh;  s.mcB.sh = usePos ? prm.code_pos.sh : prm.code.sh;
-    s.mfB.sw = usePos ? prm.feats_pos.sw : prm.feats.sw;  s.mcB.sw = usePos ? prm.code_pos.sw : prm.code.sw;
-    s.coordsB = (!s.direct && p >= 1) ? prm.coords2 : prm.coords1;
-    s.imgB = b;
-    if (!s.direct && p >= 2) s.imgB = (int)prm.perms[(size_t)(p - 2) * prm.B + b];
-    return s;
-}
-
-// tap tables for the 2 x 128 points of a tile; t in [0,256): t<128 -> A point t, else B point t-128
-__device__ __forceinline__ void build_taps(const CorrParams& prm, const TileSel& s, int b, int t, int4* tapf, int4* tapc,
-                                           float4* tapw)
-{
-    const int side = t >> 7, q = t & (TP - 1);
-    const float* cimg = s.direct ? nullptr
-                                 : (side == 0 ? prm.coords1 + (size_t)b * prm.P * 2 : s.coordsB + (size_t)b * prm.P * 2);
-    int4 yx; float4 w;
-    tap_for_point(q, prm.P, prm.S, prm.H, prm.W, s.direct, cimg, yx, w);
-    tapf[t] = taps_to_offsets(yx, side == 0 ? prm.feats.sh : s.mfB.sh, side == 0 ? prm.feats.sw : s.mfB.sw);
-    tapc[t] = taps_to_offsets(yx, side == 0 ? prm.code.sh : s.mcB.sh, side == 0 ? prm.code.sw : s.mcB.sw);
-    tapw[t] = w;
-}
-
-// =============================================================== simple kernel (4 waves, f32)
-template <int VF, int VC>
-__global__ void __launch_bounds__(NTHREADS) corr_fwd_kernel(const CorrParams prm)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* nrm = reinterpret_cast<float*>(smem + SM_NRM);
-    float* rowmean = reinterpret_cast<float*>(smem + SM_ROWMEAN);
-    float* red = reinterpret_cast<float*>(smem + SM_RED);
-    float* As = reinterpret_cast<float*>(smem + SM_BIG);
-    float* Bs = As + TP * LDA;
-    int4* tapf = reinterpret_cast<int4*>(Bs + TP * LDA);
-    int4* tapc = tapf + 256;
-    float4* tapw = reinterpret_cast<float4*>(tapc + 256);
-    float* Tfd = reinterpret_cast<float*>(smem + SM_BIG);  // epilogue alias
-    float* Tcd = Tfd + TP * LDT;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int B = prm.B;
-    const int tile = blockIdx.x;
-    const int b = tile % B, p = tile / B;      // all pair-sets of image b share blockIdx%8 (XCD L2) when B%8==0
-    const TileSel sel = select_tile(prm, p, b);
-    build_taps(prm, sel, b, tid, tapf, tapc, tapw);
-    __syncthreads();
-
-    const float* Bsrc = sel.sameAB ? As : Bs;
-    constexpr int BF = VF == 4 ? 4 : 8, BC = 4;
-
-    f32x16 accf[2][2];
-    zero_acc(accf);
-    {
-        float ssA[TP * (KC / VF) / NTHREADS], ssB[TP * (KC / VF) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VF) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
-        const float* imgA = prm.feats.p + (long long)b * prm.feats.sn;
-        const float* imgBp = sel.mfB.p + (long long)sel.imgB * sel.mfB.sn;
-        for (int c0 = 0; c0 < prm.C; c0 += KC) {
-            const int kc = min(KC, prm.C - c0);
-            const int kc8 = (kc + 7) & ~7;
-            if (!(prm.debug & 2)) {
-                gather_chunk<VF, LDA, PREC_F32, BF>(imgA, prm.feats.sc, tapf, tapw, c0, prm.C, kc8, As, ssA, tid);
-                if (!sel.sameAB)
-                    gather_chunk<VF, LDA, PREC_F32, BF>(imgBp, sel.mfB.sc, tapf + TP, tapw + TP, c0, prm.C, kc8, Bs, ssB, tid);
-            }
-            __syncthreads();
-            if (!(prm.debug & 1)) mma_chunk_f32(As, Bsrc, kc8, accf, lane, wr, wc);
-            __syncthreads();
-        }
-        publish_norms<VF>(ssA, nrm + 0 * TP, tid);
-        if (!sel.sameAB) publish_norms<VF>(ssB, nrm + 1 * TP, tid);
-    }
-
-    f32x16 accc[2][2];
-    zero_acc(accc);
-    {
-        float ssA[TP * (KC / VC) / NTHREADS], ssB[TP * (KC / VC) / NTHREADS];
-#pragma unroll
-        for (int i = 0; i < TP * (KC / VC) / NTHREADS; ++i) { ssA[i] = 0.f; ssB[i] = 0.f; }
-        const float* imgA = prm.code.p + (long long)b * prm.code.sn;
-        const float* imgBp = sel.mcB.p + (long long)sel.imgB * sel.mcB.sn;
-        for (int c0 = 0; c0 < prm.K; c0 += KC) {
-            const int kc = min(KC, prm.K - c0);
-            const int kc8 = (kc + 7) & ~7;
-            if (!(prm.debug & 2)) {
-                gather_chunk<VC, LDA, PREC_F32, BC>(imgA, prm.code.sc, tapc, tapw, c0, prm.K, kc8, As, ssA, tid);
-                if (!sel.sameAB)
-                    gather_chunk<VC, LDA, PREC_F32, BC>(imgBp, sel.mcB.sc, tapc + TP, tapw + TP, c0, prm.K, kc8, Bs, ssB, tid);
-            }
-            __syncthreads();
-            if (!(prm.debug & 1)) mma_chunk_f32(As, Bsrc, kc8, accc, lane, wr, wc);
-            __syncthreads();
-        }
-        publish_norms<VC>(ssA, nrm + 2 * TP, tid);
-        if (!sel.sameAB) publish_norms<VC>(ssB, nrm + 3 * TP, tid);
-    }
-    __syncthreads();   // norms visible; staging area is dead from here on
-
-    const float* nAf = nrm, *nBf = sel.sameAB ? nrm : nrm + TP;
-    const float* nAc = nrm + 2 * TP, *nBc = sel.sameAB ? nrm + 2 * TP : nrm + 3 * TP;
-    park_tile(accf, Tfd, nAf, nBf, lane, wr, wc);
-    park_tile(accc, Tcd, nAc, nBc, lane, wr, wc);
-    __syncthreads();
-    tile_epilogue<4>(prm, Tfd, Tcd, rowmean, red, p, b, sel.direct);
-}
-
-// ============================================================ dense tile kernel (production)
 // Linear async copy of npieces KiB from global to LDS, split over the 4 waves.  The LDS destination
 // of a global_load_lds is wave-uniform base + lane*16, i.e. each piece is one contiguous KiB.
 __device__ __forceinline__ void issue_copy(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int npieces,
@@ -365,36 +151,113 @@ __device__ __forceinline__ void issue_copy(const unsigned char* __restrict__ gsr
     }
 }
 
-__device__ __forceinline__ void park_plain(const f32x16 (&acc)[2][2], float* __restrict__ T, int lane, int wr, int wc)
+// ---- B-operand gather, software-pipelined through the MFMA stream of the previous chunk.
+// Thread mapping (256 threads): SLOTS = 64/V lanes cover one point's chunk (one contiguous 256-byte read per
+// tap per point when channels are contiguous), PPI points per pass, ITEMS passes ("items").
+// Per chunk and lane: ITEMS x 4 tap loads into registers during the first half of the MFMA k groups, blended
+// and written to the other LDS stage buffer during the second half (by then they have landed; the blend's VALU
+// work rides in the MFMA shadow).
+template <int V> struct GatherRegs {
+    typedef typename VecT<V>::type vec;
+    static constexpr int SLOTS = KC / V;
+    static constexpr int ITEMS = TP * SLOTS / NTHREADS;
+    static constexpr int PPI = NTHREADS / SLOTS;
+    vec tv[ITEMS][4];
+    // V == 4: byte offset of (point, tap, this lane's channel slot) inside a chunk of the image, kept in registers
+    // (SGPR base + 32-bit lane offset loads, no address arithmetic in the MFMA stream).  The generic V == 1 path
+    // has 4x the items and re-reads the tap table from LDS instead.
+    unsigned off[V == 4 ? ITEMS : 1][4];
+};
+
+// items [j0, j0 + n): loads.  `chunk` = image + c0 * channel_stride (wave-uniform): SGPR base + 32-bit lane offset.
+template <int V>
+__device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const float* __restrict__ chunk, const int4* __restrict__ tapo,
+                                             int lane_off, int prow, int j0, int n)
 {
+    typedef typename VecT<V>::type vec;
+    const char* cb = reinterpret_cast<const char*>(chunk);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = 64 * wc + 32 * ni + (lane & 31);
+    for (int i = 0; i < n; ++i) {
+        const int j = j0 + i;
+        if constexpr (V == 4) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int k = 0; k < 4; ++k) g.tv[j][k] = *reinterpret_cast<const vec*>(cb + g.off[j][k]);
+        } else {
+            const int4 o = tapo[j * GatherRegs<V>::PPI + prow];
+            const float* b = chunk + lane_off;
+            g.tv[j][0] = b[o.x]; g.tv[j][1] = b[o.y]; g.tv[j][2] = b[o.z]; g.tv[j][3] = b[o.w];
+        }
+    }
+}
+
+// items [j0, j0 + n): blend the 4 taps, accumulate the points' sums of squares, write the LDS operand image
+//   PREC_F32   : float [128][LDA]            PREC_BF16X3: bf16 hi[128][LDH] then lo[128][LDH]
+template <int V, int PREC>
+__device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const float4* __restrict__ tapw, bool chok,
+                                              void* __restrict__ dst_, float (&ss)[GatherRegs<V>::ITEMS], int slot, int prow,
+                                              int j0, int n)
+{
+    constexpr int PPI = GatherRegs<V>::PPI;
+    const int col = slot * V;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                T[row * LDT + col] = acc[mi][ni][r];
+    for (int i = 0; i < n; ++i) {
+        const int j = j0 + i;
+        const int q = j * PPI + prow;
+        const float4 w = tapw[q];
+        float v[V];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t0, t1, t2, t3;
+            if constexpr (V == 1) { t0 = g.tv[j][0]; t1 = g.tv[j][1]; t2 = g.tv[j][2]; t3 = g.tv[j][3]; }
+            else { t0 = g.tv[j][0][e]; t1 = g.tv[j][1][e]; t2 = g.tv[j][2][e]; t3 = g.tv[j][3][e]; }
+            float r = w.x * t0 + w.y * t1 + w.z * t2 + w.w * t3;
+            r = chok ? r : 0.f;                       // channels beyond C (generic path): zero padding
+            v[e] = r;
+            s += r * r;
+        }
+        ss[j] += s;
+        if constexpr (PREC == PREC_F32) {
+            float* d = static_cast<float*>(dst_) + q * LDA + col;
+            if constexpr (V == 4) *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+            else d[0] = v[0];
+        } else {
+            __bf16* dh = static_cast<__bf16*>(dst_) + q * LDH + col;
+            __bf16* dl = dh + TP * LDH;
+            if constexpr (V == 4) {
+                unsigned h0, l0, h1, l1;
+                split_bf16_pair(v[0], v[1], h0, l0);
+                split_bf16_pair(v[2], v[3], h1, l1);
+                *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(dl) = u32x2{l0, l1};
+            } else {
+                unsigned h0, l0;
+                split_bf16_pair(v[0], 0.f, h0, l0);
+                *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h0 & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dl) = (unsigned short)(l0 & 0xffffu);
             }
+        }
     }
 }
 
 // Result tiles are parked in LDS in the FLAT layout of the outputs, T[a + row * P + col], so that the epilogue
 // is a linear sweep: 16-byte LDS reads, 16-byte global stores.  `a` = the output tile's start address / 4 mod 4
 // (tiles are P*P floats apart and P*P is odd, so they are only 4-byte aligned): with the same shift in LDS
-// both sides of the copy are 16-byte aligned at the same time.
-__device__ __forceinline__ void park_flat(const f32x16 (&acc)[2][2], float* __restrict__ T, int P, int lane, int wr, int wc)
+// both sides of the copy are 16-byte aligned at the same time.  colscale (or null) = 1/||b_j|| of a raw B side.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+__device__ __forceinline__ void park_flat(const f32x16 (&acc)[2][2], float* __restrict__ T, int P, const float* colscale,
+                                          int lane, int wr, int wc)
 {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = 64 * wc + 32 * ni + (lane & 31);
+        const float sc = colscale ? colscale[col] : 1.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < P && col < P) T[row * P + col] = acc[mi][ni][r];
+                if (row < P && col < P) T[row * P + col] = acc[mi][ni][r] * sc;
             }
     }
 }
@@ -486,12 +349,25 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
     }
 }
 
-template <int PREC>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2])
+{
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+}
+
+template <int PREC, int V>
 __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams prm, const int stage_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* rowmean = reinterpret_cast<float*>(smem + SD_ROWMEAN);
     float* red = reinterpret_cast<float*>(smem + SD_RED);
+    float* csc = reinterpret_cast<float*>(smem + SD_CSC);
+    int4* tapo = reinterpret_cast<int4*>(smem + SD_TAPO);
+    float4* tapw = reinterpret_cast<float4*>(smem + SD_TAPW);
     unsigned char* stage = smem + SD_BIG;
     float* Tfd = reinterpret_cast<float*>(smem + SD_BIG);   // epilogue alias of the stage buffers
     float* Tcd = Tfd + TP * LDT;
@@ -510,47 +386,118 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
     const int NCH = prm.NCH;
     const int cside = TP * prm.LDK * 4;          // bytes of one code operand (a multiple of 1 KiB)
     const unsigned char* fsA = static_cast<const unsigned char*>(prm.fs) + (size_t)sA * NCH * FSIDE;
-    const unsigned char* fsB = static_cast<const unsigned char*>(prm.fs) + (size_t)sB * NCH * FSIDE;
     const unsigned char* csA = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sA * cside;
     const unsigned char* csB = reinterpret_cast<const unsigned char*>(prm.cs) + (size_t)sB * cside;
 
-    auto issue = [&](int t) {
+    // ---- B side source image (modules.py:369-386) and its tap table (written by the sampler)
+    const bool usePos = direct || p == 1;
+    const float* imgB;
+    int scB;
+    {
+        int src = b;
+        if (!direct && p >= 2) src = (int)prm.perms[(size_t)(p - 2) * B + b];
+        const float* bp = usePos ? prm.feats_pos.p : prm.feats.p;
+        const long long sn = usePos ? prm.feats_pos.sn : prm.feats.sn;
+        const int sh = usePos ? prm.feats_pos.sh : prm.feats.sh, sw = usePos ? prm.feats_pos.sw : prm.feats.sw;
+        scB = usePos ? prm.feats_pos.sc : prm.feats.sc;
+        imgB = bp + (long long)src * sn;
+        if (tid < TP) {
+            tapo[tid] = taps_to_offsets(prm.tapyx[(size_t)sB * TP + tid], sh, sw);
+            tapw[tid] = prm.tapw[(size_t)sB * TP + tid];      // padding points: weights 0 -> zero rows
+        }
+    }
+    // debug bit 256: phase stamps of every workgroup on the 100 MHz global clock (tools/stamps.py)
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.stats + (size_t)prm.n_sets * B * 4 + 256) + (size_t)blockIdx.x * 8;
+    const bool stamp_on = (prm.debug & 256) && tid == 0;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();                              // tap table visible
+
+    GatherRegs<V> greg;
+    constexpr int ITEMS = GatherRegs<V>::ITEMS, HALF = (KC / 8) / 2, IPS = ITEMS / HALF;      // items per k-group slice
+    static_assert(ITEMS % HALF == 0, "items must split over half of the k groups");
+    float ss[ITEMS];
+    const int gslot = tid % GatherRegs<V>::SLOTS, gprow = tid / GatherRegs<V>::SLOTS;
+    const int lane_off = gslot * V * scB;                             // this lane's channel slot inside a chunk
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        ss[j] = 0.f;
+        if constexpr (V == 4) {
+            const int4 o = tapo[j * GatherRegs<V>::PPI + gprow];
+            greg.off[j][0] = (unsigned)(o.x + lane_off) * 4u;
+            greg.off[j][1] = (unsigned)(o.y + lane_off) * 4u;
+            greg.off[j][2] = (unsigned)(o.z + lane_off) * 4u;
+            greg.off[j][3] = (unsigned)(o.w + lane_off) * 4u;
+        }
+    }
+    const bool gatherB = !sameAB;
+    // Channels beyond C exist only in the generic path (V == 1, the host takes V == 4 only when C % 64 == 0): such a
+    // lane re-reads the last channel and its values are zeroed at commit.
+    // (the prefetch one chunk past the end re-reads the last chunk)
+    auto chunk_ptr = [&](int t) { return V == 4 ? imgB + (long long)min(t * KC, prm.C - KC) * scB : imgB; };
+    auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(t * KC + gslot, prm.C - 1) * scB; };
+    auto chunk_ok = [&](int t) { return V == 4 || t * KC + gslot < prm.C; };
+
+    // all async copies of stage t (A features / both code operands), issued in one go: a ds_read that follows a
+    // global_load_lds makes the compiler wait for vmcnt(0) (it cannot prove the LDS addresses differ), so they
+    // must not sit between MFMA groups
+    auto copies = [&](int t) {
         unsigned char* dst = stage + (t & 1) * stage_bytes;
         if (t < NCH) {
             issue_copy(fsA + (size_t)t * FSIDE, dst, FSIDE / 1024, wave, lane);
-            if (!sameAB) issue_copy(fsB + (size_t)t * FSIDE, dst + FSIDE, FSIDE / 1024, wave, lane);
         } else {
             issue_copy(csA, dst, cside / 1024, wave, lane);
             if (!sameAB) issue_copy(csB, dst + cside, cside / 1024, wave, lane);
         }
     };
 
-    // debug bit 256: phase stamps of every workgroup on the 100 MHz global clock (tools/stamps.py)
-    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.stats + (size_t)prm.n_sets * B * 4 + 256) + (size_t)blockIdx.x * 8;
-    const bool stamp_on = (prm.debug & 256) && tid == 0;
-    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
     f32x16 accf[2][2], accc[2][2];
     zero_acc(accf);
     zero_acc(accc);
     const int T = NCH + 1;                       // feature chunks, then the whole code operand pair
-    if (!(prm.debug & 2)) issue(0);
+    copies(0);
+    if (gatherB) {
+        gather_issue<V>(greg, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
+        gather_commit<V, PREC>(greg, tapw, chunk_ok(0), stage + FSIDE, ss, gslot, gprow, 0, ITEMS);
+    }
     for (int t = 0; t < T; ++t) {
-        __syncthreads();                         // (waits vmcnt(0)) chunk t has landed; everyone is done with chunk t-1
-        if (t + 1 < T && !(prm.debug & 2)) issue(t + 1);
-        if (prm.debug & 1) continue;
+        __syncthreads();                         // (waits vmcnt(0)) stage t has landed; everyone is done with stage t-1
+        if (t + 1 < T) copies(t + 1);
         const unsigned char* Ab = stage + (t & 1) * stage_bytes;
         if (t < NCH) {
+            // The taps of chunk t+1 are loaded UNCONDITIONALLY (branch-free MFMA stream): tiles without a gathered
+            // side and the last chunk re-read valid addresses; only the commit is conditional.
+            const float* nxt = chunk_ptr(t + 1);
+            const int nxt_off = lane_ofs(t + 1);
+            const bool commit = t + 1 < NCH && gatherB;
+            const bool ok = chunk_ok(t + 1);
+            void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
+            auto pre = [&](int st) {
+                if (st < HALF) gather_issue<V>(greg, nxt, tapo, nxt_off, gprow, st * IPS, IPS);
+                else if (commit) gather_commit<V, PREC>(greg, tapw, ok, dstB, ss, gslot, gprow, (st - HALF) * IPS, IPS);
+            };
             const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
-            const int kc = min(KC, prm.C - t * KC);
             if constexpr (PREC == PREC_F32)
-                mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), (kc + 7) & ~7, accf, lane, wr, wc);
+                mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc, pre);
             else
-                mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), (kc + 15) & ~15, accf, lane, wr, wc);
+                mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), accf, lane, wr, wc, pre);
         } else {
             const unsigned char* Bb = sameAB ? Ab : Ab + cside;
             mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
         }
     }
+    // ---- 1 / ||b_j|| of the gathered side (F.normalize eps, modules.py:276); the anchor side is pre-normalised
+    {
+        constexpr int SLOTS = GatherRegs<V>::SLOTS, PPI = GatherRegs<V>::PPI;
+        const int slot = gslot, prow = gprow;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            float s = ss[j];
+#pragma unroll
+            for (int m = SLOTS / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            if (slot == 0) csc[j * PPI + prow] = sameAB ? 1.f : 1.f / fmaxf(sqrtf(s), 1e-10f);
+        }
+    }
+
     // ---- where this tile's outputs go
     const int P = prm.P, P2 = P * P;
     float* cd_out;
@@ -568,10 +515,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
     const int a = (int)((reinterpret_cast<uintptr_t>(cd_out) >> 2) & 3);
     const bool vec_ok = (!loss_out || (int)((reinterpret_cast<uintptr_t>(loss_out) >> 2) & 3) == a) &&
                         (!w_out || (int)((reinterpret_cast<uintptr_t>(w_out) >> 2) & 3) == a);
-    __syncthreads();                             // stage buffers are dead: park the result tiles over them
+    __syncthreads();                             // stage buffers are dead, csc complete: park the result tiles
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
-    park_flat(accf, Tfd + a, P, lane, wr, wc);
-    park_flat(accc, Tcd + a, P, lane, wr, wc);
+    park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
+    park_flat(accc, Tcd + a, P, nullptr, lane, wr, wc);
     __syncthreads();
     if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
     tile_epilogue_flat(prm, Tfd, Tcd, rowmean, red, p, b, direct, a, cd_out, loss_out, w_out, shift, vec_ok);
@@ -650,37 +597,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
 }
 
 // ------------------------------------------------------------------------------ launch
-static int pick_vec(const MapV& a, const MapV& b, int channels, bool allow2)
-{
-    auto ok = [&](const MapV& m, int v) {
-        return m.sc == 1 && channels % v == 0 && (m.sn % v) == 0 && (m.sh % v) == 0 && (m.sw % v) == 0 &&
-               (reinterpret_cast<uintptr_t>(m.p) % (4 * v)) == 0;
-    };
-    if (ok(a, 4) && ok(b, 4)) return 4;
-    if (allow2 && ok(a, 2) && ok(b, 2)) return 2;
-    return 1;
-}
-
-template <typename K>
-static hipError_t launch_one(K kernel, int lds, bool& attr_done, const CorrParams& prm, int threads, hipStream_t stream)
-{
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kernel, dim3(prm.n_sets * prm.B), dim3(threads), lds, stream, prm);
-    return hipGetLastError();
-}
-
-#define STEGO_LAUNCH(KERNEL, LDS, THREADS)                                         \
-    do {                                                                           \
-        static bool done = false;                                                  \
-        return launch_one(KERNEL, LDS, done, prm, THREADS, stream);                \
-    } while (0)
-
-// bytes of one stage buffer of the dense kernel: max(feature chunk pair, code operand pair)
+// bytes of one stage buffer: max(feature chunk pair, code operand pair)
 int dense_stage_bytes(int precision, int LDK)
 {
     const int f = 2 * (precision == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_BF16);
@@ -698,29 +615,32 @@ hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t st
 {
     const int stage = dense_stage_bytes(precision, prm.LDK);
     const int lds = dense_lds_bytes(precision, prm.LDK);
-    static int attr_f32 = 0, attr_bf16 = 0;
-    int& have = precision == PREC_F32 ? attr_f32 : attr_bf16;
-    const void* fn = precision == PREC_F32 ? reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32>)
-                                           : reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3>);
-    if (have < lds) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // 16-byte gathers need channels-last maps with 16-byte aligned pixels; anything else takes the scalar path
+    auto ok4 = [&](const MapV& m) {
+        return m.sc == 1 && prm.C % KC == 0 && (m.sn % 4) == 0 && (m.sh % 4) == 0 && (m.sw % 4) == 0 &&
+               (reinterpret_cast<uintptr_t>(m.p) % 16) == 0 &&
+               ((long long)(prm.H - 1) * m.sh + (long long)(prm.W - 1) * m.sw + prm.C) * 4 < (1ll << 32);
+    };
+    const bool v4 = ok4(prm.feats) && ok4(prm.feats_pos);
+    const int which = (precision == PREC_F32 ? 0 : 2) + (v4 ? 0 : 1);
+    static int have[4] = {0, 0, 0, 0};
+    const void* fns[4] = {reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32, 4>),
+                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32, 1>),
+                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3, 4>),
+                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3, 1>)};
+    if (have[which] < lds) {
+        hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        have = lds;
+        have[which] = lds;
     }
     const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
-    if (precision == PREC_F32) hipLaunchKernelGGL((corr_tile_kernel<PREC_F32>), grid, block, lds, stream, prm, stage);
-    else hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3>), grid, block, lds, stream, prm, stage);
+    switch (which) {
+        case 0: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 4>), grid, block, lds, stream, prm, stage); break;
+        case 1: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 1>), grid, block, lds, stream, prm, stage); break;
+        case 2: hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3, 4>), grid, block, lds, stream, prm, stage); break;
+        default: hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3, 1>), grid, block, lds, stream, prm, stage); break;
+    }
     return hipGetLastError();
-}
-
-// the fused-gather cross-check kernel (f32 only)
-hipError_t launch_corr_fwd_simple(const CorrParams& prm, hipStream_t stream)
-{
-    const int vf = pick_vec(prm.feats, prm.feats_pos, prm.C, false);
-    const int vc = pick_vec(prm.code, prm.code_pos, prm.K, true);
-    if (vf == 4 && vc == 4) STEGO_LAUNCH((corr_fwd_kernel<4, 4>), SM_FWD_TOTAL, NTHREADS);
-    if (vf == 4 && vc == 2) STEGO_LAUNCH((corr_fwd_kernel<4, 2>), SM_FWD_TOTAL, NTHREADS);
-    STEGO_LAUNCH((corr_fwd_kernel<1, 1>), SM_FWD_TOTAL, NTHREADS);
 }
 
 // finalize: block 0 writes scalars; the rest fix the loss tensors of the sets that output one

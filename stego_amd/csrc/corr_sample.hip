@@ -76,31 +76,18 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
     const int hl = lane & 31, hw = lane >> 5;
     const int B = prm.B, P = prm.P;
     const int nsets = prm.n_roles * B;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const bool direct = prm.mode == 1;
-
-    // Work assignment without any division: walk (role, b) with counters; the units of this block's
-    // XCD class are numbered in walk order and block `slot` takes numbers slot, slot+nslots, ...
-    int ordinal = 0, next_mine = slot;
-    (void)nsets;
-    for (int role = 0; role < prm.n_roles; ++role) {
-        for (int b0 = 0; b0 < B; b0 += 64) {
-            bool match = false;
+    // Work assignment: block -> (unit qt of 16 points, set s), qt-major.  Consecutive blocks are consecutive sets,
+    // so (observed dispatch order) block % 8 = s % 8 = b % 8 when B % 8 == 0: the 8 units of an anchor set - the
+    // only role whose FEATURES are sampled here - run on one XCD and its image is fetched from HBM once.
+    {
+        {
             {
-                const int bb = b0 + lane;
-                if (bb < B) {
-                    const int src = (!direct && role >= 2) ? (int)prm.perms[(size_t)(role - 2) * B + bb] : bb;
-                    match = (src & 7) == xcd;
-                }
-            }
-            unsigned long long mask = __ballot(match);
-            while (mask) {
-                const int b = b0 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                if (next_mine >= ordinal + 8) { ordinal += 8; continue; }      // none of this set's 8 units is mine
-                for (int qt = 0; qt < 8; ++qt, ++ordinal) {
-                    if (ordinal != next_mine) continue;
-                    next_mine += nslots;
+                {
+                    const int qt = blockIdx.x / nsets;
+                    const int s0 = blockIdx.x - qt * nsets;
+                    const int role = s0 / B;
+                    const int b = s0 - role * B;
                     // ---------------- one unit: set s = role*B + b, points [16*qt, 16*qt+16)
                     const int s = role * B + b;
                     const int src = (!direct && role >= 2) ? (int)prm.perms[(size_t)(role - 2) * B + b] : b;
@@ -140,9 +127,10 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
                         prm.tapyx[(size_t)s * TP + q] = yx;
                         prm.tapw[(size_t)s * TP + q] = w;
                     }
-                    // ---- features
+                    // ---- features (anchor role only: every other set is gathered by the one tile that uses it)
                     const int4 of = taps_to_offsets(yx, mf.sh, mf.sw);
-                    if constexpr (NJ > 0) {
+                    if (role >= prm.feat_roles) {
+                    } else if constexpr (NJ > 0) {
                         f32x4 v[NJ];
                         f32x4 t[NJ][4];
                         const char* fb = reinterpret_cast<const char*>(fimg);     // uniform base + 32-bit lane offset
@@ -259,10 +247,10 @@ __global__ void __launch_bounds__(NTHREADS) sample_norm_kernel(const SampleParam
                         }
                     }
                     }      // it
-                    }      // qt
-                }          // sets of this ballot
-            }              // b0
-        }                  // role
+                }
+            }
+        }
+    }
 }
 
 hipError_t launch_corr_sample(const SampleParams& prm_in, int precision, hipStream_t stream)
@@ -277,11 +265,7 @@ hipError_t launch_corr_sample(const SampleParams& prm_in, int precision, hipStre
     const bool ccl = prm.K % 2 == 0 && cl(prm.code, 2) && cl(prm.code_pos, 2);
     prm.div_by = prm.mode == 1 ? prm.W : prm.S;
     prm.div_magic = 65536 / prm.div_by + 1;             // (q * magic) >> 16 == q / div_by for q < 128
-    const int units = prm.n_roles * prm.B * 8;
-    int nslots = (units + 7) / 8;
-    if (nslots > 512) nslots = 512;
-    if (nslots < 1) nslots = 1;
-    const dim3 grid(8 * nslots), block(NTHREADS);
+    const dim3 grid(prm.n_roles * prm.B * 8), block(NTHREADS);      // 8 units of 16 points per set
 #define STEGO_SAMPLE_LAUNCH(N, PR, CC) hipLaunchKernelGGL((sample_norm_kernel<N, PR, CC>), grid, block, 0, stream, prm)
 #define STEGO_SAMPLE_CASE(N)                                                                        \
     case N:                                                                                         \

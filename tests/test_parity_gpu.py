@@ -119,18 +119,6 @@ def _full_size_oracle_grads(inputs, perms, cfg):
     return _ORACLE_CACHE["bwd"]
 
 
-@pytest.mark.parametrize("name", ["small_default", "cfg1_B4_vits8_dinolike"])
-def test_simple_kernel_variant_agrees(name, monkeypatch):
-    """STEGO_FWD_VARIANT=0 selects the un-pipelined 4-wave kernel: same results as the default one."""
-    c = GoldenCase(name)
-    a = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False)["out"]
-    monkeypatch.setenv("STEGO_FWD_VARIANT", "0")
-    b = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False)["out"]
-    for x, y in zip(a, b):
-        np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-6)
-    assert_close(c.sub(b[4]), c.g["neg_inter_loss"], atol_frac=5e-4, what="neg_inter_loss (simple kernel)")
-
-
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_full_size_cfg2_against_fp64_oracle(precision):
     """BASELINE config 2 (B=32, ViT-S/8 224^2: C=384, 28x28, K=70, S=11, 5 negatives), channels-last."""
