@@ -161,7 +161,7 @@ def test_library_validates_before_enqueueing():
     d = capi.make_desc(4, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46))
     ws = lib.stego_corr_workspace_bytes(ctypes.byref(d))
     ctx = lib.stego_corr_saved_ctx_bytes(ctypes.byref(d))
-    assert ws >= 28 * 6 * 128 * 68 * 4 + ctx and ctx >= 28 * 128 * (76 + 1 + 8) * 4     # operand images + saved context
+    assert ws >= 4 * 6 * 128 * 68 * 4 + ctx and ctx >= 28 * 128 * (76 + 1 + 8) * 4     # anchor operand images + saved context
     args_null = [None] * 4 + [None] * 3 + [None] * 8 + [None, 0, None]
     assert lib.stego_corr_fwd(None, *args_null) == 1                      # STEGO_ERR_NULL
     assert lib.stego_corr_fwd(ctypes.byref(d), *args_null) == 1
