@@ -450,40 +450,42 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
         }
     };
 
-    f32x16 accf[2][2], accc[2][2];
+    f32x16 accf[2][2];
     zero_acc(accf);
-    zero_acc(accc);
-    const int T = NCH + 1;                       // feature chunks, then the whole code operand pair
     copies(0);
     if (gatherB) {
         gather_issue<V>(greg, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
         gather_commit<V, PREC>(greg, tapw, chunk_ok(0), stage + FSIDE, ss, gslot, gprow, 0, ITEMS);
     }
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < NCH; ++t) {              // feature chunks
         __syncthreads();                         // (waits vmcnt(0)) stage t has landed; everyone is done with stage t-1
-        if (t + 1 < T) copies(t + 1);
+        copies(t + 1);                           // stage NCH = the code operands
         const unsigned char* Ab = stage + (t & 1) * stage_bytes;
-        if (t < NCH) {
-            // The taps of chunk t+1 are loaded UNCONDITIONALLY (branch-free MFMA stream): tiles without a gathered
-            // side and the last chunk re-read valid addresses; only the commit is conditional.
-            const float* nxt = chunk_ptr(t + 1);
-            const int nxt_off = lane_ofs(t + 1);
-            const bool commit = t + 1 < NCH && gatherB;
-            const bool ok = chunk_ok(t + 1);
-            void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
-            auto pre = [&](int st) {
-                if (st < HALF) gather_issue<V>(greg, nxt, tapo, nxt_off, gprow, st * IPS, IPS);
-                else if (commit) gather_commit<V, PREC>(greg, tapw, ok, dstB, ss, gslot, gprow, (st - HALF) * IPS, IPS);
-            };
-            const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
-            if constexpr (PREC == PREC_F32)
-                mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc, pre);
-            else
-                mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), accf, lane, wr, wc, pre);
-        } else {
-            const unsigned char* Bb = sameAB ? Ab : Ab + cside;
-            mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
-        }
+        // The taps of chunk t+1 are loaded UNCONDITIONALLY (branch-free MFMA stream): tiles without a gathered
+        // side and the last chunk re-read valid addresses; only the commit is conditional.
+        const float* nxt = chunk_ptr(t + 1);
+        const int nxt_off = lane_ofs(t + 1);
+        const bool commit = t + 1 < NCH && gatherB;
+        const bool ok = chunk_ok(t + 1);
+        void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
+        auto pre = [&](int st) {
+            if (st < HALF) gather_issue<V>(greg, nxt, tapo, nxt_off, gprow, st * IPS, IPS);
+            else if (commit) gather_commit<V, PREC>(greg, tapw, ok, dstB, ss, gslot, gprow, (st - HALF) * IPS, IPS);
+        };
+        const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
+        if constexpr (PREC == PREC_F32)
+            mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc, pre);
+        else
+            mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), accf, lane, wr, wc, pre);
+    }
+    // ---- the code correlation: one stage, exact f32 (its accumulators only live from here on)
+    f32x16 accc[2][2];
+    zero_acc(accc);
+    __syncthreads();
+    {
+        const unsigned char* Ab = stage + (NCH & 1) * stage_bytes;
+        const unsigned char* Bb = sameAB ? Ab : Ab + cside;
+        mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
     }
     // ---- 1 / ||b_j|| of the gathered side (F.normalize eps, modules.py:276); the anchor side is pre-normalised
     {
