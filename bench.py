@@ -289,8 +289,10 @@ def main():
         # dominant kernel = the larger of the two forward stages; both are reported
         kernels = {"sample_norm_kernel": ms_samp * 1e3, "corr_tile_kernel": ms_main * 1e3,
                    "corr_finalize_kernel": ms_fin * 1e3}
-        # algorithmic bytes per stage: the sampler owns the input reads, the tile kernel the output writes
-        ab_in = 4 * (2 * B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B
+        # algorithmic bytes per stage (each distinct tensor once): the sampler reads feats (anchors), both code maps,
+        # coords and perms; the tile kernel reads feats_pos (and re-reads feats for the negatives: counted once, above)
+        # and writes every output
+        ab_in = 4 * (B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B
         ab_out = ab - ab_in
         dom = "sample_norm_kernel" if ms_samp >= ms_main else "corr_tile_kernel"
         t_fwd = (ms_samp + ms_main + ms_fin) * 1e-3
