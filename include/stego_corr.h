@@ -190,6 +190,23 @@ int stego_corr_helper_bwd(const StegoCorrDesc* desc,
                           float* d_c1, float* d_c2,
                           void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
+/*
+ * All-pairs cosine top-k of precompute_knns.py:86-96 (`topk(einsum("nf,mf->nm", blk, X), 30)[1]`, all row blocks at
+ * once) without materialising the [N,N] similarity matrix.
+ *   X        : [N, D] fp32, row stride ldx elements (device)
+ *   normalize: != 0 -> rows are L2-normalised first (F.normalize, eps 1e-12: precompute_knns.py:19)
+ *   q_begin, q_count : the query rows to answer, q_begin a multiple of 128 (row-sharding across GPUs: every rank
+ *                      holds the whole X and answers its own slice)
+ *   out_idx  : OUT int64 [q_count, k], neighbours by descending similarity (rank 0 = the row itself unless a
+ *              duplicate row ties with it; torch.topk leaves tie order unspecified, so does this)
+ *   out_sims : OUT fp32 [q_count, k] or NULL
+ * Limits: 1 <= k <= 32, k <= N < 2^31.  Contraction arithmetic: split-bf16 (3 MFMAs, fp32 accumulate), ~1e-6 abs.
+ */
+size_t stego_knn_workspace_bytes(int64_t N, int32_t D, int32_t k, int64_t q_count);
+int stego_knn_topk(const float* X, int64_t N, int32_t D, int64_t ldx, int32_t k, int32_t normalize,
+                   int64_t q_begin, int64_t q_count, int64_t* out_idx, float* out_sims,
+                   void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ import sys
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
@@ -165,12 +166,34 @@ def primitives_case(M):
     print("wrote primitives")
 
 
+def knn_case():
+    """precompute_knns.py:86-96 verbatim ops (16 row blocks, einsum + topk 30) on a small normalised matrix; one
+    duplicated row gives an exact tie at rank 0/1."""
+    g = torch.Generator().manual_seed(21)
+    n, d, k, n_batches = 600, 48, 30, 16
+    feats = torch.randn(n, d, generator=g)
+    feats[17] = feats[3]                                           # exact duplicate
+    normed_feats = F.normalize(feats, dim=1)                       # :19
+    all_nns, all_vals = [], []
+    step = normed_feats.shape[0] // n_batches                      # :87
+    for i in range(0, normed_feats.shape[0], step):                # :89
+        batch_feats = normed_feats[i:i + step, :]
+        pairwise_sims = torch.einsum("nf,mf->nm", batch_feats, normed_feats)
+        v, ix = torch.topk(pairwise_sims, k)
+        all_nns.append(ix)
+        all_vals.append(v)
+    np.savez_compressed(os.path.join(OUT, "knn_small.npz"), feats=feats.numpy(), normed=normed_feats.numpy(),
+                        nns=torch.cat(all_nns, dim=0).numpy(), sims=torch.cat(all_vals, dim=0).numpy(), k=k)
+    print("knn_small", n, d, k)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = ref_shim.load_reference_modules()
     primitives_case(M)
     seeded_e2e_case(M)
+    knn_case()
     # small full-tensor cases (inputs stored); H != W catches x/y swaps, odd K/C catch padding bugs
     run_case(M, "small_default", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=1)
     run_case(M, "small_nopointwise", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=2, cfg_kw=dict(pointwise=False))

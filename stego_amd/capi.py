@@ -39,6 +39,9 @@ SIGNATURES = {
     "stego_corr_saved_ctx_bytes": (c_size_t, [_D]),
     "stego_corr_helper_workspace_bytes": (c_size_t, [_D]),
     "stego_corr_helper_saved_ctx_bytes": (c_size_t, [_D]),
+    "stego_knn_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32, c_int32, ctypes.c_int64]),
+    "stego_knn_topk": (c_int32, [_P, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64,
+                                 _P, _P, _P, c_size_t, _P]),
     "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
                                + [c_int32, POINTER(c_float)]),
@@ -249,3 +252,27 @@ def helper_bwd(desc, c1, c2, saved, cd, g_loss, g_cd):
                                          _ptr(saved_ctx), _ptr(cd), _ptr(g_loss), _ptr(g_cd), _ptr(d1), _ptr(d2),
                                          _ptr(ws), ws.numel(), _stream()))
     return d1.permute(0, 3, 1, 2), d2.permute(0, 3, 1, 2)
+
+
+def knn_topk(x, k=30, normalize=False, q_begin=0, q_count=None, return_sims=False):
+    """All-pairs cosine top-k (reference precompute_knns.py:86-96) of the rows of ``x`` [N, D] (fp32, HIP device).
+    Returns int64 [q_count, k] (and the fp32 similarities)."""
+    _require_dev(x)
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise ValueError("knn_topk expects a 2-D float32 tensor")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    lib = load()
+    N, D = x.shape
+    q_count = N - q_begin if q_count is None else q_count
+    nws = lib.stego_knn_workspace_bytes(N, D, k, q_count)
+    if nws == 0:
+        raise RuntimeError("stego_knn_topk: unsupported shape (need 1 <= k <= 32, k <= N < 2^31)")
+    dev = x.device
+    ws = _empty_bytes(nws, dev)
+    idx = torch.empty(q_count, k, dtype=torch.int64, device=dev)
+    sims = torch.empty(q_count, k, dtype=torch.float32, device=dev) if return_sims else None
+    with torch.cuda.device(dev):
+        _check(lib.stego_knn_topk(_ptr(x), N, D, x.stride(0), k, 1 if normalize else 0, q_begin, q_count, _ptr(idx), _ptr(sims),
+                                  _ptr(ws), ws.numel(), _stream()))
+    return (idx, sims) if return_sims else idx

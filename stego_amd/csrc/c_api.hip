@@ -10,6 +10,9 @@ namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
+size_t knn_workspace_bytes(long long N, int D, int k, long long q_count);
+hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, int normalize, long long q_begin,
+                      long long q_count, long long* out_idx, float* out_val, void* ws, hipStream_t stream);
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream);
 }  // namespace stego
 
@@ -360,6 +363,37 @@ int stego_corr_helper_bwd(const StegoCorrDesc* d, const float* saved_w, const fl
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
     return hip_rc(launch_corr_bwd(prm, static_cast<hipStream_t>(stream)));
+}
+
+static int knn_check(int64_t N, int32_t D, int32_t k, int64_t q_begin, int64_t q_count)
+{
+    if (N <= 0 || D <= 0 || q_count <= 0 || q_begin < 0) return STEGO_ERR_SHAPE;
+    if (k < 1 || k > 32 || k > N || N >= ((int64_t)1 << 31)) return STEGO_ERR_UNSUPPORTED;
+    if (q_begin % 128 != 0 || q_begin + q_count > N) return STEGO_ERR_SHAPE;
+    return STEGO_OK;
+}
+
+size_t stego_knn_workspace_bytes(int64_t N, int32_t D, int32_t k, int64_t q_count)
+{
+    if (knn_check(N, D, k, 0, q_count) != STEGO_OK) return 0;
+    return knn_workspace_bytes(N, D, k, q_count);
+}
+
+int stego_knn_topk(const float* X, int64_t N, int32_t D, int64_t ldx, int32_t k, int32_t normalize,
+                   int64_t q_begin, int64_t q_count, int64_t* out_idx, float* out_sims,
+                   void* workspace, size_t workspace_bytes, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    int rc = knn_check(N, D, k, q_begin, q_count);
+    if (rc) return rc;
+    if (!X || !out_idx || !workspace) return STEGO_ERR_NULL;
+    if (ldx < D) return STEGO_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(X) & 3) || (reinterpret_cast<uintptr_t>(out_idx) & 7)) return STEGO_ERR_ALIGN;
+    if (workspace_bytes < knn_workspace_bytes(N, D, k, q_count)) return STEGO_ERR_WORKSPACE;
+    unsigned char* w = static_cast<unsigned char*>(workspace);
+    w += (256 - (reinterpret_cast<uintptr_t>(w) & 255)) & 255;                 // (the size includes this slack)
+    return hip_rc(launch_knn(X, N, D, ldx, k, normalize ? 1 : 0, q_begin, q_count, reinterpret_cast<long long*>(out_idx),
+                             out_sims, w, static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

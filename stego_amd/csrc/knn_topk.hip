@@ -1,0 +1,295 @@
+// All-pairs cosine top-k (STEGO's KNN precompute) for gfx950: fused GEMM + running top-k, the [N,N] similarity
+// matrix is never materialised.
+//
+//   reference: src/precompute_knns.py:86-96  -  16 row blocks of  sims = blk . X^T ;  topk(sims, 30)[1]
+//              (:15-21 get_feats: rows are F.normalize'd mean-pooled DINO features; the consumer skips rank 0 = self,
+//               data.py:524)
+//
+// Three launches:
+//   knn_prep_kernel  - (optional F.normalize, eps 1e-12) + fp32 -> split-bf16 (hi, lo) in the LDS-image layout
+//                      [row block of 128][64-column chunk][hi|lo][128][72], zero padded: every later tile load is a
+//                      linear global_load_lds copy, no VALU.
+//   knn_tile_kernel  - one workgroup = 128 queries x one slice of the database, streamed in 128-column tiles.
+//                      sims on v_mfma_f32_32x32x16_bf16 as hi*hi + hi*lo + lo*hi (fp32 accumulate, ~1e-6 abs on a
+//                      cosine: the order of neighbours matches fp32 except for ties at that level; plain fp32 MFMA
+//                      runs at the VALU rate on gfx950 and would take 3x longer).  Wave w owns query rows
+//                      32w..32w+31 and all 128 columns, so in the MFMA C layout every register index r holds two
+//                      complete query rows (lanes 0-31 / 32-63 = 32 of the row's columns): the running top-k of a row
+//                      is ONE VGPR pair (value, index) spread over the 32 lanes of its half-wave, sorted descending.
+//                      Per tile: one compare-and-ballot per row pair against the current k-th value; the (rare:
+//                      ~k ln(N/k) per row in total) hits are inserted with a ballot-popcount position and a
+//                      one-lane shift - registers only, no LDS, no atomics, deterministic.
+//   knn_merge_kernel - merges the per-slice lists of a row (k-way, by repeated arg-max over the list heads).
+// Ties: torch.topk leaves the order of equal values unspecified; so does this.
+#include "corr_common.h"
+
+namespace stego {
+
+constexpr int KNN_TQ = 128;                         // queries per workgroup = rows of an image block
+constexpr int KNN_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] bf16
+constexpr int KNN_MAXK = 32;                        // a list lives in the 32 lanes of a half-wave
+
+struct KnnParams {
+    const float* X;             // [N][ldx] fp32
+    void* img;                  // [nblk][NCH][2][128][LDH] bf16
+    float* part_val;            // [NS][Nq_pad][k]
+    int* part_idx;
+    long long* out_idx;         // [q_count][k]
+    float* out_val;             // optional
+    long long N, ldx;
+    int D, NCH, k, normalize;
+    long long q_begin, q_count; // query rows [q_begin, q_begin + q_count)
+    int nblk, NS, tiles_per_slice;
+};
+
+// ---------------------------------------------------------------------------------------------- prep
+// grid = nblk, block = 256: two threads per row.
+__global__ void __launch_bounds__(NTHREADS) knn_prep_kernel(const KnnParams prm)
+{
+    const int tid = threadIdx.x;
+    const int rl = tid >> 1, half = tid & 1;
+    const long long row = (long long)blockIdx.x * TP + rl;
+    const bool rv = row < prm.N;
+    const float* x = prm.X + (rv ? row : 0) * prm.ldx;
+    const int D = prm.D;
+    float inv = 1.f;
+    if (prm.normalize) {
+        float ss = 0.f;
+        if (rv) for (int c = half; c < D; c += 2) ss += x[c] * x[c];
+        ss += __shfl_xor(ss, 1, 64);
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);                 // F.normalize default eps (precompute_knns.py:19)
+    }
+    __bf16* base = static_cast<__bf16*>(prm.img) + (size_t)blockIdx.x * prm.NCH * (2 * TP * LDH);
+    for (int ch = 0; ch < prm.NCH; ++ch) {
+        __bf16* dh = base + (size_t)ch * (2 * TP * LDH) + rl * LDH;
+        __bf16* dl = dh + TP * LDH;
+        for (int c2 = half * 2; c2 < LDH; c2 += 4) {             // pairs of columns, interleaved between the two threads
+            const int c = ch * KC + c2;
+            const float v0 = (rv && c2 < KC && c < D) ? x[c] * inv : 0.f;
+            const float v1 = (rv && c2 + 1 < KC && c + 1 < D) ? x[c + 1] * inv : 0.f;
+            unsigned h, l;
+            split_bf16_pair(v0, v1, h, l);
+            *reinterpret_cast<unsigned*>(dh + c2) = h;
+            *reinterpret_cast<unsigned*>(dl + c2) = l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- tile + top-k
+__device__ __forceinline__ void knn_copy(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane)
+{
+    for (int pc = wave; pc < KNN_SIDE / 1024; pc += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)pc * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + pc * 1024), 16, 0, 0);
+}
+
+// wave-row layout: this wave's 32 query rows x 128 columns: acc[ni] = 32x32 block of columns 32 ni .. 32 ni + 31
+__device__ __forceinline__ void knn_mma_chunk(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, f32x16 (&acc)[4],
+                                              int lane, int wave)
+{
+    constexpr int LO = TP * LDH;
+    const int r = lane & 31, half = lane >> 5;
+    const __bf16* ap = As + (32 * wave + r) * LDH + 8 * half;
+    const __bf16* bp = Bs + r * LDH + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 16) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + kk), al = *reinterpret_cast<const bf16x8*>(ap + LO + kk);
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            bh[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + kk);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + LO + kk);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[ni], 0, 0, 0);
+    }
+}
+
+// grid = (query blocks, NS); block = 256.  LDS = 2 stages x (A chunk + B chunk).
+__global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NCH = prm.NCH, k = prm.k;
+    const int qblk = (int)(prm.q_begin / TP) + blockIdx.x;            // q_begin is a multiple of 128 (host-checked)
+    const int slice = blockIdx.y;
+    const int tile0 = slice * prm.tiles_per_slice;
+    const int tile1 = min(prm.nblk, tile0 + prm.tiles_per_slice);
+    const unsigned char* img = static_cast<const unsigned char*>(prm.img);
+    const unsigned char* Aimg = img + (size_t)qblk * NCH * KNN_SIDE;
+
+    // running top-k: register index rr <-> query rows  32 wave + (rr&3) + 8 (rr>>2) + 4 (lane>>5)
+    float lv[16];
+    int li[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) { lv[rr] = -INFINITY; li[rr] = -1; }
+    const int slot = lane & 31, hbase = lane & 32;
+
+    const int nstage = (tile1 - tile0) * NCH;
+    auto issue = [&](int g) {
+        const int t = tile0 + g / NCH, c = g - (g / NCH) * NCH;
+        unsigned char* dst = smem + (g & 1) * (2 * KNN_SIDE);
+        knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
+        knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + KNN_SIDE, wave, lane);
+    };
+    if (nstage > 0) issue(0);
+    f32x16 acc[4];
+    int g = 0;
+    for (int t = tile0; t < tile1; ++t) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+        for (int c = 0; c < NCH; ++c, ++g) {
+            __syncthreads();                              // stage g landed (vmcnt(0)); stage g-1 is free
+            if (g + 1 < nstage) issue(g + 1);
+            const unsigned char* st = smem + (g & 1) * (2 * KNN_SIDE);
+            knn_mma_chunk(reinterpret_cast<const __bf16*>(st), reinterpret_cast<const __bf16*>(st + KNN_SIDE), acc, lane, wave);
+        }
+        // ---- selection.  Columns past N (zero rows of the last block) must never be chosen.
+        const long long col0 = (long long)t * TP;
+        if (col0 + TP > prm.N) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                if (col0 + 32 * ni + slot >= prm.N) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ni][e] = -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const float thr = __shfl(lv[rr], hbase + k - 1, 64);           // current k-th best of my row
+            const bool anyc = acc[0][rr] > thr || acc[1][rr] > thr || acc[2][rr] > thr || acc[3][rr] > thr;
+            if (__ballot(anyc) == 0ull) continue;                          // the common case
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                for (;;) {
+                    const float th = __shfl(lv[rr], hbase + k - 1, 64);
+                    const bool cand = acc[ni][rr] > th;
+                    const unsigned long long m = __ballot(cand);
+                    if (m == 0ull) break;
+                    const unsigned mh = (unsigned)(m >> hbase);            // candidates of my half (my row)
+                    const bool have = mh != 0u;
+                    const int cl = have ? __builtin_ctz(mh) : 0;           // first candidate lane of my half
+                    const float x = __shfl(acc[ni][rr], hbase + cl, 64);
+                    const int xi = (int)(col0 + 32 * ni + cl);
+                    if (have) {
+                        // position = number of entries >= x; everything behind it moves down one slot
+                        const unsigned ge = (unsigned)(__ballot(lv[rr] >= x) >> hbase);
+                        const int pos = __builtin_popcount(ge);
+                        const float upv = __shfl_up(lv[rr], 1, 32);
+                        const int upi = __shfl_up(li[rr], 1, 32);
+                        if (slot == pos) { lv[rr] = x; li[rr] = xi; }
+                        else if (slot > pos) { lv[rr] = upv; li[rr] = upi; }
+                        if (slot == cl) acc[ni][rr] = -INFINITY;           // consumed
+                    }
+                }
+            }
+        }
+    }
+    // ---- write the partial lists of this slice (sorted descending)
+    const long long qrow_base = (long long)blockIdx.x * TP + 32 * wave;       // relative to q_begin
+    const long long nq_pad = (long long)gridDim.x * TP;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const long long qr = qrow_base + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+        if (slot < k) {
+            prm.part_val[((size_t)slice * nq_pad + qr) * k + slot] = lv[rr];
+            prm.part_idx[((size_t)slice * nq_pad + qr) * k + slot] = li[rr];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- merge
+// one half-wave per query row: lane s < NS walks slice s's sorted list; k rounds of arg-max over the heads.
+__global__ void __launch_bounds__(NTHREADS) knn_merge_kernel(const KnnParams prm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, s = lane & 31;
+    const long long q = (long long)blockIdx.x * (NTHREADS / 32) + (tid >> 5);
+    if (q >= prm.q_count) return;
+    const int k = prm.k, NS = prm.NS;
+    const long long nq_pad = (long long)((prm.q_count + TP - 1) / TP) * TP;
+    int p = 0;                                                   // my list's head
+    const float* pv = prm.part_val + ((size_t)min(s, NS - 1) * nq_pad + q) * k;
+    const int* pi = prm.part_idx + ((size_t)min(s, NS - 1) * nq_pad + q) * k;
+    for (int out = 0; out < k; ++out) {
+        float v = (s < NS && p < k) ? pv[p] : -INFINITY;
+        int who = s;
+        float best = v;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {                      // arg-max (ties: lower slice first)
+            const float ov = __shfl_xor(best, m, 32);
+            const int ow = __shfl_xor(who, m, 32);
+            if (ov > best || (ov == best && ow < who)) { best = ov; who = ow; }
+        }
+        const int idx = __shfl((s < NS && p < k) ? pi[p] : -1, (lane & 32) + who, 64);
+        if (s == 0) {
+            prm.out_idx[q * k + out] = (long long)idx;
+            if (prm.out_val) prm.out_val[q * k + out] = best;
+        }
+        if (s == who) ++p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int knn_slices(long long q_count, int nblk)
+{
+    // enough workgroups to fill the chip several times over, but slices of at least 8 tiles
+    const long long qb = (q_count + TP - 1) / TP;
+    int ns = (int)((8 * 256 + qb - 1) / qb);
+    if (ns > 32) ns = 32;
+    if (ns > (nblk + 7) / 8) ns = (nblk + 7) / 8;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+size_t knn_workspace_bytes(long long N, int D, int k, long long q_count)
+{
+    const long long nblk = (N + TP - 1) / TP;
+    const int NCH = (D + KC - 1) / KC;
+    const long long nq_pad = ((q_count + TP - 1) / TP) * TP;
+    const int ns = knn_slices(q_count, (int)nblk);
+    size_t b = (size_t)nblk * NCH * KNN_SIDE;
+    b = (b + 255) & ~(size_t)255;
+    b += (size_t)ns * nq_pad * k * 8;
+    return b + 256;
+}
+
+hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, int normalize, long long q_begin,
+                      long long q_count, long long* out_idx, float* out_val, void* ws, hipStream_t stream)
+{
+    KnnParams prm{};
+    prm.X = X; prm.N = N; prm.D = D; prm.ldx = ldx; prm.k = k; prm.normalize = normalize;
+    prm.q_begin = q_begin; prm.q_count = q_count; prm.out_idx = out_idx; prm.out_val = out_val;
+    prm.nblk = (int)((N + TP - 1) / TP);
+    prm.NCH = (D + KC - 1) / KC;
+    prm.NS = knn_slices(q_count, prm.nblk);
+    prm.tiles_per_slice = (prm.nblk + prm.NS - 1) / prm.NS;
+    const long long nq_pad = ((q_count + TP - 1) / TP) * TP;
+    unsigned char* w = static_cast<unsigned char*>(ws);
+    prm.img = w;
+    size_t off = ((size_t)prm.nblk * prm.NCH * KNN_SIDE + 255) & ~(size_t)255;
+    prm.part_val = reinterpret_cast<float*>(w + off);
+    prm.part_idx = reinterpret_cast<int*>(w + off + (size_t)prm.NS * nq_pad * k * 4);
+
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(prm.nblk), dim3(NTHREADS), 0, stream, prm);
+    const int lds = 4 * KNN_SIDE;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(knn_tile_kernel, dim3((unsigned)(nq_pad / TP), prm.NS), dim3(NTHREADS), lds, stream, prm);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + NTHREADS / 32 - 1) / (NTHREADS / 32))), dim3(NTHREADS), 0,
+                       stream, prm);
+    return hipGetLastError();
+}
+
+}  // namespace stego

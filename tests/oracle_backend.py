@@ -75,3 +75,13 @@ def helper_bwd(desc, c1, c2, saved, cd, g_loss, g_cd):
     ga, gb = O._helper_bwd_codes(_np(c1).astype(np.float64), _np(c2).astype(np.float64), fd, cdv,
                                  desc.pos_intra_shift, cfg, gl, None if g_cd is None else _np(g_cd).astype(np.float64))
     return _t(ga, c1), _t(gb, c1)
+
+
+def knn_topk(x, k=30, normalize=False, q_begin=0, q_count=None, return_sims=False):
+    """Oracle-backed double of capi.knn_topk (CPU tests of the sharding logic only)."""
+    import numpy as _np
+    import torch as _torch
+    from oracle import knn_oracle as _K
+    idx, val = _K.knn_topk(x.detach().cpu().numpy(), k, normalize=normalize, q_begin=q_begin, q_count=q_count)
+    i = _torch.from_numpy(idx)
+    return (i, _torch.from_numpy(val.astype(_np.float32))) if return_sims else i

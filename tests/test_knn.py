@@ -1,0 +1,143 @@
+"""KNN precompute: oracle vs the reference-generated golden vectors (CPU), the row-sharded
+multi-rank path on gloo (CPU, oracle-backed backend double), and the HIP kernel through the C ABI (GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import oracle_backend
+from oracle import knn_oracle as K
+from stego_amd import precompute_knns as PK
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "knn_small.npz")
+
+
+def test_oracle_matches_reference_ops_golden():
+    g = np.load(GOLD)
+    idx, val = K.knn_topk(g["normed"], int(g["k"]))
+    np.testing.assert_allclose(val, g["sims"], atol=1e-6)
+    assert (idx == g["nns"]).mean() > 0.99                       # the rest are fp32 near-ties of the reference itself
+    assert K.check_neighbours(g["normed"], g["nns"], int(g["k"]), sims=g["sims"], tol=2e-6) <= 600 // 20
+    np.testing.assert_allclose(K.normalize_rows(g["feats"]), g["normed"], atol=1e-6)
+    # the two duplicated rows sit at rank 0/1 of each other
+    assert set(g["nns"][3, :2]) == {3, 17} and set(g["nns"][17, :2]) == {3, 17}
+
+
+def test_shard_rows_cover_and_align():
+    for n in (1, 127, 128, 129, 1000, 100000):
+        for world in (1, 2, 3, 8):
+            b = [PK.shard_rows(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all(s % 128 == 0 for s, _ in b if s < n)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    PK._backend = oracle_backend
+    g = np.load(GOLD)
+    x = torch.from_numpy(g["normed"])
+    q0, q1 = PK.shard_rows(x.shape[0], world, rank)
+    res = PK.sharded_nearest_neighbors(x[q0:q1].clone(), k=int(g["k"]))
+    if rank == 0:
+        np.save(out, res.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_knn_gloo(tmp_path):
+    """world_size 2: all-gather of the shards, per-rank query slices, gather to rank 0 == the single-rank table."""
+    out = str(tmp_path / "nns.npy")
+    mp.spawn(_shard_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = np.load(GOLD)
+    got = np.load(out)
+    ref, _ = K.knn_topk(g["normed"], int(g["k"]))
+    np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(x, k, **kw):
+    from stego_amd import capi
+    idx, sims = capi.knn_topk(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV), k=k, return_sims=True, **kw)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), sims.cpu().numpy()
+
+
+@gpu
+def test_knn_golden_reference_vectors():
+    g = np.load(GOLD)
+    k = int(g["k"])
+    idx, sims = _run(g["normed"], k)
+    assert idx.dtype == np.int64 and idx.shape == (600, k)
+    K.check_neighbours(g["normed"], idx, k, sims=sims)
+    np.testing.assert_allclose(sims, g["sims"], atol=2e-5)          # the reference's own top-k similarities
+    rows = np.setdiff1d(np.arange(600), [3, 17])
+    np.testing.assert_array_equal(idx[rows, 0], rows)               # self at rank 0 (data.py:524 relies on it)
+    assert set(idx[3, :2]) == {3, 17} and set(idx[17, :2]) == {3, 17}
+    idx2, _ = _run(g["feats"], k, normalize=True)                   # F.normalize inside (precompute_knns.py:19)
+    K.check_neighbours(g["normed"], idx2, k)
+
+
+@gpu
+@pytest.mark.parametrize("n,d,k", [(50, 7, 30), (129, 64, 1), (1000, 100, 32), (1500, 384, 30), (300, 130, 5)])
+def test_knn_edge_shapes(n, d, k):
+    """N below / not a multiple of the 128-row block, D straddling the 64-column chunk, k = 1 and k = 32."""
+    rng = np.random.default_rng(n + d)
+    x = K.normalize_rows(rng.standard_normal((n, d))).astype(np.float32)
+    idx, sims = _run(x, k)
+    assert idx.min() >= 0 and idx.max() < n
+    K.check_neighbours(x, idx, k, sims=sims)
+
+
+@gpu
+def test_knn_query_slices_equal_full_table_and_are_deterministic():
+    rng = np.random.default_rng(5)
+    x = K.normalize_rows(rng.standard_normal((1100, 96))).astype(np.float32)
+    full, fs = _run(x, 30)
+    again, _ = _run(x, 30)
+    np.testing.assert_array_equal(full, again)
+    for q0, qc in ((0, 128), (128, 300), (1024, 76), (256, 844)):
+        part, ps = _run(x, 30, q_begin=q0, q_count=qc)
+        K.check_neighbours(x, part, 30, sims=ps, q_begin=q0)
+        np.testing.assert_allclose(ps, fs[q0:q0 + qc], atol=2e-6)
+
+
+@gpu
+def test_knn_vits8_width_8k_rows_against_oracle():
+    """D = 384 (ViT-S features), 8192 rows, clustered data so that neighbours are meaningful (config 5 shape, scaled)."""
+    rng = np.random.default_rng(11)
+    centers = rng.standard_normal((64, 384))
+    x = centers[rng.integers(0, 64, 8192)] + 0.7 * rng.standard_normal((8192, 384))
+    x = K.normalize_rows(x).astype(np.float32)
+    idx, sims = _run(x, 30)
+    differing = K.check_neighbours(x, idx, 30, sims=sims)
+    assert differing <= 8192 // 100                                  # only tie-band swaps may differ
+    np.testing.assert_array_equal(idx[:, 0], np.arange(8192))
+
+
+@gpu
+def test_knn_rejects_bad_arguments():
+    from stego_amd import capi
+    x = torch.randn(64, 16, device=DEV)
+    with pytest.raises(RuntimeError):
+        capi.knn_topk(x, k=33)
+    with pytest.raises(RuntimeError):
+        capi.knn_topk(x, k=65)                                       # k > N
+    with pytest.raises(RuntimeError):
+        capi.knn_topk(x.cpu(), k=5)                                  # no CPU path
