@@ -109,7 +109,37 @@ __device__ __forceinline__ void knn_mma_chunk(const __bf16* __restrict__ As, con
     }
 }
 
-// grid = (query blocks, NS); block = 256.  LDS = 2 stages x (A chunk + B chunk).
+// A operand from registers (the query block never changes: re-streaming it with every database tile doubled the
+// L2 traffic, and the kernel is bound by that traffic, not by the MFMAs)
+__device__ __forceinline__ void knn_mma_chunk_areg(const bf16x8 (&ah)[KC / 16], const bf16x8 (&al)[KC / 16],
+                                                   const __bf16* __restrict__ Bs, f32x16 (&acc)[4], int lane)
+{
+    constexpr int LO = TP * LDH;
+    const int r = lane & 31, half = lane >> 5;
+    const __bf16* bp = Bs + r * LDH + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+        const int kk = 16 * ks;
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            bh[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + kk);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + LO + kk);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[ni], acc[ni], 0, 0, 0);
+    }
+}
+
+constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 192 VGPRs
+
+// grid = (query blocks, NS); block = 256.  AREG: LDS = 2 stages x B chunk, A in registers (D <= 384);
+// otherwise 2 stages x (A chunk + B chunk).
+template <bool AREG>
 __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,12 +161,26 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
     const int slot = lane & 31, hbase = lane & 32;
 
     const int nstage = (tile1 - tile0) * NCH;
+    constexpr int STAGE = AREG ? KNN_SIDE : 2 * KNN_SIDE;
     auto issue = [&](int g) {
         const int t = tile0 + g / NCH, c = g - (g / NCH) * NCH;
-        unsigned char* dst = smem + (g & 1) * (2 * KNN_SIDE);
-        knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
-        knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + KNN_SIDE, wave, lane);
+        unsigned char* dst = smem + (g & 1) * STAGE;
+        if constexpr (!AREG) knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
+        knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + (AREG ? 0 : KNN_SIDE), wave, lane);
     };
+    bf16x8 Ah[AREG ? KNN_AREG_CHUNKS : 1][KC / 16], Al[AREG ? KNN_AREG_CHUNKS : 1][KC / 16];
+    if constexpr (AREG) {
+        const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
+            const __bf16* ap = reinterpret_cast<const __bf16*>(Aimg + (size_t)min(c, NCH - 1) * KNN_SIDE) + (32 * wave + r) * LDH + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                Ah[c][ks] = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+                Al[c][ks] = *reinterpret_cast<const bf16x8*>(ap + TP * LDH + 16 * ks);
+            }
+        }
+    }
     if (nstage > 0) issue(0);
     f32x16 acc[4];
     int g = 0;
@@ -145,11 +189,23 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
-        for (int c = 0; c < NCH; ++c, ++g) {
-            __syncthreads();                              // stage g landed (vmcnt(0)); stage g-1 is free
-            if (g + 1 < nstage) issue(g + 1);
-            const unsigned char* st = smem + (g & 1) * (2 * KNN_SIDE);
-            knn_mma_chunk(reinterpret_cast<const __bf16*>(st), reinterpret_cast<const __bf16*>(st + KNN_SIDE), acc, lane, wave);
+        if constexpr (AREG) {
+#pragma unroll
+            for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
+                if (c < NCH) {
+                    __syncthreads();                      // stage g landed (vmcnt(0)); stage g-1 is free
+                    if (g + 1 < nstage) issue(g + 1);
+                    knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const __bf16*>(smem + (g & 1) * STAGE), acc, lane);
+                    ++g;
+                }
+            }
+        } else {
+            for (int c = 0; c < NCH; ++c, ++g) {
+                __syncthreads();                          // stage g landed (vmcnt(0)); stage g-1 is free
+                if (g + 1 < nstage) issue(g + 1);
+                const unsigned char* st = smem + (g & 1) * STAGE;
+                knn_mma_chunk(reinterpret_cast<const __bf16*>(st), reinterpret_cast<const __bf16*>(st + KNN_SIDE), acc, lane, wave);
+            }
         }
         // ---- selection.  Columns past N (zero rows of the last block) must never be chosen.
         const long long col0 = (long long)t * TP;
@@ -278,15 +334,19 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     prm.part_idx = reinterpret_cast<int*>(w + off + (size_t)prm.NS * nq_pad * k * 4);
 
     hipLaunchKernelGGL(knn_prep_kernel, dim3(prm.nblk), dim3(NTHREADS), 0, stream, prm);
-    const int lds = 4 * KNN_SIDE;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel),
+    const bool areg = prm.NCH <= KNN_AREG_CHUNKS;
+    const int lds = areg ? 2 * KNN_SIDE : 4 * KNN_SIDE;
+    static bool attr[2] = {false, false};
+    if (!attr[areg]) {
+        hipError_t e = hipFuncSetAttribute(areg ? reinterpret_cast<const void*>(&knn_tile_kernel<true>)
+                                                : reinterpret_cast<const void*>(&knn_tile_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr[areg] = true;
     }
-    hipLaunchKernelGGL(knn_tile_kernel, dim3((unsigned)(nq_pad / TP), prm.NS), dim3(NTHREADS), lds, stream, prm);
+    const dim3 grid((unsigned)(nq_pad / TP), prm.NS);
+    if (areg) hipLaunchKernelGGL(knn_tile_kernel<true>, grid, dim3(NTHREADS), lds, stream, prm);
+    else hipLaunchKernelGGL(knn_tile_kernel<false>, grid, dim3(NTHREADS), lds, stream, prm);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + NTHREADS / 32 - 1) / (NTHREADS / 32))), dim3(NTHREADS), 0,
                        stream, prm);
     return hipGetLastError();
