@@ -166,6 +166,8 @@ def test_cfg4_vitb_shape_against_oracle():
     dict(B=5, C=130, H=7, W=6, K=66, S=7, n_neg=2),     # C, K straddle the 64-wide chunk
     dict(B=3, C=64, H=1, W=1, K=72, S=3, n_neg=1),      # 1x1 map (every tap clamps), K at the limit
     dict(B=2, C=16, H=5, W=5, K=2, S=11, n_neg=0),      # no negatives
+    dict(B=2, C=8, H=3, W=70, K=6, S=4, n_neg=1),       # W > 64: the backward's band (LDS) unsample fallback
+    dict(B=2, C=64, H=40, W=40, K=70, S=11, n_neg=2),   # 32 < W <= 64: 4 pixel tiles per row in the unsample kernel
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_edge_shapes(shape, precision):
