@@ -112,7 +112,8 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
  *   loss_means       : [2] = { pos_intra_loss.mean(), pos_inter_loss.mean() }
  *   pos_intra_cd, pos_inter_cd : [B,S,S,S,S]
  *   neg_inter_loss, neg_inter_cd : [n_neg*B,S,S,S,S]   (torch.cat over negatives, :390-391)
- *   saved_w          : optional [(2+n_neg)*B, S^4]: (fd_centred - shift) per pair-set, and
+ *   saved_w          : optional [(2+n_neg)*B, S^4]: (fd_centred - shift) per pair-set with the clamp pass-mask
+ *                      1[min <= cd <= max] in the mantissa LSB (opaque to callers), and
  *   saved_mean       : optional [2+n_neg]: old_mean per pair-set; both or neither;
  *   saved_ctx        : optional, stego_corr_saved_ctx_bytes(); with saved_w/saved_mean it is all the
  *                      backward needs (the feature side is no_grad in the reference, :326).
@@ -149,7 +150,8 @@ int stego_corr_fwd_profile(const StegoCorrDesc* desc,
  * modules.py:335-347,369-391: clamp mask, the two code GEMM adjoints, normalize backward, the
  * adjoint of the bilinear sampling incl. the orig_code[perm] gather of :385).  Two launches, no
  * global atomics.  Everything about the inputs comes from the forward's saved_w / saved_mean /
- * saved_ctx and the forward's cd outputs; only perms is passed again.
+ * saved_ctx; only perms is passed again (the cd outputs are accepted for ABI stability and may be NULL: the clamp
+ * mask travels inside saved_w).
  *
  *   g_intra, g_inter : device scalars, upstream of loss_means[0], loss_means[1] (NULL -> 0)
  *   g_neg_loss       : upstream of neg_inter_loss; g_neg_loss_stride = 1 -> dense

@@ -116,7 +116,6 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         const int P2 = P * P;
         const size_t t0 = direct ? (size_t)b * P2 : (p < 2 ? (size_t)b * P2 : ((size_t)(p - 2) * B + b) * P2);
         const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
-        const float* cdp = direct ? prm.neg_cd + t0 : (p == 0 ? prm.intra_cd + t0 : (p == 1 ? prm.inter_cd + t0 : prm.neg_cd + t0));
         const float inv_numel = 1.f / ((float)B * (float)P2);
         const float* glp = wp;      // dummy when there is no upstream (scale 0)
         int gl_mul = 0;
@@ -136,17 +135,15 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         const float gc_scale = gcd ? 1.f : 0.f;
         const float* gcp = gcd ? gcd + t0 : wp;
         const float om = prm.saved_mean[p];
-        const float cmin = prm.cmin, cmax = prm.cmax;
         constexpr int RB = 4;
         for (int i0 = 0; i0 < TP / 4; i0 += RB) {
-            float cdv[RB][2], wv[RB][2], glv[RB][2], gcv[RB][2];
+            float wv[RB][2], glv[RB][2], gcv[RB][2];
 #pragma unroll
             for (int j = 0; j < RB; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
                     const int idx = min(r, P - 1) * P + min(c, P - 1);
-                    cdv[j][h] = cdp[idx];
                     wv[j][h] = wp[idx];
                     glv[j][h] = glp[idx * gl_mul];
                     gcv[j][h] = gcp[idx];
@@ -156,8 +153,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
-                    const bool pass = cdv[j][h] >= cmin && cdv[j][h] <= cmax;
-                    float g = pass ? -(wv[j][h] + om) * (glv[j][h] * gl_scale) : 0.f;
+                    // the forward left the clamp pass-mask 1[cmin <= cd <= cmax] in the mantissa LSB of w
+                    const unsigned wb = __builtin_bit_cast(unsigned, wv[j][h]);
+                    const float w = __builtin_bit_cast(float, wb & ~1u);
+                    float g = (wb & 1u) ? -(w + om) * (glv[j][h] * gl_scale) : 0.f;
                     g += gcv[j][h] * gc_scale;
                     G[r * LDG + c] = (r < P && c < P) ? g : 0.f;
                 }

@@ -312,7 +312,11 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
                 const float w = fd4[k] - (rowmean[r] + shift);                 // fd_centred - shift
                 const float cl = fminf(fmaxf(cd4[k], cmin), cmax);
                 const float lp = -cl * w;                                      // loss without the old_mean term
-                w4[k] = w; lp4[k] = lp;
+                // saved for the backward: w with the clamp pass-mask in its mantissa LSB (1 ulp), so that the
+                // backward never has to read cd again (13 MB less HBM traffic in its bandwidth-bound phase)
+                const unsigned pass = (cd4[k] >= cmin && cd4[k] <= cmax) ? 1u : 0u;
+                w4[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, w) & ~1u) | pass);
+                lp4[k] = lp;
                 if (ok[k]) { loss_part += lp; clamp_part += cl; }
             }
             if (prm.debug & 4) continue;
