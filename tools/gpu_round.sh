@@ -46,7 +46,7 @@ if has pmc; then
   for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     NAME=$(echo $CNT | tr ' ' '_' | cut -c1-40)
     timeout 300 rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_$NAME -o pmc -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/pmc_$NAME.err; echo "pmc $CNT rc=$?" | tee -a $OUT/summary.txt
-    python tools/rocpd_stats.py $OUT/pmc_$NAME/pmc_results.db 2>&1 | grep -E "counter|corr_" | tee -a $OUT/summary.txt
+    python tools/rocpd_stats.py $OUT/pmc_$NAME/pmc_results.db 2>&1 | grep -E "counter|corr_|sample_norm|knn_" | tee -a $OUT/summary.txt
     rm -f $OUT/pmc_$NAME/pmc_results.db.keep
   done
 fi
