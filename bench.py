@@ -71,7 +71,7 @@ def head_grad_numel(C, K, n_classes=27):
     return (C * K + K) + (C * C + C + C * K + K) + (K * n_classes + n_classes) + n_classes * K
 
 
-def make_inputs(B, C, H, W, K, S, n_neg, seed, dev):
+def make_inputs(B, C, H, W, K, S, n_neg, seed, dev, layout="cl"):
     """DINO-like synthetic features (SURVEY.md 8(d) distribution ii), channels-last strided views
     exactly as DinoFeaturizer hands them over (modules.py:97), plus the RNG draws of one step."""
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -97,8 +97,10 @@ def make_inputs(B, C, H, W, K, S, n_neg, seed, dev):
         p = torch.where(p == torch.arange(B, device=dev), p + 1, p) % B
         perms.append(p)
     perms = torch.stack(perms) if perms else torch.zeros(0, B, dtype=torch.long, device=dev)
-    return dict(feats=f.permute(0, 3, 1, 2), feats_pos=fp.permute(0, 3, 1, 2),
-                code=c.permute(0, 3, 1, 2), code_pos=cp.permute(0, 3, 1, 2),
+    maps = [t.permute(0, 3, 1, 2) for t in (f, fp, c, cp)]        # channels-last strided views (modules.py:97)
+    if layout == "nchw":
+        maps = [t.contiguous() for t in maps]                      # NCHW-contiguous: the generic (scalar gather) paths
+    return dict(feats=maps[0], feats_pos=maps[1], code=maps[2], code_pos=maps[3],
                 coords1=coords1, coords2=coords2, perms=perms)
 
 
@@ -164,6 +166,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="time the forward alone (reported in config)")
+    ap.add_argument("--layout", default="cl", choices=["cl", "nchw"],
+                    help="cl = channels-last strided views as DinoFeaturizer emits (default); nchw = contiguous NCHW")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,7 +190,7 @@ def main():
     prec = capi.PREC_F32 if args.precision == "f32" else capi.PREC_BF16X3
     desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
                           prec)
-    sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev) for i in range(args.sets)]
+    sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
     # upstream gradients exactly as train_segmentation.py:169-181 produces them
     g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
     g_inter = torch.tensor(cfg.pos_inter_weight, device=dev)
@@ -325,7 +329,7 @@ def main():
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,
                                                              "forward only" if args.fwd_only else "forward+backward"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
-                       "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)",
+                       "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
                        "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
             "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us,
             "cpu_baseline": cpu,
