@@ -198,10 +198,13 @@ def main():
     grad_buf = torch.zeros(head_grad_numel(C, K), device=dev)     # flat head-gradient bucket (DDP)
     keep = [None] * args.sets
 
+    from stego_amd.modules import as_channels_last      # the host-side layout policy of the op (no-op for cl views)
+
     def step_compute(i):
         d = sets[i]
         need_grad = not args.fwd_only
-        out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"],
+        out = capi.corr_fwd(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
+                            as_channels_last(d["code"]), as_channels_last(d["code_pos"]), d["coords1"], d["coords2"],
                             d["perms"], need_grad)
         if need_grad:
             lm, icd, ecd, nl, ncd, saved = out

@@ -101,6 +101,26 @@ def test_backward_general_upstream(name):
     assert_close(r["d_code_pos"], g["d_code_pos_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos_gen")
 
 
+def test_generic_strided_path_direct_through_capi():
+    """modules.py re-lays large NCHW maps out channels-last (as_channels_last); the kernels' generic strided path
+    is still part of the C ABI: call it directly with NCHW-contiguous maps and compare with the channels-last run."""
+    d = O.synth_inputs(4, 192, 14, 14, 70, 11, 2, seed=31, dino_like=True)
+    cfg = O.CorrCfg(neg_samples=2)
+    t = {k: _dev(v) for k, v in d.items() if k != "perms"}
+    perms = _dev(d["perms"])
+    desc = capi.make_desc(4, 192, 70, 14, 14, 11, 2, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
+                          capi.PREC_F32)
+    assert t["feats"].numel() >= 1 << 16 and t["feats"].stride(1) != 1            # would be re-laid out by modules.py
+    a = capi.corr_fwd(desc, t["feats"], t["feats_pos"], t["code"], t["code_pos"], t["coords1"], t["coords2"], perms, False)
+    cl = [_channels_last(t[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+    b = capi.corr_fwd(desc, *cl, t["coords1"], t["coords2"], perms, False)
+    for x, y in zip(a[:5], b[:5]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    ref = O.corr_loss_forward(**{k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")},
+                              perms=d["perms"], cfg=cfg)
+    assert_close(a[3].cpu().numpy().reshape(ref.neg_inter_loss.shape), ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
+
+
 _ORACLE_CACHE = {}
 
 
