@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level table
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-input MFMA (same table)
-MFMA_BF16_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA
+MFMA_F16_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA
 
 
 class Cfg:
@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (B)")
     ap.add_argument("--workload", default="vits8_224", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
     ap.add_argument("--sets", type=int, default=4, help="input sets rotated (4 x 91 MB > 256 MB Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,7 +187,7 @@ def main():
     cfg.corr_precision = args.precision
     C, H, W, K = WORKLOADS[args.workload]
     B, S, n_neg = args.batch, cfg.feature_samples, cfg.neg_samples
-    prec = capi.PREC_F32 if args.precision == "f32" else capi.PREC_BF16X3
+    prec = capi.PREC_F32 if args.precision == "f32" else capi.PREC_F16X3
     desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
                           prec)
     sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
@@ -311,10 +311,10 @@ def main():
                                                            frac=ab_in / (ms_samp * 1e-3) / HBM_PEAK),
                                 "corr_tile_kernel": dict(algorithmic_bytes=ab_out, achieved_GBps=ab_out / (ms_main * 1e-3) / 1e9,
                                                          frac=ab_out / (ms_main * 1e-3) / HBM_PEAK)})
-        peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_BF16_PEAK / 3.0
+        peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_F16_PEAK / 3.0
         roof_mfma = dict(bound="mfma", kernel="corr_tile_kernel", achieved=fl / (ms_main * 1e-3) / 1e12,
                          peak=peak / 1e12, unit="TFLOP/s", frac=fl / (ms_main * 1e-3) / peak, algorithmic_flops=fl,
-                         note="f32: v_mfma_f32_32x32x2_f32 peak; bf16x3: dense bf16 peak / 3 (three MFMAs per product)")
+                         note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -326,7 +326,7 @@ def main():
             "metric": "image-pairs/sec through correspondence loss, B=32 224^2, ViT-S/8",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3-split (f32 accumulate)",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3-split (fp16 hi+lo operands, 3 MFMAs, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s: B=%d/GPU, C=%d, %dx%d map, K=%d, S=%d, %d negatives, self+KNN+random "
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,

@@ -42,7 +42,7 @@ enum {
 /* Arithmetic used for the channel contraction (the einsum of modules.py:283-284). */
 enum {
     STEGO_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate  */
-    STEGO_PREC_BF16X3 = 1    /* feature correlation on split-bf16 (hi*hi + hi*lo + lo*hi, bf16  */
+    STEGO_PREC_F16X3 = 1     /* feature correlation on split-fp16 (hi*hi + hi*lo + lo*hi, fp16  */
                              /* MFMA, fp32 accumulate; ~1e-6 abs error on a cosine, fp32 ~1e-7); */
                              /* the code correlation (which carries gradients) stays exact fp32  */
 };
@@ -202,7 +202,7 @@ int stego_corr_helper_bwd(const StegoCorrDesc* desc,
  *   out_idx  : OUT int64 [q_count, k], neighbours by descending similarity (rank 0 = the row itself unless a
  *              duplicate row ties with it; torch.topk leaves tie order unspecified, so does this)
  *   out_sims : OUT fp32 [q_count, k] or NULL
- * Limits: 1 <= k <= 32, k <= N < 2^31.  Contraction arithmetic: split-bf16 (3 MFMAs, fp32 accumulate), ~1e-6 abs.
+ * Limits: 1 <= k <= 32, k <= N < 2^31.  Contraction arithmetic: split-fp16 (3 MFMAs, fp32 accumulate), ~2e-7 abs.
  */
 size_t stego_knn_workspace_bytes(int64_t N, int32_t D, int32_t k, int64_t q_count);
 int stego_knn_topk(const float* X, int64_t N, int32_t D, int64_t ldx, int32_t k, int32_t normalize,

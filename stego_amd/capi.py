@@ -13,7 +13,8 @@ import torch
 from . import _build
 
 PREC_F32 = 0
-PREC_BF16X3 = 1
+PREC_F16X3 = 1
+PREC_BF16X3 = PREC_F16X3        # old name of the split mode (it used bf16 halves until round 1, third design)
 
 
 class StegoMap(Structure):

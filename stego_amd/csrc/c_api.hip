@@ -53,7 +53,7 @@ int check_desc(const StegoCorrDesc* d, bool helper)
         if (d->S * d->S > TP) return STEGO_ERR_UNSUPPORTED;
         if (d->n_neg + 2 > 256) return STEGO_ERR_UNSUPPORTED;
     }
-    if (d->precision != STEGO_PREC_F32 && d->precision != STEGO_PREC_BF16X3) return STEGO_ERR_UNSUPPORTED;
+    if (d->precision != STEGO_PREC_F32 && d->precision != STEGO_PREC_F16X3) return STEGO_ERR_UNSUPPORTED;
     return STEGO_OK;
 }
 
@@ -73,7 +73,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.LDK = g.KQ + 4;
     const size_t n_tiles = (size_t)(helper ? 1 : 2 + d->n_neg) * d->B;
     g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * 64, 256);      // tail: debug stamps (8 per tile)
-    const size_t fside = d->precision == STEGO_PREC_BF16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
+    const size_t fside = d->precision == STEGO_PREC_F16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
     g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only
     g.cs_bytes = round_up((size_t)g.nset * TP * g.LDK * sizeof(float) + 1024, 256);
     g.nrm_bytes = round_up((size_t)g.nset * TP * sizeof(float), 256);

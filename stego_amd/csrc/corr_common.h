@@ -8,18 +8,19 @@ namespace stego {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half_t;                        // element type of the split operands (see split_f16_pair)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TP = 128;        // sample points per side, padded (S*S <= 128)
 constexpr int NTHREADS = 256;  // 4 wave64 (the gather team size everywhere)
 constexpr int KC = 64;         // channels per staged chunk
 constexpr int LDA = KC + 4;    // f32 stage row stride in floats: 272 B rows, conflict-free ds_read_b128
-constexpr int LDH = KC + 8;    // bf16 stage row stride in elements: 144 B rows, conflict-free ds_read_b128
+constexpr int LDH = KC + 8;    // fp16 stage row stride in elements: 144 B rows, conflict-free ds_read_b128
 constexpr int LDT = 129;       // epilogue tile row stride (odd -> conflict-free column walks)
 
-enum { PREC_F32 = 0, PREC_BF16X3 = 1 };
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
 // float32 [N,C,H,W] view; strides in elements. Per-image offsets are < 2^31 (host-checked).
 struct MapV {
@@ -60,7 +61,7 @@ struct SampleParams {
     const float* coords1;
     const float* coords2;
     const long long* perms;                    // [n_neg][B]
-    void* fs;                                  // f32: [B][NCH][128][LDA] float; bf16x3: [B][NCH][2][128][LDH] bf16 (roles < feat_roles)
+    void* fs;                                  // f32: [B][NCH][128][LDA] float; f16x3: [B][NCH][2][128][LDH] fp16 (roles < feat_roles)
     float* cs;                                 // [nset][128][LDK] normalised sampled codes
     float* nrm;                                // [nset][128] code norms before normalisation
     int4* tapyx;                               // optional [nset][128] packed tap pixels (for the backward)
@@ -160,14 +161,17 @@ template <> struct VecT<4> { typedef f32x4 type; };
 template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<1> { typedef float type; };
 
-// fp32 -> (hi, lo) bf16 split, both round-to-nearest-even (v_cvt_pk_bf16_f32):  x ~= hi + lo with
-// |x - hi - lo| <= 2^-16 |x|.  Returns the two packed dwords for a pair of values.
-__device__ __forceinline__ void split_bf16_pair(float x, float y, unsigned& hi, unsigned& lo)
+// fp32 -> (hi, lo) fp16 split (v_cvt_pk_f16_f32):  x = hi + lo + e with |e| <= 2^-22 |x| for |x| in the fp16 normal
+// range (11 + 11 mantissa bits; below it the absolute error is < 2^-25).  hi*hi + hi*lo + lo*hi on the fp16 matrix
+// cores (3 MFMAs, fp32 accumulate) therefore carries products to ~2^-21: fp32-grade, at 3/16 of the cost of the
+// fp32 MFMA (which runs at the VALU rate on gfx950).  Callers keep |x| < 65504 (raw gathered features are scaled by
+// 2^-4 first, their L2 normalisation cancels the scale).  Returns the two packed dwords for a pair of values.
+__device__ __forceinline__ void split_f16_pair(float x, float y, unsigned& hi, unsigned& lo)
 {
-    const bf16x2 h = __builtin_convertvector(f32x2{x, y}, bf16x2);
+    const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    const float hx = __builtin_bit_cast(float, hi << 16), hy = __builtin_bit_cast(float, hi & 0xffff0000u);
-    const bf16x2 l = __builtin_convertvector(f32x2{x - hx, y - hy}, bf16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(f32x2{x - hf[0], y - hf[1]}, f16x2);
     lo = __builtin_bit_cast(unsigned, l);
 }
 

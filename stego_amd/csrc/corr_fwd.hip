@@ -21,7 +21,7 @@
 //   * codes (K <= 72, both sides): normalised by the sampler (the backward needs them anyway), one
 //     global_load_lds stage at the end.
 // Contraction arithmetic: PREC_F32 = v_mfma_f32_32x32x2_f32 (exact fp32) for both correlations;
-// PREC_BF16X3 = the feature correlation on split-bf16 (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_bf16, fp32
+// PREC_F16X3 = the feature correlation on split-fp16 (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_f16, fp32
 // accumulate, ~1e-6 abs error on a cosine); the code correlation stays exact f32 because its sign decides the
 // clamp mask of the backward.
 //
@@ -38,7 +38,7 @@ constexpr int SD_TAPO = SD_CSC + TP * 4;          // int4 tapo[128]: element off
 constexpr int SD_TAPW = SD_TAPO + TP * 16;        // float4 tapw[128]
 constexpr int SD_BIG = SD_TAPW + TP * 16;         // 5376: two stage buffers, aliased by the result tiles
 constexpr int FEAT_SIDE_F32 = TP * LDA * 4;       // 34816 = 34 x 1 KB : one operand, one 64-channel chunk
-constexpr int FEAT_SIDE_BF16 = 2 * TP * LDH * 2;  // 36864 = 36 x 1 KB : hi + lo
+constexpr int FEAT_SIDE_F16 = 2 * TP * LDH * 2;  // 36864 = 36 x 1 KB : hi + lo
 constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;  // epilogue: fd + cd tiles
 
 // One staged chunk of the contraction on v_mfma_f32_32x32x2_f32.  Wave (wr,wc) owns the
@@ -99,42 +99,42 @@ __device__ __forceinline__ void mma_code_f32(const float* __restrict__ As, const
     }
 }
 
-// Split-bf16 contraction of one chunk: a.b ~= ah.bh + ah.bl + al.bh (the al.bl term is < 2^-16).
-// Stage layout: hi[128][LDH] then lo[128][LDH] (bf16).  Each lane reads 8 consecutive k
+// Split-fp16 contraction of one chunk: a.b ~= ah.bh + ah.bl + al.bh (the al.bl term is < 2^-22).
+// Stage layout: hi[128][LDH] then lo[128][LDH] (fp16).  Each lane reads 8 consecutive k
 // (lanes 0-31: kk..kk+7, lanes 32-63: kk+8..kk+15) per operand with one ds_read_b128.
 template <class F>
-__device__ __forceinline__ void mma_chunk_bf16x3(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs,
+__device__ __forceinline__ void mma_chunk_f16x3(const half_t* __restrict__ As, const half_t* __restrict__ Bs,
                                                  f32x16 (&acc)[2][2], int lane, int wr, int wc, F&& pre)
 {
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
-    const __bf16* a0p = As + (64 * wr + r) * LDH + 8 * half;
-    const __bf16* a1p = a0p + 32 * LDH;
-    const __bf16* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
-    const __bf16* b1p = b0p + 32 * LDH;
+    const half_t* a0p = As + (64 * wr + r) * LDH + 8 * half;
+    const half_t* a1p = a0p + 32 * LDH;
+    const half_t* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
+    const half_t* b1p = b0p + 32 * LDH;
 #pragma unroll
     for (int st = 0; st < KC / 8; ++st) {         // 8 slots like the f32 version: MFMAs on the even ones
         pre(st);
         __builtin_amdgcn_sched_barrier(0);
         const int kk = 8 * st;
         if ((st & 1) == 0) {
-            const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0p + kk), al0 = *reinterpret_cast<const bf16x8*>(a0p + LO + kk);
-            const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1p + kk), al1 = *reinterpret_cast<const bf16x8*>(a1p + LO + kk);
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b0p + kk), bl0 = *reinterpret_cast<const bf16x8*>(b0p + LO + kk);
-            const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b1p + kk), bl1 = *reinterpret_cast<const bf16x8*>(b1p + LO + kk);
+            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(a0p + kk), al0 = *reinterpret_cast<const f16x8*>(a0p + LO + kk);
+            const f16x8 ah1 = *reinterpret_cast<const f16x8*>(a1p + kk), al1 = *reinterpret_cast<const f16x8*>(a1p + LO + kk);
+            const f16x8 bh0 = *reinterpret_cast<const f16x8*>(b0p + kk), bl0 = *reinterpret_cast<const f16x8*>(b0p + LO + kk);
+            const f16x8 bh1 = *reinterpret_cast<const f16x8*>(b1p + kk), bl1 = *reinterpret_cast<const f16x8*>(b1p + LO + kk);
             // small cross terms first, then the leading term; accumulators interleaved
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
         }
     }
 }
@@ -157,6 +157,8 @@ __device__ __forceinline__ void issue_copy(const unsigned char* __restrict__ gsr
 // Per chunk and lane: ITEMS x 4 tap loads into registers during the first half of the MFMA k groups, blended
 // and written to the other LDS stage buffer during the second half (by then they have landed; the blend's VALU
 // work rides in the MFMA shadow).
+constexpr float B_RAW_SCALE = 0.0625f;            // split mode: raw B values are staged as x / 16
+
 template <int V> struct GatherRegs {
     typedef typename VecT<V>::type vec;
     static constexpr int SLOTS = KC / V;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const float* __re
 }
 
 // items [j0, j0 + n): blend the 4 taps, accumulate the points' sums of squares, write the LDS operand image
-//   PREC_F32   : float [128][LDA]            PREC_BF16X3: bf16 hi[128][LDH] then lo[128][LDH]
+//   PREC_F32   : float [128][LDA]            PREC_F16X3: fp16 hi[128][LDH] then lo[128][LDH]
 template <int V, int PREC>
 __device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const float4* __restrict__ tapw, bool chok,
                                               void* __restrict__ dst_, float (&ss)[GatherRegs<V>::ITEMS], int slot, int prow,
@@ -222,17 +224,20 @@ __device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const floa
             if constexpr (V == 4) *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
             else d[0] = v[0];
         } else {
-            __bf16* dh = static_cast<__bf16*>(dst_) + q * LDH + col;
-            __bf16* dl = dh + TP * LDH;
+            half_t* dh = static_cast<half_t*>(dst_) + q * LDH + col;
+            half_t* dl = dh + TP * LDH;
+            // raw (un-normalised) values: 2^-4 keeps |x| < 1e6 inside fp16; the column scale undoes it
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] *= B_RAW_SCALE;
             if constexpr (V == 4) {
                 unsigned h0, l0, h1, l1;
-                split_bf16_pair(v[0], v[1], h0, l0);
-                split_bf16_pair(v[2], v[3], h1, l1);
+                split_f16_pair(v[0], v[1], h0, l0);
+                split_f16_pair(v[2], v[3], h1, l1);
                 *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
                 *reinterpret_cast<u32x2*>(dl) = u32x2{l0, l1};
             } else {
                 unsigned h0, l0;
-                split_bf16_pair(v[0], 0.f, h0, l0);
+                split_f16_pair(v[0], 0.f, h0, l0);
                 *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h0 & 0xffffu);
                 *reinterpret_cast<unsigned short*>(dl) = (unsigned short)(l0 & 0xffffu);
             }
@@ -375,7 +380,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
     unsigned char* stage = smem + SD_BIG;
     float* Tfd = reinterpret_cast<float*>(smem + SD_BIG);   // epilogue alias of the stage buffers
     float* Tcd = Tfd + TP * LDT;
-    constexpr int FSIDE = PREC == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_BF16;
+    constexpr int FSIDE = PREC == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_F16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -480,7 +485,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
         if constexpr (PREC == PREC_F32)
             mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc, pre);
         else
-            mma_chunk_bf16x3(reinterpret_cast<const __bf16*>(Ab), reinterpret_cast<const __bf16*>(Bb), accf, lane, wr, wc, pre);
+            mma_chunk_f16x3(reinterpret_cast<const half_t*>(Ab), reinterpret_cast<const half_t*>(Bb), accf, lane, wr, wc, pre);
     }
     // ---- the code correlation: one stage, exact f32 (its accumulators only live from here on)
     f32x16 accc[2][2];
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
             float s = ss[j];
 #pragma unroll
             for (int m = SLOTS / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            if (slot == 0) csc[j * PPI + prow] = sameAB ? 1.f : 1.f / fmaxf(sqrtf(s), 1e-10f);
+            if (slot == 0) csc[j * PPI + prow] = sameAB ? 1.f : (PREC == PREC_F16X3 ? 1.f / B_RAW_SCALE : 1.f) / fmaxf(sqrtf(s), 1e-10f);
         }
     }
 
@@ -606,7 +611,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
 // bytes of one stage buffer: max(feature chunk pair, code operand pair)
 int dense_stage_bytes(int precision, int LDK)
 {
-    const int f = 2 * (precision == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_BF16);
+    const int f = 2 * (precision == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_F16);
     const int c = 2 * TP * LDK * 4;
     return f > c ? f : c;
 }
@@ -632,8 +637,8 @@ hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t st
     static int have[4] = {0, 0, 0, 0};
     const void* fns[4] = {reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32, 4>),
                           reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F32, 1>),
-                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3, 4>),
-                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_BF16X3, 1>)};
+                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F16X3, 4>),
+                          reinterpret_cast<const void*>(&corr_tile_kernel<PREC_F16X3, 1>)};
     if (have[which] < lds) {
         hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -643,8 +648,8 @@ hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t st
     switch (which) {
         case 0: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 4>), grid, block, lds, stream, prm, stage); break;
         case 1: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 1>), grid, block, lds, stream, prm, stage); break;
-        case 2: hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3, 4>), grid, block, lds, stream, prm, stage); break;
-        default: hipLaunchKernelGGL((corr_tile_kernel<PREC_BF16X3, 1>), grid, block, lds, stream, prm, stage); break;
+        case 2: hipLaunchKernelGGL((corr_tile_kernel<PREC_F16X3, 4>), grid, block, lds, stream, prm, stage); break;
+        default: hipLaunchKernelGGL((corr_tile_kernel<PREC_F16X3, 1>), grid, block, lds, stream, prm, stage); break;
     }
     return hipGetLastError();
 }

@@ -34,11 +34,11 @@ __device__ __forceinline__ void store_feat4(const SampleParams& prm, int s, int 
         float* d = static_cast<float*>(prm.fs) + (((size_t)s * prm.NCH + chunk) * TP + q) * LDA + col;
         *reinterpret_cast<f32x4*>(d) = v;
     } else {
-        __bf16* dh = static_cast<__bf16*>(prm.fs) + ((((size_t)s * prm.NCH + chunk) * 2) * TP + q) * LDH + col;
-        __bf16* dl = dh + TP * LDH;
+        half_t* dh = static_cast<half_t*>(prm.fs) + ((((size_t)s * prm.NCH + chunk) * 2) * TP + q) * LDH + col;
+        half_t* dl = dh + TP * LDH;
         unsigned h0, l0, h1, l1;
-        split_bf16_pair(v[0], v[1], h0, l0);
-        split_bf16_pair(v[2], v[3], h1, l1);
+        split_f16_pair(v[0], v[1], h0, l0);
+        split_f16_pair(v[2], v[3], h1, l1);
         *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(dl) = u32x2{l0, l1};
     }
@@ -51,9 +51,9 @@ __device__ __forceinline__ void store_feat1(const SampleParams& prm, int s, int 
     if constexpr (PREC == PREC_F32) {
         static_cast<float*>(prm.fs)[(((size_t)s * prm.NCH + chunk) * TP + q) * LDA + col] = v;
     } else {
-        __bf16* dh = static_cast<__bf16*>(prm.fs) + ((((size_t)s * prm.NCH + chunk) * 2) * TP + q) * LDH + col;
+        half_t* dh = static_cast<half_t*>(prm.fs) + ((((size_t)s * prm.NCH + chunk) * 2) * TP + q) * LDH + col;
         unsigned h0, l0;
-        split_bf16_pair(v, 0.f, h0, l0);
+        split_f16_pair(v, 0.f, h0, l0);
         *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h0 & 0xffffu);
         *reinterpret_cast<unsigned short*>(dh + TP * LDH) = (unsigned short)(l0 & 0xffffu);
     }
@@ -269,7 +269,7 @@ hipError_t launch_corr_sample(const SampleParams& prm_in, int precision, hipStre
 #define STEGO_SAMPLE_LAUNCH(N, PR, CC) hipLaunchKernelGGL((sample_norm_kernel<N, PR, CC>), grid, block, 0, stream, prm)
 #define STEGO_SAMPLE_CASE(N)                                                                        \
     case N:                                                                                         \
-        if (precision == PREC_BF16X3) { if (ccl) STEGO_SAMPLE_LAUNCH(N, PREC_BF16X3, true); else STEGO_SAMPLE_LAUNCH(N, PREC_BF16X3, false); } \
+        if (precision == PREC_F16X3) { if (ccl) STEGO_SAMPLE_LAUNCH(N, PREC_F16X3, true); else STEGO_SAMPLE_LAUNCH(N, PREC_F16X3, false); } \
         else { if (ccl) STEGO_SAMPLE_LAUNCH(N, PREC_F32, true); else STEGO_SAMPLE_LAUNCH(N, PREC_F32, false); } \
         break;
     switch (nj) {

@@ -6,11 +6,11 @@
 //               data.py:524)
 //
 // Three launches:
-//   knn_prep_kernel  - (optional F.normalize, eps 1e-12) + fp32 -> split-bf16 (hi, lo) in the LDS-image layout
+//   knn_prep_kernel  - (optional F.normalize, eps 1e-12) + fp32 -> split-fp16 (hi, lo) in the LDS-image layout
 //                      [row block of 128][64-column chunk][hi|lo][128][72], zero padded: every later tile load is a
 //                      linear global_load_lds copy, no VALU.
 //   knn_tile_kernel  - one workgroup = 128 queries x one slice of the database, streamed in 128-column tiles.
-//                      sims on v_mfma_f32_32x32x16_bf16 as hi*hi + hi*lo + lo*hi (fp32 accumulate, ~1e-6 abs on a
+//                      sims on v_mfma_f32_32x32x16_f16 as hi*hi + hi*lo + lo*hi (fp32 accumulate, ~2e-7 abs on a
 //                      cosine: the order of neighbours matches fp32 except for ties at that level; plain fp32 MFMA
 //                      runs at the VALU rate on gfx950 and would take 3x longer).  Wave w owns query rows
 //                      32w..32w+31 and all 128 columns, so in the MFMA C layout every register index r holds two
@@ -26,12 +26,12 @@
 namespace stego {
 
 constexpr int KNN_TQ = 128;                         // queries per workgroup = rows of an image block
-constexpr int KNN_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] bf16
+constexpr int KNN_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] fp16
 constexpr int KNN_MAXK = 32;                        // a list lives in the 32 lanes of a half-wave
 
 struct KnnParams {
     const float* X;             // [N][ldx] fp32
-    void* img;                  // [nblk][NCH][2][128][LDH] bf16
+    void* img;                  // [nblk][NCH][2][128][LDH] fp16
     float* part_val;            // [NS][Nq_pad][k]
     int* part_idx;
     long long* out_idx;         // [q_count][k]
@@ -59,16 +59,16 @@ __global__ void __launch_bounds__(NTHREADS) knn_prep_kernel(const KnnParams prm)
         ss += __shfl_xor(ss, 1, 64);
         inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);                 // F.normalize default eps (precompute_knns.py:19)
     }
-    __bf16* base = static_cast<__bf16*>(prm.img) + (size_t)blockIdx.x * prm.NCH * (2 * TP * LDH);
+    half_t* base = static_cast<half_t*>(prm.img) + (size_t)blockIdx.x * prm.NCH * (2 * TP * LDH);
     for (int ch = 0; ch < prm.NCH; ++ch) {
-        __bf16* dh = base + (size_t)ch * (2 * TP * LDH) + rl * LDH;
-        __bf16* dl = dh + TP * LDH;
+        half_t* dh = base + (size_t)ch * (2 * TP * LDH) + rl * LDH;
+        half_t* dl = dh + TP * LDH;
         for (int c2 = half * 2; c2 < LDH; c2 += 4) {             // pairs of columns, interleaved between the two threads
             const int c = ch * KC + c2;
             const float v0 = (rv && c2 < KC && c < D) ? x[c] * inv : 0.f;
             const float v1 = (rv && c2 + 1 < KC && c + 1 < D) ? x[c + 1] * inv : 0.f;
             unsigned h, l;
-            split_bf16_pair(v0, v1, h, l);
+            split_f16_pair(v0, v1, h, l);
             *reinterpret_cast<unsigned*>(dh + c2) = h;
             *reinterpret_cast<unsigned*>(dl + c2) = l;
         }
@@ -84,54 +84,54 @@ __device__ __forceinline__ void knn_copy(const unsigned char* __restrict__ gsrc,
 }
 
 // wave-row layout: this wave's 32 query rows x 128 columns: acc[ni] = 32x32 block of columns 32 ni .. 32 ni + 31
-__device__ __forceinline__ void knn_mma_chunk(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, f32x16 (&acc)[4],
+__device__ __forceinline__ void knn_mma_chunk(const half_t* __restrict__ As, const half_t* __restrict__ Bs, f32x16 (&acc)[4],
                                               int lane, int wave)
 {
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
-    const __bf16* ap = As + (32 * wave + r) * LDH + 8 * half;
-    const __bf16* bp = Bs + r * LDH + 8 * half;
+    const half_t* ap = As + (32 * wave + r) * LDH + 8 * half;
+    const half_t* bp = Bs + r * LDH + 8 * half;
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 16) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + kk), al = *reinterpret_cast<const bf16x8*>(ap + LO + kk);
-        bf16x8 bh[4], bl[4];
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(ap + kk), al = *reinterpret_cast<const f16x8*>(ap + LO + kk);
+        f16x8 bh[4], bl[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            bh[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + kk);
-            bl[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + LO + kk);
+            bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + kk);
+            bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + kk);
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[ni], 0, 0, 0);
     }
 }
 
 // A operand from registers (the query block never changes: re-streaming it with every database tile doubled the
 // L2 traffic, and the kernel is bound by that traffic, not by the MFMAs)
-__device__ __forceinline__ void knn_mma_chunk_areg(const bf16x8 (&ah)[KC / 16], const bf16x8 (&al)[KC / 16],
-                                                   const __bf16* __restrict__ Bs, f32x16 (&acc)[4], int lane)
+__device__ __forceinline__ void knn_mma_chunk_areg(const f16x8 (&ah)[KC / 16], const f16x8 (&al)[KC / 16],
+                                                   const half_t* __restrict__ Bs, f32x16 (&acc)[4], int lane)
 {
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
-    const __bf16* bp = Bs + r * LDH + 8 * half;
+    const half_t* bp = Bs + r * LDH + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
         const int kk = 16 * ks;
-        bf16x8 bh[4], bl[4];
+        f16x8 bh[4], bl[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            bh[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + kk);
-            bl[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 32 * LDH + LO + kk);
+            bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + kk);
+            bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + kk);
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[ni], acc[ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ni], acc[ni], 0, 0, 0);
     }
 }
 
@@ -168,16 +168,16 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
         if constexpr (!AREG) knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
         knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + (AREG ? 0 : KNN_SIDE), wave, lane);
     };
-    bf16x8 Ah[AREG ? KNN_AREG_CHUNKS : 1][KC / 16], Al[AREG ? KNN_AREG_CHUNKS : 1][KC / 16];
+    f16x8 Ah[AREG ? KNN_AREG_CHUNKS : 1][KC / 16], Al[AREG ? KNN_AREG_CHUNKS : 1][KC / 16];
     if constexpr (AREG) {
         const int r = lane & 31, half = lane >> 5;
 #pragma unroll
         for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
-            const __bf16* ap = reinterpret_cast<const __bf16*>(Aimg + (size_t)min(c, NCH - 1) * KNN_SIDE) + (32 * wave + r) * LDH + 8 * half;
+            const half_t* ap = reinterpret_cast<const half_t*>(Aimg + (size_t)min(c, NCH - 1) * KNN_SIDE) + (32 * wave + r) * LDH + 8 * half;
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ++ks) {
-                Ah[c][ks] = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
-                Al[c][ks] = *reinterpret_cast<const bf16x8*>(ap + TP * LDH + 16 * ks);
+                Ah[c][ks] = *reinterpret_cast<const f16x8*>(ap + 16 * ks);
+                Al[c][ks] = *reinterpret_cast<const f16x8*>(ap + TP * LDH + 16 * ks);
             }
         }
     }
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
                 if (c < NCH) {
                     __syncthreads();                      // stage g landed (vmcnt(0)); stage g-1 is free
                     if (g + 1 < nstage) issue(g + 1);
-                    knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const __bf16*>(smem + (g & 1) * STAGE), acc, lane);
+                    knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const half_t*>(smem + (g & 1) * STAGE), acc, lane);
                     ++g;
                 }
             }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
                 __syncthreads();                          // stage g landed (vmcnt(0)); stage g-1 is free
                 if (g + 1 < nstage) issue(g + 1);
                 const unsigned char* st = smem + (g & 1) * STAGE;
-                knn_mma_chunk(reinterpret_cast<const __bf16*>(st), reinterpret_cast<const __bf16*>(st + KNN_SIDE), acc, lane, wave);
+                knn_mma_chunk(reinterpret_cast<const half_t*>(st), reinterpret_cast<const half_t*>(st + KNN_SIDE), acc, lane, wave);
             }
         }
         // ---- selection.  Columns past N (zero rows of the last block) must never be chosen.

@@ -76,8 +76,8 @@ def _precision_of(cfg):
     name = getattr(cfg, "corr_precision", "f32")
     if name in ("f32", "fp32", 0):
         return capi.PREC_F32
-    if name in ("bf16x3", 1):
-        return capi.PREC_BF16X3
+    if name in ("f16x3", "bf16x3", 1):          # "bf16x3": the split mode's former name
+        return capi.PREC_F16X3
     raise ValueError("unknown corr_precision %r" % (name,))
 
 
@@ -143,7 +143,7 @@ class ContrastiveCorrelationLoss(nn.Module):
     """Drop-in for the reference class (modules.py:314-398); same cfg keys:
     feature_samples, neg_samples, pointwise, zero_clamp, stabalize, use_salience,
     pos_intra_shift, pos_inter_shift, neg_inter_shift.  Optional extra key
-    ``corr_precision`` ('f32' default | 'bf16x3')."""
+    ``corr_precision`` ('f32' default | 'f16x3')."""
 
     def __init__(self, cfg, ):
         super(ContrastiveCorrelationLoss, self).__init__()

@@ -58,7 +58,7 @@ def test_library_loaded_is_the_in_tree_hip_extension():
     assert torch.cuda.is_available()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("layout", ["nchw", "cl"])
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_forward_backward_match_reference_golden(name, layout, precision):
@@ -139,7 +139,7 @@ def _full_size_oracle_grads(inputs, perms, cfg):
     return _ORACLE_CACHE["bwd"]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_full_size_cfg2_against_fp64_oracle(precision):
     """BASELINE config 2 (B=32, ViT-S/8 224^2: C=384, 28x28, K=70, S=11, 5 negatives), channels-last."""
     B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5
@@ -189,7 +189,7 @@ def test_cfg4_vitb_shape_against_oracle():
     dict(B=2, C=8, H=3, W=70, K=6, S=4, n_neg=1),       # W > 64: the backward's band (LDS) unsample fallback
     dict(B=2, C=64, H=40, W=40, K=70, S=11, n_neg=2),   # 32 < W <= 64: 4 pixel tiles per row in the unsample kernel
 ])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_edge_shapes(shape, precision):
     d = O.synth_inputs(seed=5, **shape)
     cfg = O.CorrCfg(feature_samples=shape["S"], neg_samples=shape["n_neg"])

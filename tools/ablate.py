@@ -37,7 +37,7 @@ def main():
                     ts += k0; tm += m; tf += f; n += 1
         return ts / n * 1e3, tm / n * 1e3, tf / n * 1e3
 
-    for prec, pname in ((capi.PREC_F32, "f32"), (capi.PREC_BF16X3, "bf16x3")):
+    for prec, pname in ((capi.PREC_F32, "f32"), (capi.PREC_BF16X3, "f16x3")):
         for variant in (0, 1):
             if variant == 0 and prec != capi.PREC_F32:
                 continue

@@ -52,7 +52,7 @@ def main():
     agree = float((idx[:args.cpu_rows].cpu()[:, :5] == ref[:, :5]).float().mean())
     rec = {"metric": "KNN precompute: query rows/s, all-pairs cosine top-%d over N=%d x D=%d" % (args.k, args.n, args.d),
            "value": args.n / (ms * 1e-3), "unit": "rows/s", "ms_total": ms, "n_gpus": 1,
-           "dtype": "bf16x3-split (f32 accumulate)", "data": "synthetic (256 clusters)",
+           "dtype": "f16x3-split (f32 accumulate)", "data": "synthetic (256 clusters)",
            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 2500.0 / 3, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / (2500.0 / 3), "algorithmic_flops": flops},
            "cpu_baseline": {"value": args.cpu_rows / best[0], "unit": "rows/s", "cores": best[1], "kind": "reference",

@@ -30,8 +30,8 @@ if has bench; then
   echo "== bench" | tee -a $OUT/summary.txt
   timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
   cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -3 $OUT/bench.err | tee -a $OUT/summary.txt
-  timeout 300 python bench.py --steps 200 --warmup 20 --precision bf16x3 --no-cpu-baseline > $OUT/bench_bf16x3.json 2>> $OUT/bench.err
-  cat $OUT/bench_bf16x3.json | tee -a $OUT/summary.txt
+  timeout 300 python bench.py --steps 200 --warmup 20 --precision f16x3 --no-cpu-baseline > $OUT/bench_f16x3.json 2>> $OUT/bench.err
+  cat $OUT/bench_f16x3.json | tee -a $OUT/summary.txt
   timeout 300 python bench.py --steps 200 --warmup 20 --fwd-only --no-cpu-baseline > $OUT/bench_fwd.json 2>> $OUT/bench.err
   cat $OUT/bench_fwd.json | tee -a $OUT/summary.txt
 fi
