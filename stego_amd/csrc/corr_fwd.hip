@@ -44,23 +44,16 @@ constexpr int SM_TILES_BYTES = 2 * TP * LDT * 4;  // epilogue: fd + cd tiles
 // One staged chunk of the contraction on v_mfma_f32_32x32x2_f32.  Wave (wr,wc) owns the
 // 64x64 quadrant; lanes 0-31 take k = kk..kk+3, lanes 32-63 k = kk+4..kk+7 of every 8-wide
 // k group via one ds_read_b128 per operand (any k permutation is fine as long as A and B agree).
-// `pre(s)` is called before the MFMAs of 8-wide k group s: the caller issues a slice of the NEXT chunk's loads
-// there.  (Issuing all ~45 loads of a chunk back to back stalls the wave at issue until the first ones return -
-// the per-wave memory queue is shallow - which cost 8 us per tile; one slice per 16 MFMAs never fills it.)
-template <class F>
 __device__ __forceinline__ void mma_chunk_f32(const float* __restrict__ As, const float* __restrict__ Bs,
-                                              f32x16 (&acc)[2][2], int lane, int wr, int wc, F&& pre)
+                                              f32x16 (&acc)[2][2], int lane, int wr, int wc)
 {
     const int r = lane & 31, half = lane >> 5;
     const float* a0p = As + (64 * wr + r) * LDA + 4 * half;
     const float* a1p = a0p + 32 * LDA;
     const float* b0p = Bs + (64 * wc + r) * LDA + 4 * half;
     const float* b1p = b0p + 32 * LDA;
-#pragma unroll
-    for (int st = 0; st < KC / 8; ++st) {
-        pre(st);
-        __builtin_amdgcn_sched_barrier(0);        // keep each slice of loads in front of its own MFMA group
-        const int kk = 8 * st;             // always the full 64 channels: both operand images are zero-padded
+#pragma unroll 2
+    for (int kk = 0; kk < KC; kk += 8) {       // always the full 64 channels: both operand images are zero-padded
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + kk);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + kk);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + kk);
@@ -102,9 +95,8 @@ __device__ __forceinline__ void mma_code_f32(const float* __restrict__ As, const
 // Split-fp16 contraction of one chunk: a.b ~= ah.bh + ah.bl + al.bh (the al.bl term is < 2^-22).
 // Stage layout: hi[128][LDH] then lo[128][LDH] (fp16).  Each lane reads 8 consecutive k
 // (lanes 0-31: kk..kk+7, lanes 32-63: kk+8..kk+15) per operand with one ds_read_b128.
-template <class F>
 __device__ __forceinline__ void mma_chunk_f16x3(const half_t* __restrict__ As, const half_t* __restrict__ Bs,
-                                                 f32x16 (&acc)[2][2], int lane, int wr, int wc, F&& pre)
+                                                f32x16 (&acc)[2][2], int lane, int wr, int wc)
 {
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
@@ -112,30 +104,25 @@ __device__ __forceinline__ void mma_chunk_f16x3(const half_t* __restrict__ As, c
     const half_t* a1p = a0p + 32 * LDH;
     const half_t* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
     const half_t* b1p = b0p + 32 * LDH;
-#pragma unroll
-    for (int st = 0; st < KC / 8; ++st) {         // 8 slots like the f32 version: MFMAs on the even ones
-        pre(st);
-        __builtin_amdgcn_sched_barrier(0);
-        const int kk = 8 * st;
-        if ((st & 1) == 0) {
-            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(a0p + kk), al0 = *reinterpret_cast<const f16x8*>(a0p + LO + kk);
-            const f16x8 ah1 = *reinterpret_cast<const f16x8*>(a1p + kk), al1 = *reinterpret_cast<const f16x8*>(a1p + LO + kk);
-            const f16x8 bh0 = *reinterpret_cast<const f16x8*>(b0p + kk), bl0 = *reinterpret_cast<const f16x8*>(b0p + LO + kk);
-            const f16x8 bh1 = *reinterpret_cast<const f16x8*>(b1p + kk), bl1 = *reinterpret_cast<const f16x8*>(b1p + LO + kk);
-            // small cross terms first, then the leading term; accumulators interleaved
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
-        }
+#pragma unroll 2
+    for (int kk = 0; kk < KC; kk += 16) {
+        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(a0p + kk), al0 = *reinterpret_cast<const f16x8*>(a0p + LO + kk);
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(a1p + kk), al1 = *reinterpret_cast<const f16x8*>(a1p + LO + kk);
+        const f16x8 bh0 = *reinterpret_cast<const f16x8*>(b0p + kk), bl0 = *reinterpret_cast<const f16x8*>(b0p + LO + kk);
+        const f16x8 bh1 = *reinterpret_cast<const f16x8*>(b1p + kk), bl1 = *reinterpret_cast<const f16x8*>(b1p + LO + kk);
+        // small cross terms first, then the leading term; accumulators interleaved
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
     }
 }
 
@@ -164,17 +151,19 @@ template <int V> struct GatherRegs {
     static constexpr int SLOTS = KC / V;
     static constexpr int ITEMS = TP * SLOTS / NTHREADS;
     static constexpr int PPI = NTHREADS / SLOTS;
-    vec tv[ITEMS][4];
+    vec tv[ITEMS][4];               // the 4 taps of every item of one chunk (two of these are alive: chunk t+1, t+2)
+};
+template <int V> struct GatherOffs {
     // V == 4: byte offset of (point, tap, this lane's channel slot) inside a chunk of the image, kept in registers
     // (SGPR base + 32-bit lane offset loads, no address arithmetic in the MFMA stream).  The generic V == 1 path
     // has 4x the items and re-reads the tap table from LDS instead.
-    unsigned off[V == 4 ? ITEMS : 1][4];
+    unsigned off[V == 4 ? GatherRegs<V>::ITEMS : 1][4];
 };
 
 // items [j0, j0 + n): loads.  `chunk` = image + c0 * channel_stride (wave-uniform): SGPR base + 32-bit lane offset.
 template <int V>
-__device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const float* __restrict__ chunk, const int4* __restrict__ tapo,
-                                             int lane_off, int prow, int j0, int n)
+__device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const GatherOffs<V>& go, const float* __restrict__ chunk,
+                                             const int4* __restrict__ tapo, int lane_off, int prow, int j0, int n)
 {
     typedef typename VecT<V>::type vec;
     const char* cb = reinterpret_cast<const char*>(chunk);
@@ -183,7 +172,7 @@ __device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const float* __re
         const int j = j0 + i;
         if constexpr (V == 4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g.tv[j][k] = *reinterpret_cast<const vec*>(cb + g.off[j][k]);
+            for (int k = 0; k < 4; ++k) g.tv[j][k] = *reinterpret_cast<const vec*>(cb + go.off[j][k]);
         } else {
             const int4 o = tapo[j * GatherRegs<V>::PPI + prow];
             const float* b = chunk + lane_off;
@@ -278,7 +267,7 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
     const int B = prm.B, P = prm.P;
     float fd_part = 0.f;
     {
-        const int row = tid >> 1, half = tid & 1;
+        const int row = tid >> 1, half = tid & 1;          // threads 0..255; any further waves idle here
         const int hl = (P + 1) >> 1;
         float s0 = 0.f, s1 = 0.f;
         if (row < P) {
@@ -293,6 +282,7 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
         if (half == 0) {
             fd_part = sfull;
             if (row < TP) rowmean[row] = prm.pointwise ? sfull / (float)P : 0.f;    // fd.mean([3,4]) (modules.py:332)
+            else fd_part = 0.f;
         }
     }
     __syncthreads();
@@ -303,7 +293,7 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
     float loss_part = 0.f, clamp_part = 0.f;
     if (!(prm.debug & 8)) {
         const int nvec = (a + P2 + 3) >> 2;
-        for (int v = tid; v < nvec; v += NTHREADS) {
+        for (int v = tid; v < nvec; v += (int)blockDim.x) {
             const int f0 = 4 * v;
             const f32x4 fd4 = *reinterpret_cast<const f32x4*>(Tfd + f0);
             const f32x4 cd4 = *reinterpret_cast<const f32x4*>(Tcd + f0);
@@ -351,10 +341,9 @@ __device__ __forceinline__ void tile_epilogue_flat(const CorrParams& prm, const 
     __syncthreads();
     if (tid == 0) {
         float* st = prm.stats + ((size_t)p * B + b) * 4;
-        st[0] = (red[0] + red[3]) + (red[6] + red[9]);
-        st[1] = (red[1] + red[4]) + (red[7] + red[10]);
-        st[2] = (red[2] + red[5]) + (red[8] + red[11]);
-        st[3] = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += red[w * 3]; s1 += red[w * 3 + 1]; s2 += red[w * 3 + 2]; }
+        st[0] = s0; st[1] = s1; st[2] = s2; st[3] = 0.f;
     }
 }
 
@@ -368,8 +357,10 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2])
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 }
 
+constexpr int TILE_THREADS = 2 * NTHREADS;        // waves 0-3: MFMA team, waves 4-7: gather team
+
 template <int PREC, int V>
-__global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams prm, const int stage_bytes)
+__global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParams prm, const int stage_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* rowmean = reinterpret_cast<float*>(smem + SD_ROWMEAN);
@@ -383,7 +374,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
     constexpr int FSIDE = PREC == PREC_F32 ? FEAT_SIDE_F32 : FEAT_SIDE_F16;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mfma_team = wave8 < 4;            // wave-uniform role
+    const int wave = wave8 & 3;
+    const int gt = tid & (NTHREADS - 1);         // index inside the 256-thread team
     const int wr = wave >> 1, wc = wave & 1;
     const int B = prm.B;
     const int tile = blockIdx.x;
@@ -421,35 +415,8 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
     if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();                              // tap table visible
 
-    GatherRegs<V> greg;
-    constexpr int ITEMS = GatherRegs<V>::ITEMS, HALF = (KC / 8) / 2, IPS = ITEMS / HALF;      // items per k-group slice
-    static_assert(ITEMS % HALF == 0, "items must split over half of the k groups");
-    float ss[ITEMS];
-    const int gslot = tid % GatherRegs<V>::SLOTS, gprow = tid / GatherRegs<V>::SLOTS;
-    const int lane_off = gslot * V * scB;                             // this lane's channel slot inside a chunk
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        ss[j] = 0.f;
-        if constexpr (V == 4) {
-            const int4 o = tapo[j * GatherRegs<V>::PPI + gprow];
-            greg.off[j][0] = (unsigned)(o.x + lane_off) * 4u;
-            greg.off[j][1] = (unsigned)(o.y + lane_off) * 4u;
-            greg.off[j][2] = (unsigned)(o.z + lane_off) * 4u;
-            greg.off[j][3] = (unsigned)(o.w + lane_off) * 4u;
-        }
-    }
     const bool gatherB = !sameAB;
-    // Channels beyond C exist only in the generic path (V == 1, the host takes V == 4 only when C % 64 == 0): such a
-    // lane re-reads the last channel and its values are zeroed at commit.
-    // (the prefetch one chunk past the end re-reads the last chunk)
-    auto chunk_ptr = [&](int t) { return V == 4 ? imgB + (long long)min(t * KC, prm.C - KC) * scB : imgB; };
-    auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(t * KC + gslot, prm.C - 1) * scB; };
-    auto chunk_ok = [&](int t) { return V == 4 || t * KC + gslot < prm.C; };
-
-    // all async copies of stage t (A features / both code operands), issued in one go: a ds_read that follows a
-    // global_load_lds makes the compiler wait for vmcnt(0) (it cannot prove the LDS addresses differ), so they
-    // must not sit between MFMA groups
-    auto copies = [&](int t) {
+    auto copies = [&](int t) {                    // async LDS copies of stage t: A features / both code operands
         unsigned char* dst = stage + (t & 1) * stage_bytes;
         if (t < NCH) {
             issue_copy(fsA + (size_t)t * FSIDE, dst, FSIDE / 1024, wave, lane);
@@ -459,53 +426,85 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
         }
     };
 
-    f32x16 accf[2][2];
-    zero_acc(accf);
-    copies(0);
-    if (gatherB) {
-        gather_issue<V>(greg, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
-        gather_commit<V, PREC>(greg, tapw, chunk_ok(0), stage + FSIDE, ss, gslot, gprow, 0, ITEMS);
-    }
-    for (int t = 0; t < NCH; ++t) {              // feature chunks
-        __syncthreads();                         // (waits vmcnt(0)) stage t has landed; everyone is done with stage t-1
-        copies(t + 1);                           // stage NCH = the code operands
-        const unsigned char* Ab = stage + (t & 1) * stage_bytes;
-        // The taps of chunk t+1 are loaded UNCONDITIONALLY (branch-free MFMA stream): tiles without a gathered
-        // side and the last chunk re-read valid addresses; only the commit is conditional.
-        const float* nxt = chunk_ptr(t + 1);
-        const int nxt_off = lane_ofs(t + 1);
-        const bool commit = t + 1 < NCH && gatherB;
-        const bool ok = chunk_ok(t + 1);
-        void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
-        auto pre = [&](int st) {
-            if (st < HALF) gather_issue<V>(greg, nxt, tapo, nxt_off, gprow, st * IPS, IPS);
-            else if (commit) gather_commit<V, PREC>(greg, tapw, ok, dstB, ss, gslot, gprow, (st - HALF) * IPS, IPS);
-        };
-        const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
-        if constexpr (PREC == PREC_F32)
-            mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc, pre);
-        else
-            mma_chunk_f16x3(reinterpret_cast<const half_t*>(Ab), reinterpret_cast<const half_t*>(Bb), accf, lane, wr, wc, pre);
-    }
-    // ---- the code correlation: one stage, exact f32 (its accumulators only live from here on)
-    f32x16 accc[2][2];
-    zero_acc(accc);
-    __syncthreads();
-    {
+    f32x16 accf[2][2], accc[2][2];
+    if (mfma_team) {
+        // ================================================================= MFMA team
+        zero_acc(accf);
+        copies(0);
+        for (int t = 0; t < NCH; ++t) {
+            __syncthreads();                     // B1(t): stage t complete (copies: vmcnt(0); gathered B: written before)
+            copies(t + 1);                       // stage NCH = the code operands
+            const unsigned char* Ab = stage + (t & 1) * stage_bytes;
+            const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
+            if constexpr (PREC == PREC_F32)
+                mma_chunk_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), accf, lane, wr, wc);
+            else
+                mma_chunk_f16x3(reinterpret_cast<const half_t*>(Ab), reinterpret_cast<const half_t*>(Bb), accf, lane, wr, wc);
+        }
+        zero_acc(accc);
+        __syncthreads();                         // B1(NCH): code stage landed
         const unsigned char* Ab = stage + (NCH & 1) * stage_bytes;
         const unsigned char* Bb = sameAB ? Ab : Ab + cside;
         mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);
-    }
-    // ---- 1 / ||b_j|| of the gathered side (F.normalize eps, modules.py:276); the anchor side is pre-normalised
-    {
-        constexpr int SLOTS = GatherRegs<V>::SLOTS, PPI = GatherRegs<V>::PPI;
-        const int slot = gslot, prow = gprow;
+    } else {
+        // ================================================================= gather team
+        // Rolling pipeline over the items (point group x channel slot) of the B operand: while the MFMA team
+        // multiplies chunk t, item j of chunk t+1 (loaded one chunk time ago) is blended into the free stage buffer
+        // and its registers immediately take the taps of item j of chunk t+2.  In split-fp16 mode the MFMAs run on
+        // the matrix cores, so this VALU / memory work genuinely overlaps them (in f32 mode the fp32 MFMA owns the
+        // VALU and the two teams time-slice: no worse than doing it in one wave).
+        GatherRegs<V> g;
+        GatherOffs<V> goff;
+        constexpr int ITEMS = GatherRegs<V>::ITEMS;
+        float ss[ITEMS];
+        const int gslot = gt % GatherRegs<V>::SLOTS, gprow = gt / GatherRegs<V>::SLOTS;
+        const int lane_off = gslot * V * scB;                         // this lane's channel slot inside a chunk
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            float s = ss[j];
+            ss[j] = 0.f;
+            if constexpr (V == 4) {
+                const int4 o = tapo[j * GatherRegs<V>::PPI + gprow];
+                goff.off[j][0] = (unsigned)(o.x + lane_off) * 4u;
+                goff.off[j][1] = (unsigned)(o.y + lane_off) * 4u;
+                goff.off[j][2] = (unsigned)(o.z + lane_off) * 4u;
+                goff.off[j][3] = (unsigned)(o.w + lane_off) * 4u;
+            }
+        }
+        // Channels beyond C exist only in the generic path (V == 1, the host takes V == 4 only when C % 64 == 0):
+        // such a lane re-reads the last channel and its values are zeroed at commit.  Prefetches past the last
+        // chunk re-read it and are never committed.
+        auto chunk_ptr = [&](int t) { return V == 4 ? imgB + (long long)min(t * KC, prm.C - KC) * scB : imgB; };
+        auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(t * KC + gslot, prm.C - 1) * scB; };
+        auto chunk_ok = [&](int t) { return V == 4 || t * KC + gslot < prm.C; };
+        if (gatherB) {
+            gather_issue<V>(g, goff, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
+            gather_commit<V, PREC>(g, tapw, chunk_ok(0), stage + FSIDE, ss, gslot, gprow, 0, ITEMS);
+            gather_issue<V>(g, goff, chunk_ptr(1), tapo, lane_ofs(1), gprow, 0, ITEMS);
+        }
+        for (int t = 0; t < NCH; ++t) {
+            __syncthreads();                     // B1(t): the MFMA team is done with stage t-1 = the buffer written next
+            if (gatherB && t + 1 < NCH) {
+                const float* nxt = chunk_ptr(t + 2);
+                const int nxt_off = lane_ofs(t + 2);
+                const bool ok = chunk_ok(t + 1);
+                void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
 #pragma unroll
-            for (int m = SLOTS / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            if (slot == 0) csc[j * PPI + prow] = sameAB ? 1.f : (PREC == PREC_F16X3 ? 1.f / B_RAW_SCALE : 1.f) / fmaxf(sqrtf(s), 1e-10f);
+                for (int j = 0; j < ITEMS; ++j) {
+                    gather_commit<V, PREC>(g, tapw, ok, dstB, ss, gslot, gprow, j, 1);
+                    gather_issue<V>(g, goff, nxt, tapo, nxt_off, gprow, j, 1);
+                }
+            }
+        }
+        __syncthreads();                         // B1(NCH)
+        // ---- 1 / ||b_j|| of the gathered side (F.normalize eps, modules.py:276); the anchor side is pre-normalised
+        constexpr int SLOTS = GatherRegs<V>::SLOTS, PPI = GatherRegs<V>::PPI;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            float sq = ss[j];
+#pragma unroll
+            for (int m = SLOTS / 2; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+            if (gslot == 0)
+                csc[j * PPI + gprow] = sameAB ? 1.f : (PREC == PREC_F16X3 ? 1.f / B_RAW_SCALE : 1.f) / fmaxf(sqrtf(sq), 1e-10f);
         }
     }
 
@@ -528,8 +527,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_tile_kernel(const CorrParams pr
                         (!w_out || (int)((reinterpret_cast<uintptr_t>(w_out) >> 2) & 3) == a);
     __syncthreads();                             // stage buffers are dead, csc complete: park the result tiles
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
-    park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
-    park_flat(accc, Tcd + a, P, nullptr, lane, wr, wc);
+    if (mfma_team) {
+        park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
+        park_flat(accc, Tcd + a, P, nullptr, lane, wr, wc);
+    }
     __syncthreads();
     if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
     tile_epilogue_flat(prm, Tfd, Tcd, rowmean, red, p, b, direct, a, cd_out, loss_out, w_out, shift, vec_ok);
@@ -644,7 +645,7 @@ hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t st
         if (e != hipSuccess) return e;
         have[which] = lds;
     }
-    const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
+    const dim3 grid(prm.n_sets * prm.B), block(TILE_THREADS);
     switch (which) {
         case 0: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 4>), grid, block, lds, stream, prm, stage); break;
         case 1: hipLaunchKernelGGL((corr_tile_kernel<PREC_F32, 1>), grid, block, lds, stream, prm, stage); break;
