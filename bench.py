@@ -44,7 +44,7 @@ class Cfg:
     pos_intra_weight = 0.67
     pos_inter_weight = 0.25
     neg_inter_weight = 0.63
-    corr_precision = "f32"
+    corr_precision = "f16x3"
 
 
 WORKLOADS = {
@@ -161,7 +161,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (B)")
     ap.add_argument("--workload", default="vits8_224", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="contraction arithmetic of the feature correlation: f16x3 = fp16 hi+lo split products on the matrix "
+                         "cores with f32 accumulation (22-bit products; measured error equals the f32 path); f32 = "
+                         "v_mfma_f32 (runs at the VALU rate on gfx950)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other precision mode")
     ap.add_argument("--sets", type=int, default=4, help="input sets rotated (4 x 91 MB > 256 MB Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,79 +191,90 @@ def main():
     cfg.corr_precision = args.precision
     C, H, W, K = WORKLOADS[args.workload]
     B, S, n_neg = args.batch, cfg.feature_samples, cfg.neg_samples
-    prec = capi.PREC_F32 if args.precision == "f32" else capi.PREC_F16X3
-    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
-                          prec)
     sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
     # upstream gradients exactly as train_segmentation.py:169-181 produces them
     g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
     g_inter = torch.tensor(cfg.pos_inter_weight, device=dev)
     g_neg = torch.full((1,), cfg.neg_inter_weight / (n_neg * B * S ** 4), device=dev).expand(n_neg * B, S, S, S, S)
     grad_buf = torch.zeros(head_grad_numel(C, K), device=dev)     # flat head-gradient bucket (DDP)
-    keep = [None] * args.sets
-
     from stego_amd.modules import as_channels_last      # the host-side layout policy of the op (no-op for cl views)
-
-    def step_compute(i):
-        d = sets[i]
-        need_grad = not args.fwd_only
-        out = capi.corr_fwd(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
-                            as_channels_last(d["code"]), as_channels_last(d["code_pos"]), d["coords1"], d["coords2"],
-                            d["perms"], need_grad)
-        if need_grad:
-            lm, icd, ecd, nl, ncd, saved = out
-            grads = capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved,
-                                  icd, ecd, ncd, g_intra, g_inter, g_neg, None, None, None)
-            keep[i] = (out, grads)
-        else:
-            keep[i] = (out,)
-
-    for i in range(args.sets):          # eager warm-up (also sets kernel attributes before any capture)
-        step_compute(i)
-    torch.cuda.synchronize()
-
-    graphs = None
-    launch = "eager"
-    if not args.no_graph:
-        try:
-            graphs = []
-            for i in range(args.sets):
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
-                    step_compute(i)
-                graphs.append(gr)
-            launch = "hipgraph"
-        except Exception as e:      # noqa: BLE001 - fall back to eager launches, say so in the output
-            graphs = None
-            launch = "eager (graph capture failed: %s)" % type(e).__name__
-            torch.cuda.synchronize()
-
-    def step(k):
-        i = k % args.sets
-        if graphs is not None:
-            graphs[i].replay()
-        else:
-            step_compute(i)
-        if dist is not None:
-            dist.all_reduce(grad_buf)               # gradients of the segmentation head only (backbone frozen)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run(precision, steps, warmup):
+        """W untimed + K timed steps of the whole job in one precision mode; returns (seconds, launch mode, desc)."""
+        prec = capi.PREC_F32 if precision == "f32" else capi.PREC_F16X3
+        desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
+                              prec)
+        keep = [None] * args.sets
+
+        def step_compute(i):
+            d = sets[i]
+            need_grad = not args.fwd_only
+            out = capi.corr_fwd(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
+                                as_channels_last(d["code"]), as_channels_last(d["code_pos"]), d["coords1"], d["coords2"],
+                                d["perms"], need_grad)
+            if need_grad:
+                lm, icd, ecd, nl, ncd, saved = out
+                grads = capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved,
+                                      icd, ecd, ncd, g_intra, g_inter, g_neg, None, None, None)
+                keep[i] = (out, grads)
+            else:
+                keep[i] = (out,)
+
+        for i in range(args.sets):          # eager warm-up (also sets kernel attributes before any capture)
+            step_compute(i)
+        torch.cuda.synchronize()
+        graphs = None
+        launch = "eager"
+        if not args.no_graph:
+            try:
+                graphs = []
+                for i in range(args.sets):
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        step_compute(i)
+                    graphs.append(gr)
+                launch = "hipgraph"
+            except Exception as e:      # noqa: BLE001 - fall back to eager launches, say so in the output
+                graphs = None
+                launch = "eager (graph capture failed: %s)" % type(e).__name__
+                torch.cuda.synchronize()
+
+        def step(k):
+            i = k % args.sets
+            if graphs is not None:
+                graphs[i].replay()
+            else:
+                step_compute(i)
+            if dist is not None:
+                dist.all_reduce(grad_buf)               # gradients of the segmentation head only (backbone frozen)
+
+        for k in range(warmup):
+            step(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, launch, desc
+
+    dt, launch, desc = timed_run(args.precision, args.steps, args.warmup)
+    alt = None
+    if not args.no_alt:                     # the other arithmetic mode, shorter, for the record (all ranks take part)
+        other = "f32" if args.precision == "f16x3" else "f16x3"
+        steps_alt = max(20, args.steps // 4)
+        dt_alt, _, _ = timed_run(other, steps_alt, max(4, args.warmup // 4))
+        alt = {"precision": other, "value": world * B * steps_alt / dt_alt, "unit": "image-pairs/s",
+               "ms_per_step": dt_alt / steps_alt * 1e3, "steps": steps_alt}
 
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
     roof = roof_mfma = None
@@ -326,7 +341,8 @@ def main():
             "metric": "image-pairs/sec through correspondence loss, B=32 224^2, ViT-S/8",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3-split (fp16 hi+lo operands, 3 MFMAs, f32 accumulate)",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3 (f32 inputs/outputs/accumulate; feature products as fp16 hi+lo splits, "
+                                                                   "22-bit, on the matrix cores; code correlation and backward exact f32)",
             "data": "synthetic",
             "config": {"workload": "%s: B=%d/GPU, C=%d, %dx%d map, K=%d, S=%d, %d negatives, self+KNN+random "
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,
@@ -334,7 +350,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
                        "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
-            "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us,
+            "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,
         }
         print(json.dumps(rec))

@@ -73,7 +73,7 @@ _backend = capi      # tests may swap this for an oracle-backed double to exerci
 
 
 def _precision_of(cfg):
-    name = getattr(cfg, "corr_precision", "f32")
+    name = getattr(cfg, "corr_precision", "f16x3")
     if name in ("f32", "fp32", 0):
         return capi.PREC_F32
     if name in ("f16x3", "bf16x3", 1):          # "bf16x3": the split mode's former name
@@ -143,7 +143,7 @@ class ContrastiveCorrelationLoss(nn.Module):
     """Drop-in for the reference class (modules.py:314-398); same cfg keys:
     feature_samples, neg_samples, pointwise, zero_clamp, stabalize, use_salience,
     pos_intra_shift, pos_inter_shift, neg_inter_shift.  Optional extra key
-    ``corr_precision`` ('f32' default | 'f16x3')."""
+    ``corr_precision`` ('f16x3' default | 'f32')."""
 
     def __init__(self, cfg, ):
         super(ContrastiveCorrelationLoss, self).__init__()

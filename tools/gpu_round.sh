@@ -30,14 +30,14 @@ if has bench; then
   echo "== bench" | tee -a $OUT/summary.txt
   timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
   cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -3 $OUT/bench.err | tee -a $OUT/summary.txt
-  timeout 300 python bench.py --steps 200 --warmup 20 --precision f16x3 --no-cpu-baseline > $OUT/bench_f16x3.json 2>> $OUT/bench.err
-  cat $OUT/bench_f16x3.json | tee -a $OUT/summary.txt
-  timeout 300 python bench.py --steps 200 --warmup 20 --fwd-only --no-cpu-baseline > $OUT/bench_fwd.json 2>> $OUT/bench.err
+  timeout 300 python bench.py --steps 200 --warmup 20 --precision f32 --no-cpu-baseline --no-alt > $OUT/bench_f32.json 2>> $OUT/bench.err
+  cat $OUT/bench_f32.json | tee -a $OUT/summary.txt
+  timeout 300 python bench.py --steps 200 --warmup 20 --fwd-only --no-cpu-baseline --no-alt > $OUT/bench_fwd.json 2>> $OUT/bench.err
   cat $OUT/bench_fwd.json | tee -a $OUT/summary.txt
 fi
 if has prof; then
   echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-graph > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-graph --no-alt > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" | tee -a $OUT/summary.txt
   python tools/rocpd_stats.py $OUT/prof/bench_results.db 2>&1 | head -12 | tee -a $OUT/summary.txt
 fi
 if has pmc; then
@@ -45,7 +45,7 @@ if has pmc; then
   rocprofv3 -L > $OUT/counters_list.txt 2>&1
   for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     NAME=$(echo $CNT | tr ' ' '_' | cut -c1-40)
-    timeout 300 rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_$NAME -o pmc -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/pmc_$NAME.err; echo "pmc $CNT rc=$?" | tee -a $OUT/summary.txt
+    timeout 300 rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_$NAME -o pmc -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-graph --no-alt > /dev/null 2> $OUT/pmc_$NAME.err; echo "pmc $CNT rc=$?" | tee -a $OUT/summary.txt
     python tools/rocpd_stats.py $OUT/pmc_$NAME/pmc_results.db 2>&1 | grep -E "counter|corr_|sample_norm|knn_" | tee -a $OUT/summary.txt
     rm -f $OUT/pmc_$NAME/pmc_results.db.keep
   done
