@@ -21,6 +21,7 @@
 //                      one-lane shift - registers only, no LDS, no atomics, deterministic.
 //   knn_merge_kernel - merges the per-slice lists of a row (k-way, by repeated arg-max over the list heads).
 // Ties: torch.topk leaves the order of equal values unspecified; so does this.
+#include <cstdlib>
 #include "corr_common.h"
 
 namespace stego {
@@ -40,6 +41,7 @@ struct KnnParams {
     int D, NCH, k, normalize;
     long long q_begin, q_count; // query rows [q_begin, q_begin + q_count)
     int nblk, NS, tiles_per_slice;
+    int debug;                  // STEGO_DEBUG_KNN: 1 skip the selection, 2 skip the MFMAs (measurement only)
 };
 
 // ---------------------------------------------------------------------------------------------- prep
@@ -137,6 +139,11 @@ __device__ __forceinline__ void knn_mma_chunk_areg(const f16x8 (&ah)[KC / 16], c
 
 constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 192 VGPRs
 
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // grid = (query blocks, NS); block = 256.  AREG: LDS = 2 stages x B chunk, A in registers (D <= 384);
 // otherwise 2 stages x (A chunk + B chunk).
 template <bool AREG>
@@ -158,7 +165,8 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
     int li[16];
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) { lv[rr] = -INFINITY; li[rr] = -1; }
-    const int slot = lane & 31, hbase = lane & 32;
+    const int slot = lane & 31;
+    const bool upper = lane >= 32;
 
     const int nstage = (tile1 - tile0) * NCH;
     constexpr int STAGE = AREG ? KNN_SIDE : 2 * KNN_SIDE;
@@ -195,7 +203,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
                 if (c < NCH) {
                     __syncthreads();                      // stage g landed (vmcnt(0)); stage g-1 is free
                     if (g + 1 < nstage) issue(g + 1);
-                    knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const half_t*>(smem + (g & 1) * STAGE), acc, lane);
+                    if (!(prm.debug & 2)) knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const half_t*>(smem + (g & 1) * STAGE), acc, lane);
                     ++g;
                 }
             }
@@ -208,42 +216,45 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
             }
         }
         // ---- selection.  Columns past N (zero rows of the last block) must never be chosen.
+        if (prm.debug & 1) { lv[0] += acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3]; continue; }
         const long long col0 = (long long)t * TP;
-        if (col0 + TP > prm.N) {
+        bool cv[4];                                    // column of this lane in block ni exists (only the last tile has holes)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                if (col0 + 32 * ni + slot >= prm.N) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[ni][e] = -INFINITY;
-                }
-        }
+        for (int ni = 0; ni < 4; ++ni) cv[ni] = col0 + 32 * ni + slot < prm.N;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-            const float thr = __shfl(lv[rr], hbase + k - 1, 64);           // current k-th best of my row
-            const bool anyc = acc[0][rr] > thr || acc[1][rr] > thr || acc[2][rr] > thr || acc[3][rr] > thr;
-            if (__ballot(anyc) == 0ull) continue;                          // the common case
+            // everything wave-uniform goes through SGPRs (v_readlane / s_ff1 / s_bcnt1): the first version used
+            // ds_bpermute shuffles here and the selection cost more than the MFMAs (32 of 55 ms at N = 100 k)
+            float thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);      // current k-th best of my row
+            const bool any4 = (cv[0] && acc[0][rr] > thr) || (cv[1] && acc[1][rr] > thr) || (cv[2] && acc[2][rr] > thr) ||
+                              (cv[3] && acc[3][rr] > thr);
+            if (__ballot(any4) == 0ull) continue;                          // the common case
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                for (;;) {
-                    const float th = __shfl(lv[rr], hbase + k - 1, 64);
-                    const bool cand = acc[ni][rr] > th;
-                    const unsigned long long m = __ballot(cand);
-                    if (m == 0ull) break;
-                    const unsigned mh = (unsigned)(m >> hbase);            // candidates of my half (my row)
-                    const bool have = mh != 0u;
-                    const int cl = have ? __builtin_ctz(mh) : 0;           // first candidate lane of my half
-                    const float x = __shfl(acc[ni][rr], hbase + cl, 64);
+                // the accumulators stay READ-ONLY here (consumed candidates are tracked in a scalar mask): writing
+                // -inf into them made every branch join copy all 64 accumulators between AGPRs and VGPRs
+                unsigned long long done = 0ull;
+                unsigned long long m = __ballot(cv[ni] && acc[ni][rr] > thr);
+                while (m != 0ull) {
+                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+                    const int c0 = mlo ? __builtin_ctz(mlo) : 0, c1 = mhi ? __builtin_ctz(mhi) : 0;    // first candidate per half
+                    const float x0 = readlane_f(acc[ni][rr], c0), x1 = readlane_f(acc[ni][rr], 32 + c1);
+                    const bool have = upper ? mhi != 0u : mlo != 0u;
+                    const float x = upper ? x1 : x0;
+                    const int cl = upper ? c1 : c0;
                     const int xi = (int)(col0 + 32 * ni + cl);
+                    // position = number of entries >= x in my half; everything behind it moves down one slot
+                    const unsigned long long ge = __ballot(lv[rr] >= x);
+                    const int pos = upper ? __builtin_popcount((unsigned)(ge >> 32)) : __builtin_popcount((unsigned)ge);
+                    const float upv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lv[rr]), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(0, li[rr], 0x138, 0xf, 0xf, false);         // wave_shr:1
                     if (have) {
-                        // position = number of entries >= x; everything behind it moves down one slot
-                        const unsigned ge = (unsigned)(__ballot(lv[rr] >= x) >> hbase);
-                        const int pos = __builtin_popcount(ge);
-                        const float upv = __shfl_up(lv[rr], 1, 32);
-                        const int upi = __shfl_up(li[rr], 1, 32);
                         if (slot == pos) { lv[rr] = x; li[rr] = xi; }
                         else if (slot > pos) { lv[rr] = upv; li[rr] = upi; }
-                        if (slot == cl) acc[ni][rr] = -INFINITY;           // consumed
                     }
+                    done |= (mlo ? 1ull << c0 : 0ull) | (mhi ? 1ull << (32 + c1) : 0ull);
+                    thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);
+                    m = __ballot(cv[ni] && acc[ni][rr] > thr) & ~done;
                 }
             }
         }
@@ -326,6 +337,10 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     prm.NCH = (D + KC - 1) / KC;
     prm.NS = knn_slices(q_count, prm.nblk);
     prm.tiles_per_slice = (prm.nblk + prm.NS - 1) / prm.NS;
+    {
+        const char* e = getenv("STEGO_DEBUG_KNN");
+        prm.debug = e ? atoi(e) : 0;
+    }
     const long long nq_pad = ((q_count + TP - 1) / TP) * TP;
     unsigned char* w = static_cast<unsigned char*>(ws);
     prm.img = w;
