@@ -3,18 +3,18 @@
 // Two launches, no global atomics, no memsets:
 //
 // 1. corr_bwd_tile_kernel - one workgroup per (pair-set p, image b) tile, same tiling as the forward:
-//      G[hw][ij]  = dL/dcd = g_cd + g_loss * (-(fd_final - shift)) * 1[cmin <= cd <= cmax]   (clamp/mul backward)
+//      G[hw][ij]  = dL/dcd = g_cd + g_loss * (-(fd_final - shift)) * 1[cmin <= cd <= cmax]   (clamp/mul backward;
+//                   fd_final - shift = saved w + old_mean, the clamp mask rides in the LSB of the saved w)
 //      dAn = G . Bn          dBn = G^T . An          (the two bmm adjoints; An/Bn = normalised sampled codes,
 //                                                      re-used from the forward's saved context: no re-gather)
 //      dA  = (dAn - An <An,dAn>) / ||a||             (F.normalize backward), likewise dB
 //    GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32).  Output: per (tile, side) the gradient w.r.t. the RAW
 //    sampled codes, DT[tile][side][128][LDK].
 //
-// 2. corr_unsample_kernel - the adjoint of the bilinear sampling (grid_sampler_2d_backward) and of the
-//    orig_code[perm] gather (index_put, modules.py:385) written as a GATHER: one workgroup owns a band of
-//    rows of one destination image, walks every sample set that reads that image (anchor role: all
-//    pair-sets of the image; negative roles: the (i,b) with perm_i[b] == image), and accumulates the
-//    4-tap contributions in an LDS copy of the band with ds_add_f32; the band is then stored once.
+// 2. corr_unsample_row_kernel - the adjoint of the bilinear sampling (grid_sampler_2d_backward) and of the
+//    orig_code[perm] gather (index_put, modules.py:385) written as a GATHER per destination pixel row, accumulated
+//    in registers as a sparse GEMM on the f32 MFMA (details at the kernel).  corr_unsample_kernel (rows in an LDS
+//    band, worklists, plain LDS read-modify-write) is the general fallback for maps wider than 64 pixels.
 //
 // The first version of this backward scattered with 15 M global fp32 atomics (93 of its 136 us).
 //

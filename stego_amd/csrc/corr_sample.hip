@@ -1,5 +1,6 @@
-// Stage 1 of the forward: bilinear sampling + L2 normalisation of every (role, image) "set"
-// exactly once, written in the LDS-image layout the tile kernel copies with global_load_lds.
+// Stage 1 of the forward: bilinear sampling + L2 normalisation of (i) the ANCHOR features, written as ready-made LDS
+// operand images the tile kernel copies with global_load_lds, and (ii) the CODES of every (role, image) "set", the
+// tap tables and the code norms = the saved context the backward re-uses.
 //
 //   reference: sample() modules.py:287-288 (grid_sample bilinear/border/align_corners) and
 //              norm() :275-276, applied at :369-373 (anchor @coords1, positive @coords2) and
@@ -9,10 +10,11 @@
 // (feats_pos/code_pos[b] @ coords2[b]); role 2+i = negative i (feats/code[perm_i[b]] @ coords2[b]).
 // helper mode: role 0 = (f1,c1), role 1 = (f2,c2), both taken pixel-for-pixel (already sampled).
 //
-// Why a separate pass: in the fused-gather kernel every negative tile pulled its source image into
-// a different XCD's L2 (166 MB of L2 misses for 91 MB of input).  Here the work is placed so that all
-// sets whose SOURCE image is j run on XCD j%8 (blockIdx%8 -> XCD is the observed dispatch order; it
-// only affects speed): each image is fetched from HBM once and re-read from that XCD's L2.
+// Only the anchor features are sampled here: they are the one feature set used by more than one tile (all 2+n_neg
+// tiles of their image).  Every other set feeds exactly one tile, which gathers it straight from the source image
+// (corr_fwd.hip); materialising them (second design) made this kernel HBM-bound at 43 us.
+// Work assignment: block -> (16-point unit, set), unit-major, so that blockIdx % 8 = b % 8 (B % 8 == 0): the 8 units
+// of an anchor set share an XCD L2 (observed dispatch order; it only affects speed).
 //
 // One half-wave (32 lanes) owns one sample point: lane hl holds channels 128*j + 4*hl .. +3, so a
 // wave instruction is two coalesced 512 B runs; the row norm is a 5-step shuffle reduction.
