@@ -210,6 +210,18 @@ int stego_knn_topk(const float* X, int64_t N, int32_t D, int64_t ldx, int32_t k,
                    int64_t q_begin, int64_t q_count, int64_t* out_idx, float* out_sims,
                    void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
+/*
+ * Dense feature correspondence, tensor_correlation() of modules.py:283-284:
+ *   out[n,h,w,i,j] = sum_c a[n,c,h,w] * b[n,c,i,j]        a: [B,C,H1,W1]   b: [B,C,H2,W2]   out: [B,H1,W1,H2,W2] contiguous
+ * normalize != 0 applies norm() (:275-276, F.normalize over C with eps 1e-10) to both maps first, which is how
+ * plot_dino_correspondence.py:39-58 and plot_pr_curves.py:108-121 call it.  Forward only (those callers are
+ * inference); products as fp16 hi+lo splits on the matrix cores, fp32 accumulate (fp32-grade, see STEGO_PREC_F16X3).
+ */
+size_t stego_dense_corr_workspace_bytes(int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2, int32_t W2);
+int stego_dense_corr(const StegoMap* a, const StegoMap* b, int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2,
+                     int32_t W2, int32_t normalize, float* out, void* workspace, size_t workspace_bytes,
+                     stego_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

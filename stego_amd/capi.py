@@ -40,6 +40,8 @@ SIGNATURES = {
     "stego_corr_saved_ctx_bytes": (c_size_t, [_D]),
     "stego_corr_helper_workspace_bytes": (c_size_t, [_D]),
     "stego_corr_helper_saved_ctx_bytes": (c_size_t, [_D]),
+    "stego_dense_corr_workspace_bytes": (c_size_t, [c_int32] * 6),
+    "stego_dense_corr": (c_int32, [_M, _M] + [c_int32] * 7 + [_P, _P, c_size_t, _P]),
     "stego_knn_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32, c_int32, ctypes.c_int64]),
     "stego_knn_topk": (c_int32, [_P, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64,
                                  _P, _P, _P, c_size_t, _P]),
@@ -277,3 +279,24 @@ def knn_topk(x, k=30, normalize=False, q_begin=0, q_count=None, return_sims=Fals
         _check(lib.stego_knn_topk(_ptr(x), N, D, x.stride(0), k, 1 if normalize else 0, q_begin, q_count, _ptr(idx), _ptr(sims),
                                   _ptr(ws), ws.numel(), _stream()))
     return (idx, sims) if return_sims else idx
+
+
+def dense_corr(a, b, normalize=False):
+    """tensor_correlation (reference modules.py:283-284), optionally on norm()'ed maps: a [B,C,H1,W1], b [B,C,H2,W2]
+    (fp32, HIP device, any strides) -> [B,H1,W1,H2,W2].  Forward only."""
+    _require_dev(a, b)
+    if a.dim() != 4 or b.dim() != 4 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("dense_corr expects two 4-D float32 maps")
+    if a.shape[:2] != b.shape[:2]:
+        raise ValueError("dense_corr: batch / channel mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    lib = load()
+    B, C, H1, W1 = a.shape
+    H2, W2 = b.shape[2:]
+    dev = a.device
+    out = torch.empty(B, H1, W1, H2, W2, dtype=torch.float32, device=dev)
+    ws = _empty_bytes(lib.stego_dense_corr_workspace_bytes(B, C, H1, W1, H2, W2), dev)
+    ma, mb = _map(a), _map(b)
+    with torch.cuda.device(dev):
+        _check(lib.stego_dense_corr(byref(ma), byref(mb), B, C, H1, W1, H2, W2, 1 if normalize else 0, _ptr(out), _ptr(ws),
+                                    ws.numel(), _stream()))
+    return out

@@ -10,6 +10,9 @@ namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
+size_t dense_workspace_bytes(int B, int C, int M, int N);
+hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
+                             float* out, void* ws, hipStream_t stream);
 size_t knn_workspace_bytes(long long N, int D, int k, long long q_count);
 hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, int normalize, long long q_begin,
                       long long q_count, long long* out_idx, float* out_val, void* ws, hipStream_t stream);
@@ -394,6 +397,35 @@ int stego_knn_topk(const float* X, int64_t N, int32_t D, int64_t ldx, int32_t k,
     w += (256 - (reinterpret_cast<uintptr_t>(w) & 255)) & 255;                 // (the size includes this slack)
     return hip_rc(launch_knn(X, N, D, ldx, k, normalize ? 1 : 0, q_begin, q_count, reinterpret_cast<long long*>(out_idx),
                              out_sims, w, static_cast<hipStream_t>(stream)));
+}
+
+static int dense_check(int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2, int32_t W2)
+{
+    if (B <= 0 || C <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0) return STEGO_ERR_SHAPE;
+    if ((int64_t)H1 * W1 > (1 << 24) || (int64_t)H2 * W2 > (1 << 24) || B > 65535) return STEGO_ERR_UNSUPPORTED;
+    return STEGO_OK;
+}
+
+size_t stego_dense_corr_workspace_bytes(int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2, int32_t W2)
+{
+    if (dense_check(B, C, H1, W1, H2, W2) != STEGO_OK) return 0;
+    return dense_workspace_bytes(B, C, H1 * W1, H2 * W2);
+}
+
+int stego_dense_corr(const StegoMap* a, const StegoMap* b, int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2,
+                     int32_t W2, int32_t normalize, float* out, void* workspace, size_t workspace_bytes,
+                     stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    int rc = dense_check(B, C, H1, W1, H2, W2);
+    if (rc) return rc;
+    if (!a || !b || !out || !workspace) return STEGO_ERR_NULL;
+    if (workspace_bytes < dense_workspace_bytes(B, C, H1 * W1, H2 * W2)) return STEGO_ERR_WORKSPACE;
+    MapV ma, mb;
+    if ((rc = to_mapv(a, C, H1, W1, &ma))) return rc;
+    if ((rc = to_mapv(b, C, H2, W2, &mb))) return rc;
+    return hip_rc(launch_dense_corr(ma, mb, B, C, H1, W1, H2, W2, normalize ? 1 : 0, out, workspace,
+                                    static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

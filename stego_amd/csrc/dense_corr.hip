@@ -1,0 +1,207 @@
+// Dense feature correspondence  out[n,h,w,i,j] = sum_c a[n,c,h,w] * b[n,c,i,j]  (gfx950).
+//
+//   reference: tensor_correlation() src/modules.py:283-284 = einsum("nchw,ncij->nhwij") - the literal north-star
+//              tensor; used at full map resolution by plot_dino_correspondence.py:39-58 / plot_pr_curves.py:108-121
+//              (optionally on norm()'ed maps, :275-276).  SURVEY.md 8(f) rank 3: the MFMA-bound regime
+//              ([B, 784, 784] per pair at 224^2 / 8).
+//
+// Two launches:
+//   dense_prep_kernel - any-stride [B,C,H,W] map -> per image, per 128-pixel block, per 64-channel chunk an LDS
+//                       operand image [hi|lo][128][72] of fp16 halves (optional L2 normalisation over C, zero padded):
+//                       the same split-fp16 layout the loss and KNN kernels multiply.
+//   dense_tile_kernel - one workgroup per 128x128 output tile of one image: both operands are streamed with
+//                       global_load_lds (double-buffered), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (22-bit
+//                       products, fp32 accumulate), the tile is stored straight from the accumulators (each wave
+//                       instruction writes 128-byte row segments).  Output-write bound at C = 384.
+#include "corr_common.h"
+
+namespace stego {
+
+constexpr int DC_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] fp16
+
+struct DenseParams {
+    MapV a, b;                  // [B,C,H1,W1], [B,C,H2,W2]
+    void* imgA;                 // [B][nbA][NCH][2][128][LDH] fp16
+    void* imgB;
+    float* out;                 // [B][M][N]
+    int B, C, M, N, W1, W2, nbA, nbB, NCH, normalize;
+};
+
+// grid = (B * (nbA + nbB)), block = 256 = 8 half-waves; a half-wave owns 16 of the block's 128 pixel rows, one at a time.
+// Channels-last maps (channel stride 1, 16-byte aligned pixels, C % 4 == 0, C <= 1024): lane hl holds channels
+// 4 hl + 128 j of the row in registers (16-byte loads, one coalesced run per row), the norm is a 5-step shuffle
+// reduction, hi/lo halves go out as 8-byte stores.  Anything else: scalar loads, two passes over the row.
+__global__ void __launch_bounds__(NTHREADS) dense_prep_kernel(const DenseParams prm, const int vec)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hl = lane & 31, hw = tid >> 5;                // half-wave 0..7
+    const int per_img = prm.nbA + prm.nbB;
+    const int n = blockIdx.x / per_img;
+    int blk = blockIdx.x - n * per_img;
+    const bool isB = blk >= prm.nbA;
+    if (isB) blk -= prm.nbA;
+    const MapV m = isB ? prm.b : prm.a;
+    const int P = isB ? prm.N : prm.M, W = isB ? prm.W2 : prm.W1;
+    const int C = prm.C;
+    half_t* base = static_cast<half_t*>(isB ? prm.imgB : prm.imgA) +
+                   ((size_t)n * (isB ? prm.nbB : prm.nbA) + blk) * prm.NCH * (2 * TP * LDH);
+    constexpr int MAXJ = 8;
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 8 + hw;
+        const int pix = blk * TP + rl;
+        const bool rv = pix < P;
+        const int hh = rv ? pix / W : 0, ww = rv ? pix - hh * W : 0;
+        const float* x = m.p + (long long)n * m.sn + (long long)hh * m.sh + (long long)ww * m.sw;
+        if (vec) {
+            f32x4 v[MAXJ];
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = 128 * j + 4 * hl;
+                v[j] = (rv && c < C) ? *reinterpret_cast<const f32x4*>(x + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+            }
+#pragma unroll
+            for (int s2 = 16; s2 >= 1; s2 >>= 1) ss += __shfl_xor(ss, s2, 64);
+            const float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;      // norm(), modules.py:276
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = 128 * j + 4 * hl;
+                if (c < prm.NCH * KC) {                                                  // zero padding up to the chunk end
+                    half_t* dh = base + (size_t)(c >> 6) * (2 * TP * LDH) + rl * LDH + (c & 63);
+                    unsigned h0, l0, h1, l1;
+                    split_f16_pair(v[j][0] * inv, v[j][1] * inv, h0, l0);
+                    split_f16_pair(v[j][2] * inv, v[j][3] * inv, h1, l1);
+                    *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(dh + TP * LDH) = u32x2{l0, l1};
+                }
+            }
+        } else {
+            float ss = 0.f;
+            if (rv) for (int c = hl; c < C; c += 32) { const float t = x[(long long)c * m.sc]; ss += t * t; }
+#pragma unroll
+            for (int s2 = 16; s2 >= 1; s2 >>= 1) ss += __shfl_xor(ss, s2, 64);
+            const float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;
+            for (int c = hl; c < prm.NCH * KC; c += 32) {
+                const float t = (rv && c < C) ? x[(long long)c * m.sc] * inv : 0.f;
+                unsigned h, l;
+                split_f16_pair(t, 0.f, h, l);
+                half_t* dh = base + (size_t)(c >> 6) * (2 * TP * LDH) + rl * LDH + (c & 63);
+                *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dh + TP * LDH) = (unsigned short)(l & 0xffffu);
+            }
+        }
+    }
+}
+
+// grid = (nbB, nbA, B); block = 256 (4 waves, 2x2 quadrants of 64x64); LDS = 2 stages x (A chunk + B chunk)
+__global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nj = blockIdx.x, mi = blockIdx.y, n = blockIdx.z;
+    const int NCH = prm.NCH;
+    const unsigned char* A = static_cast<const unsigned char*>(prm.imgA) + ((size_t)n * prm.nbA + mi) * NCH * DC_SIDE;
+    const unsigned char* Bm = static_cast<const unsigned char*>(prm.imgB) + ((size_t)n * prm.nbB + nj) * NCH * DC_SIDE;
+    auto issue = [&](int c) {
+        unsigned char* dst = smem + (c & 1) * (2 * DC_SIDE);
+        for (int pc = wave; pc < DC_SIDE / 1024; pc += 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)c * DC_SIDE + (size_t)pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bm + (size_t)c * DC_SIDE + (size_t)pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + DC_SIDE + pc * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue(0);
+    constexpr int LO = TP * LDH;
+    const int r = lane & 31, half = lane >> 5;
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();                                  // chunk c landed (vmcnt(0)); chunk c-1 is free
+        if (c + 1 < NCH) issue(c + 1);
+        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * (2 * DC_SIDE));
+        const half_t* Bs = As + DC_SIDE / 2;
+        const half_t* a0p = As + (64 * wr + r) * LDH + 8 * half;
+        const half_t* a1p = a0p + 32 * LDH;
+        const half_t* b0p = Bs + (64 * wc + r) * LDH + 8 * half;
+        const half_t* b1p = b0p + 32 * LDH;
+#pragma unroll 2
+        for (int kk = 0; kk < KC; kk += 16) {
+            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(a0p + kk), al0 = *reinterpret_cast<const f16x8*>(a0p + LO + kk);
+            const f16x8 ah1 = *reinterpret_cast<const f16x8*>(a1p + kk), al1 = *reinterpret_cast<const f16x8*>(a1p + LO + kk);
+            const f16x8 bh0 = *reinterpret_cast<const f16x8*>(b0p + kk), bl0 = *reinterpret_cast<const f16x8*>(b0p + LO + kk);
+            const f16x8 bh1 = *reinterpret_cast<const f16x8*>(b1p + kk), bl1 = *reinterpret_cast<const f16x8*>(b1p + LO + kk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- store: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* out = prm.out + (size_t)n * prm.M * prm.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = nj * TP + 64 * wc + 32 * j + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mi * TP + 64 * wr + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < prm.M && col < prm.N) out[(size_t)row * prm.N + col] = acc[i][j][e];
+            }
+        }
+}
+
+size_t dense_workspace_bytes(int B, int C, int M, int N)
+{
+    const size_t nbA = (M + TP - 1) / TP, nbB = (N + TP - 1) / TP, NCH = (C + KC - 1) / KC;
+    return (size_t)B * (nbA + nbB) * NCH * DC_SIDE + 512;
+}
+
+hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
+                             float* out, void* ws, hipStream_t stream)
+{
+    DenseParams prm{};
+    prm.a = a; prm.b = b; prm.out = out;
+    prm.B = B; prm.C = C; prm.M = H1 * W1; prm.N = H2 * W2; prm.W1 = W1; prm.W2 = W2;
+    prm.nbA = (prm.M + TP - 1) / TP; prm.nbB = (prm.N + TP - 1) / TP; prm.NCH = (C + KC - 1) / KC;
+    prm.normalize = normalize;
+    unsigned char* w = static_cast<unsigned char*>(ws);
+    w += (256 - (reinterpret_cast<uintptr_t>(w) & 255)) & 255;
+    prm.imgA = w;
+    prm.imgB = w + (size_t)B * prm.nbA * prm.NCH * DC_SIDE;
+    auto cl = [&](const MapV& m) {
+        return m.sc == 1 && C % 4 == 0 && C <= 1024 && (m.sn % 4) == 0 && (m.sh % 4) == 0 && (m.sw % 4) == 0 &&
+               (reinterpret_cast<uintptr_t>(m.p) % 16) == 0;
+    };
+    const int vec = cl(a) && cl(b) ? 1 : 0;
+    hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * (prm.nbA + prm.nbB))), dim3(NTHREADS), 0, stream, prm, vec);
+    const int lds = 4 * DC_SIDE;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
+    return hipGetLastError();
+}
+
+}  // namespace stego

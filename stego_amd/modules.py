@@ -35,7 +35,12 @@ def average_norm(t):
 
 
 def tensor_correlation(a, b):
-    """reference modules.py:283-284."""
+    """reference modules.py:283-284.  Inference-time calls on HIP tensors (the plotting / PR-curve scripts) run on the
+    native dense-correspondence kernel (stego_dense_corr); anything that needs autograd, or lives on the CPU, is the
+    reference's einsum (this helper is not on the training hot path: the fused loss has its own contraction)."""
+    if (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and
+            not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad))):
+        return capi.dense_corr(a, b)
     return torch.einsum("nchw,ncij->nhwij", a, b)
 
 
