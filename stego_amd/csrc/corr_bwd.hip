@@ -172,31 +172,38 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { dA[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dB[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    {
-        const int cl = lane & 15, kq = lane >> 4;
-        const int row0 = 32 * wave + cl;
-        for (int kk = 0; kk < ((prm.debug & 1) ? 0 : TP); kk += 4) {
-            const int k = kk + kq;
-            float ga[2], gt[2], bn[NT], an[NT];
-            ga[0] = G[row0 * LDG + k];                 // G[i][k]
-            ga[1] = G[(row0 + 16) * LDG + k];
-            gt[0] = G[k * LDG + row0];                 // G^T[i][k] = G[k][i]
-            gt[1] = G[k * LDG + row0 + 16];
+    // dA first, its normalize-backward + stores next (they drain while the second GEMM runs), then dB
+    const int cl = lane & 15, kq = lane >> 4;
+    const int row0 = 32 * wave + cl;
+    const int kend = (prm.debug & 1) ? 0 : TP;
+    float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
+    for (int kk = 0; kk < kend; kk += 4) {
+        const int k = kk + kq;
+        float ga[2], bn[NT];
+        ga[0] = G[row0 * LDG + k];                 // G[i][k]
+        ga[1] = G[(row0 + 16) * LDG + k];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bn[nt] = Bn[k * ldk + 16 * nt + cl];
-                an[nt] = An[k * ldk + 16 * nt + cl];
-            }
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = Bn[k * ldk + 16 * nt + cl];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                dA[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], bn[nt], dA[0][nt], 0, 0, 0);
-                dA[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], bn[nt], dA[1][nt], 0, 0, 0);
-                dB[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[0], an[nt], dB[0][nt], 0, 0, 0);
-                dB[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[1], an[nt], dB[1][nt], 0, 0, 0);
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            dA[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], bn[nt], dA[0][nt], 0, 0, 0);
+            dA[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], bn[nt], dA[1][nt], 0, 0, 0);
         }
     }
-
+    if (!sameAB) normalize_bwd_store<NT>(dA, An, ldk, nrm, dtA, K, prm.KQ, lane, wave);
+    for (int kk = 0; kk < kend; kk += 4) {
+        const int k = kk + kq;
+        float gt[2], an[NT];
+        gt[0] = G[k * LDG + row0];                 // G^T[i][k] = G[k][i]
+        gt[1] = G[k * LDG + row0 + 16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) an[nt] = An[k * ldk + 16 * nt + cl];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            dB[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[0], an[nt], dB[0][nt], 0, 0, 0);
+            dB[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[1], an[nt], dB[1][nt], 0, 0, 0);
+        }
+    }
     if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
     // ---- normalize backward -> DT[tile][side]
     if (sameAB) {
@@ -204,11 +211,10 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dA[mt][nt] += dB[mt][nt];   // c1 is c2: both adjoints hit the same samples
-    }
-    float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
-    normalize_bwd_store<NT>(dA, An, ldk, nrm, dtA, K, prm.KQ, lane, wave);
-    if (!sameAB)
+        normalize_bwd_store<NT>(dA, An, ldk, nrm, dtA, K, prm.KQ, lane, wave);
+    } else {
         normalize_bwd_store<NT>(dB, Bn, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
+    }
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
 }
 
