@@ -144,8 +144,6 @@ __device__ __forceinline__ void issue_copy(const unsigned char* __restrict__ gsr
 // Per chunk and lane: ITEMS x 4 tap loads into registers during the first half of the MFMA k groups, blended
 // and written to the other LDS stage buffer during the second half (by then they have landed; the blend's VALU
 // work rides in the MFMA shadow).
-constexpr float B_RAW_SCALE = 0.0625f;            // split mode: raw B values are staged as x / 16
-
 template <int V> struct GatherRegs {
     typedef typename VecT<V>::type vec;
     static constexpr int SLOTS = KC / V;
@@ -153,16 +151,10 @@ template <int V> struct GatherRegs {
     static constexpr int PPI = NTHREADS / SLOTS;
     vec tv[ITEMS][4];               // the 4 taps of every item of one chunk (two of these are alive: chunk t+1, t+2)
 };
-template <int V> struct GatherOffs {
-    // V == 4: byte offset of (point, tap, this lane's channel slot) inside a chunk of the image, kept in registers
-    // (SGPR base + 32-bit lane offset loads, no address arithmetic in the MFMA stream).  The generic V == 1 path
-    // has 4x the items and re-reads the tap table from LDS instead.
-    unsigned off[V == 4 ? GatherRegs<V>::ITEMS : 1][4];
-};
-
-// items [j0, j0 + n): loads.  `chunk` = image + c0 * channel_stride (wave-uniform): SGPR base + 32-bit lane offset.
+// items [j0, j0 + n): loads.  `chunk` = image + c0 * channel_stride (wave-uniform): SGPR base + 32-bit lane offsets
+// (tap offset from the LDS table + this lane's channel slot).
 template <int V>
-__device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const GatherOffs<V>& go, const float* __restrict__ chunk,
+__device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const float* __restrict__ chunk,
                                              const int4* __restrict__ tapo, int lane_off, int prow, int j0, int n)
 {
     typedef typename VecT<V>::type vec;
@@ -170,11 +162,13 @@ __device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const GatherOffs<
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         const int j = j0 + i;
+        const int4 o = tapo[j * GatherRegs<V>::PPI + prow];
         if constexpr (V == 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g.tv[j][k] = *reinterpret_cast<const vec*>(cb + go.off[j][k]);
+            g.tv[j][0] = *reinterpret_cast<const vec*>(cb + (unsigned)(o.x + lane_off) * 4u);
+            g.tv[j][1] = *reinterpret_cast<const vec*>(cb + (unsigned)(o.y + lane_off) * 4u);
+            g.tv[j][2] = *reinterpret_cast<const vec*>(cb + (unsigned)(o.z + lane_off) * 4u);
+            g.tv[j][3] = *reinterpret_cast<const vec*>(cb + (unsigned)(o.w + lane_off) * 4u);
         } else {
-            const int4 o = tapo[j * GatherRegs<V>::PPI + prow];
             const float* b = chunk + lane_off;
             g.tv[j][0] = b[o.x]; g.tv[j][1] = b[o.y]; g.tv[j][2] = b[o.z]; g.tv[j][3] = b[o.w];
         }
@@ -183,10 +177,13 @@ __device__ __forceinline__ void gather_issue(GatherRegs<V>& g, const GatherOffs<
 
 // items [j0, j0 + n): blend the 4 taps, accumulate the points' sums of squares, write the LDS operand image
 //   PREC_F32   : float [128][LDA]            PREC_F16X3: fp16 hi[128][LDH] then lo[128][LDH]
+// Split mode stages the RAW sampled values as fp16 halves, so every point gets its own power-of-two scale bsc[j]
+// (chosen from the first chunk in which the point is non-zero: |x| * bsc in [0.5, 1)) - F.normalize is scale invariant
+// and so is this path for features of any magnitude; the epilogue's column scale divides it out again.
 template <int V, int PREC>
 __device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const float4* __restrict__ tapw, bool chok,
-                                              void* __restrict__ dst_, float (&ss)[GatherRegs<V>::ITEMS], int slot, int prow,
-                                              int j0, int n)
+                                              void* __restrict__ dst_, float (&ss)[GatherRegs<V>::ITEMS],
+                                              float (&bsc)[GatherRegs<V>::ITEMS], int slot, int prow, int j0, int n)
 {
     constexpr int PPI = GatherRegs<V>::PPI;
     const int col = slot * V;
@@ -215,9 +212,17 @@ __device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const floa
         } else {
             half_t* dh = static_cast<half_t*>(dst_) + q * LDH + col;
             half_t* dl = dh + TP * LDH;
-            // raw (un-normalised) values: 2^-4 keeps |x| < 1e6 inside fp16; the column scale undoes it
+            if (bsc[j] == 0.f) {                      // (uniform over the lanes of a point)
+                float mx = 0.f;
 #pragma unroll
-            for (int e = 0; e < V; ++e) v[e] *= B_RAW_SCALE;
+                for (int e = 0; e < V; ++e) mx = fmaxf(mx, fabsf(v[e]));
+#pragma unroll
+                for (int m = GatherRegs<V>::SLOTS / 2; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+                if (mx > 0.f) bsc[j] = __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx));
+            }
+            const float sc = bsc[j] == 0.f ? 1.f : bsc[j];
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] *= sc;
             if constexpr (V == 4) {
                 unsigned h0, l0, h1, l1;
                 split_f16_pair(v[0], v[1], h0, l0);
@@ -454,21 +459,14 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
         // the matrix cores, so this VALU / memory work genuinely overlaps them (in f32 mode the fp32 MFMA owns the
         // VALU and the two teams time-slice: no worse than doing it in one wave).
         GatherRegs<V> g;
-        GatherOffs<V> goff;
         constexpr int ITEMS = GatherRegs<V>::ITEMS;
-        float ss[ITEMS];
+        float ss[ITEMS], bsc[ITEMS];
         const int gslot = gt % GatherRegs<V>::SLOTS, gprow = gt / GatherRegs<V>::SLOTS;
         const int lane_off = gslot * V * scB;                         // this lane's channel slot inside a chunk
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             ss[j] = 0.f;
-            if constexpr (V == 4) {
-                const int4 o = tapo[j * GatherRegs<V>::PPI + gprow];
-                goff.off[j][0] = (unsigned)(o.x + lane_off) * 4u;
-                goff.off[j][1] = (unsigned)(o.y + lane_off) * 4u;
-                goff.off[j][2] = (unsigned)(o.z + lane_off) * 4u;
-                goff.off[j][3] = (unsigned)(o.w + lane_off) * 4u;
-            }
+            bsc[j] = 0.f;
         }
         // Channels beyond C exist only in the generic path (V == 1, the host takes V == 4 only when C % 64 == 0):
         // such a lane re-reads the last channel and its values are zeroed at commit.  Prefetches past the last
@@ -477,9 +475,9 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
         auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(t * KC + gslot, prm.C - 1) * scB; };
         auto chunk_ok = [&](int t) { return V == 4 || t * KC + gslot < prm.C; };
         if (gatherB) {
-            gather_issue<V>(g, goff, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
-            gather_commit<V, PREC>(g, tapw, chunk_ok(0), stage + FSIDE, ss, gslot, gprow, 0, ITEMS);
-            gather_issue<V>(g, goff, chunk_ptr(1), tapo, lane_ofs(1), gprow, 0, ITEMS);
+            gather_issue<V>(g, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
+            gather_commit<V, PREC>(g, tapw, chunk_ok(0), stage + FSIDE, ss, bsc, gslot, gprow, 0, ITEMS);
+            gather_issue<V>(g, chunk_ptr(1), tapo, lane_ofs(1), gprow, 0, ITEMS);
         }
         for (int t = 0; t < NCH; ++t) {
             __syncthreads();                     // B1(t): the MFMA team is done with stage t-1 = the buffer written next
@@ -490,8 +488,8 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
                 void* dstB = stage + ((t + 1) & 1) * stage_bytes + FSIDE;
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
-                    gather_commit<V, PREC>(g, tapw, ok, dstB, ss, gslot, gprow, j, 1);
-                    gather_issue<V>(g, goff, nxt, tapo, nxt_off, gprow, j, 1);
+                    gather_commit<V, PREC>(g, tapw, ok, dstB, ss, bsc, gslot, gprow, j, 1);
+                    gather_issue<V>(g, nxt, tapo, nxt_off, gprow, j, 1);
                 }
             }
         }
@@ -504,7 +502,7 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
 #pragma unroll
             for (int m = SLOTS / 2; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
             if (gslot == 0)
-                csc[j * PPI + gprow] = sameAB ? 1.f : (PREC == PREC_F16X3 ? 1.f / B_RAW_SCALE : 1.f) / fmaxf(sqrtf(sq), 1e-10f);
+                csc[j * PPI + gprow] = sameAB ? 1.f : ((PREC == PREC_F16X3 && bsc[j] != 0.f) ? 1.f / bsc[j] : 1.f) / fmaxf(sqrtf(sq), 1e-10f);
         }
     }
 

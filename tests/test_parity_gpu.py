@@ -101,6 +101,22 @@ def test_backward_general_upstream(name):
     assert_close(r["d_code_pos"], g["d_code_pos_gen"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos_gen")
 
 
+@pytest.mark.parametrize("scale", [1e-6, 3e4])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_feature_scale_invariance(scale, precision):
+    """norm() makes the loss independent of the magnitude of the feature maps (modules.py:275-276).  The split-fp16
+    mode stages raw samples as fp16 halves, so it must rescale them itself: 1e-6 would vanish, 3e4 overflow."""
+    c = GoldenCase("cfg1_B4_vits8_dinolike")
+    base = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision=precision)["out"]
+    scaled = dict(c.inputs)
+    scaled["feats"] = c.inputs["feats"] * np.float32(scale)
+    scaled["feats_pos"] = c.inputs["feats_pos"] * np.float32(scale)
+    alt = _run(scaled, c.perms, c.cfg, layout="cl", grad=False, precision=precision)["out"]
+    for x, y in zip(base, alt):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=2e-6)
+    assert_close(c.sub(alt[4]), c.g["neg_inter_loss"], atol_frac=5e-4, what="neg_inter_loss (features x %g)" % scale)
+
+
 def test_generic_strided_path_direct_through_capi():
     """modules.py re-lays large NCHW maps out channels-last (as_channels_last); the kernels' generic strided path
     is still part of the C ABI: call it directly with NCHW-contiguous maps and compare with the channels-last run."""
