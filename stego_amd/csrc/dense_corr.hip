@@ -24,6 +24,8 @@ struct DenseParams {
     void* imgA;                 // [B][nbA][NCH][2][128][LDH] fp16
     void* imgB;
     float* out;                 // [B][M][N]
+    float* rsA;                 // [B][nbA*128] 1 / (power-of-two row scale) of the fp16 staging; rsB likewise
+    float* rsB;
     int B, C, M, N, W1, W2, nbA, nbB, NCH, normalize;
 };
 
@@ -63,7 +65,16 @@ __global__ void __launch_bounds__(NTHREADS) dense_prep_kernel(const DenseParams 
             }
 #pragma unroll
             for (int s2 = 16; s2 >= 1; s2 >>= 1) ss += __shfl_xor(ss, s2, 64);
-            const float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;      // norm(), modules.py:276
+            float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;            // norm(), modules.py:276
+            float mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j][0]), fabsf(v[j][1])), fmaxf(fabsf(v[j][2]), fabsf(v[j][3]))));
+#pragma unroll
+            for (int s2 = 16; s2 >= 1; s2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s2, 64));
+            // fp16 staging wants |x| ~ 1: a power-of-two row scale (exact), divided out again by the tile kernel
+            const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
+            inv *= rs;
+            if (hl == 0) (isB ? prm.rsB : prm.rsA)[((size_t)n * (isB ? prm.nbB : prm.nbA) + blk) * TP + rl] = 1.f / rs;
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
                 const int c = 128 * j + 4 * hl;
@@ -77,11 +88,14 @@ __global__ void __launch_bounds__(NTHREADS) dense_prep_kernel(const DenseParams 
                 }
             }
         } else {
-            float ss = 0.f;
-            if (rv) for (int c = hl; c < C; c += 32) { const float t = x[(long long)c * m.sc]; ss += t * t; }
+            float ss = 0.f, mx = 0.f;
+            if (rv) for (int c = hl; c < C; c += 32) { const float t = x[(long long)c * m.sc]; ss += t * t; mx = fmaxf(mx, fabsf(t)); }
 #pragma unroll
-            for (int s2 = 16; s2 >= 1; s2 >>= 1) ss += __shfl_xor(ss, s2, 64);
-            const float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;
+            for (int s2 = 16; s2 >= 1; s2 >>= 1) { ss += __shfl_xor(ss, s2, 64); mx = fmaxf(mx, __shfl_xor(mx, s2, 64)); }
+            float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;
+            const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
+            inv *= rs;
+            if (hl == 0) (isB ? prm.rsB : prm.rsA)[((size_t)n * (isB ? prm.nbB : prm.nbA) + blk) * TP + rl] = 1.f / rs;
             for (int c = hl; c < prm.NCH * KC; c += 32) {
                 const float t = (rv && c < C) ? x[(long long)c * m.sc] * inv : 0.f;
                 unsigned h, l;
@@ -155,15 +169,20 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
     }
     // ---- store: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* out = prm.out + (size_t)n * prm.M * prm.N;
+    const float* ra = prm.rsA + ((size_t)n * prm.nbA + mi) * TP;       // undo the rows' staging scales
+    const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = nj * TP + 64 * wc + 32 * j + (lane & 31);
+            const int cl = 64 * wc + 32 * j + (lane & 31);
+            const int col = nj * TP + cl;
+            const float sb = rb[cl];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = mi * TP + 64 * wr + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < prm.M && col < prm.N) out[(size_t)row * prm.N + col] = acc[i][j][e];
+                const int rw = 64 * wr + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int row = mi * TP + rw;
+                if (row < prm.M && col < prm.N) out[(size_t)row * prm.N + col] = acc[i][j][e] * (ra[rw] * sb);
             }
         }
 }
@@ -171,7 +190,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
 size_t dense_workspace_bytes(int B, int C, int M, int N)
 {
     const size_t nbA = (M + TP - 1) / TP, nbB = (N + TP - 1) / TP, NCH = (C + KC - 1) / KC;
-    return (size_t)B * (nbA + nbB) * NCH * DC_SIDE + 512;
+    return (size_t)B * (nbA + nbB) * NCH * DC_SIDE + (size_t)B * (nbA + nbB) * TP * sizeof(float) + 512;
 }
 
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
@@ -186,6 +205,8 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
     w += (256 - (reinterpret_cast<uintptr_t>(w) & 255)) & 255;
     prm.imgA = w;
     prm.imgB = w + (size_t)B * prm.nbA * prm.NCH * DC_SIDE;
+    prm.rsA = reinterpret_cast<float*>(w + (size_t)B * (prm.nbA + prm.nbB) * prm.NCH * DC_SIDE);
+    prm.rsB = prm.rsA + (size_t)B * prm.nbA * TP;
     auto cl = [&](const MapV& m) {
         return m.sc == 1 && C % 4 == 0 && C <= 1024 && (m.sn % 4) == 0 && (m.sh % 4) == 0 && (m.sw % 4) == 0 &&
                (reinterpret_cast<uintptr_t>(m.p) % 16) == 0;

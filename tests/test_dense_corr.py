@@ -57,3 +57,15 @@ def test_dense_corr_matches_float64_einsum(shape, layout):
         self_sim = capi.dense_corr(ta, ta, normalize=True).cpu().numpy().reshape(B, H1 * W1, H1 * W1)
         np.testing.assert_allclose(np.diagonal(self_sim, axis1=1, axis2=2), 1.0, atol=2e-6)      # unit self-similarity
         np.testing.assert_allclose(self_sim, self_sim.transpose(0, 2, 1), atol=1e-6)              # symmetric
+
+
+@pytest.mark.parametrize("scale", [1e-7, 1.0, 1e6])
+def test_dense_corr_raw_products_any_magnitude(scale):
+    """Without norm() the products are raw: the fp16 staging must not lose tiny maps or overflow on huge ones."""
+    from stego_amd import capi
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((2, 96, 6, 7)) * scale).astype(np.float32)
+    b = (rng.standard_normal((2, 96, 5, 4)) * scale).astype(np.float32)
+    out = capi.dense_corr(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    ref = _ref(a, b, False)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).mean())
