@@ -132,10 +132,12 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
             if (gs) { glp = gs; gl_scale = inv_numel; }
         }
         const float* gcd = direct ? prm.g_neg_cd : (p == 0 ? prm.g_intra_cd : (p == 1 ? prm.g_inter_cd : prm.g_neg_cd));
-        const float gc_scale = gcd ? 1.f : 0.f;
         const float* gcp = gcd ? gcd + t0 : wp;
         const float om = prm.saved_mean[p];
-        constexpr int RB = 4;
+        // absent / broadcast upstreams cost no loads (uniform branches around whole batches of loads)
+        const bool has_gl = gl_mul != 0, has_gc = gcd != nullptr;
+        const float gl_b = has_gl ? 0.f : glp[0] * gl_scale;
+        constexpr int RB = 16;
         for (int i0 = 0; i0 < TP / 4; i0 += RB) {
             float wv[RB][2], glv[RB][2], gcv[RB][2];
 #pragma unroll
@@ -143,11 +145,26 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
-                    const int idx = min(r, P - 1) * P + min(c, P - 1);
-                    wv[j][h] = wp[idx];
-                    glv[j][h] = glp[idx * gl_mul];
-                    gcv[j][h] = gcp[idx];
+                    wv[j][h] = wp[min(r, P - 1) * P + min(c, P - 1)];
                 }
+            if (has_gl) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
+                        glv[j][h] = glp[min(r, P - 1) * P + min(c, P - 1)] * gl_scale;
+                    }
+            }
+            if (has_gc) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r = wave + 4 * (i0 + j), c = lane + 64 * h;
+                        gcv[j][h] = gcp[min(r, P - 1) * P + min(c, P - 1)];
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < RB; ++j)
 #pragma unroll
@@ -156,8 +173,8 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
                     // the forward left the clamp pass-mask 1[cmin <= cd <= cmax] in the mantissa LSB of w
                     const unsigned wb = __builtin_bit_cast(unsigned, wv[j][h]);
                     const float w = __builtin_bit_cast(float, wb & ~1u);
-                    float g = (wb & 1u) ? -(w + om) * (glv[j][h] * gl_scale) : 0.f;
-                    g += gcv[j][h] * gc_scale;
+                    float g = (wb & 1u) ? -(w + om) * (has_gl ? glv[j][h] : gl_b) : 0.f;
+                    if (has_gc) g += gcv[j][h];
                     G[r * LDG + c] = (r < P && c < P) ? g : 0.f;
                 }
         }
