@@ -542,7 +542,6 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
 // one set); block 0 also writes the scalar means and saved_mean.
 __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParams prm)
 {
-    __shared__ float s_mean;
     const int B = prm.B, P2 = prm.P * prm.P;
     const float inv_cnt = 1.f / ((float)B * (float)P2);
     const int first_loss_set = prm.mode == 1 ? 0 : 2;
@@ -564,18 +563,13 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
     const size_t blocks_per_set = (per_set + span - 1) / span;
     const int ps = (int)(blockIdx.x / blocks_per_set);
     if (ps >= n_loss_sets) return;
-    if (threadIdx.x == 0) {
-        float fs = 0.f;
-        const int p = first_loss_set + ps;
-        for (int b = 0; b < B; ++b) fs += prm.stats[((size_t)p * B + b) * 4];
-        s_mean = fs * inv_cnt;
-    }
-    __syncthreads();
-    const float om = s_mean;
+    // Every lane sums the pair-set's B tile sums itself (same addresses across the wave: one request per load, same
+    // order as block 0 above), so these loads fly together with the data loads below: one round trip, no barrier.
     const float cmin = prm.cmin, cmax = prm.cmax;
     const size_t beg = (size_t)(blockIdx.x % blocks_per_set) * span;
     float* loss = prm.neg_loss + (size_t)ps * per_set;
     const float* cd = prm.neg_cd + (size_t)ps * per_set;
+    const float* stp = prm.stats + (size_t)(first_loss_set + ps) * B * 4;
     const bool vec_ok = (per_set % 4 == 0) && ((reinterpret_cast<uintptr_t>(loss) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(cd) & 15) == 0);
     if (vec_ok) {
@@ -584,11 +578,13 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             e[i] = beg + ((size_t)i * NTHREADS + threadIdx.x) * 4;
-            if (e[i] < per_set) {
-                l[i] = *reinterpret_cast<const f32x4*>(loss + e[i]);
-                c[i] = *reinterpret_cast<const f32x4*>(cd + e[i]);
-            }
+            const size_t ec = e[i] < per_set ? e[i] : 0;
+            l[i] = *reinterpret_cast<const f32x4*>(loss + ec);
+            c[i] = *reinterpret_cast<const f32x4*>(cd + ec);
         }
+        float fs = 0.f;
+        for (int b = 0; b < B; ++b) fs += stp[b * 4];
+        const float om = fs * inv_cnt;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (e[i] < per_set) {
@@ -598,6 +594,9 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
             }
         }
     } else {
+        float fs = 0.f;
+        for (int b = 0; b < B; ++b) fs += stp[b * 4];
+        const float om = fs * inv_cnt;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const size_t e = beg + (size_t)i * NTHREADS + threadIdx.x;
