@@ -9,7 +9,8 @@
 //   knn_prep_kernel  - (optional F.normalize, eps 1e-12) + fp32 -> split-fp16 (hi, lo) in the LDS-image layout
 //                      [row block of 128][64-column chunk][hi|lo][128][72], zero padded: every later tile load is a
 //                      linear global_load_lds copy, no VALU.
-//   knn_tile_kernel  - one workgroup = 128 queries x one slice of the database, streamed in 128-column tiles.
+//   knn_tile_kernel  - persistent workgroups, each an even share of the (128-query block, 128-column tile) units,
+//                      walked query block by query block (a block is cut at most where two workgroups meet).
 //                      sims on v_mfma_f32_32x32x16_f16 as hi*hi + hi*lo + lo*hi (fp32 accumulate, ~2e-7 abs on a
 //                      cosine: the order of neighbours matches fp32 except for ties at that level; plain fp32 MFMA
 //                      runs at the VALU rate on gfx950 and would take 3x longer).  Wave w owns query rows
@@ -19,7 +20,7 @@
 //                      Per tile: one compare-and-ballot per row pair against the current k-th value; the (rare:
 //                      ~k ln(N/k) per row in total) hits are inserted with a ballot-popcount position and a
 //                      one-lane shift - registers only, no LDS, no atomics, deterministic.
-//   knn_merge_kernel - merges the per-slice lists of a row (k-way, by repeated arg-max over the list heads).
+//   knn_merge_kernel - merges the per-segment lists of a row (k-way, by repeated arg-max over the list heads).
 // Ties: torch.topk leaves the order of equal values unspecified; so does this.
 #include <cstdlib>
 #include "corr_common.h"
@@ -40,8 +41,10 @@ struct KnnParams {
     long long N, ldx;
     int D, NCH, k, normalize;
     long long q_begin, q_count; // query rows [q_begin, q_begin + q_count)
-    int nblk, NS, tiles_per_slice;
-    int debug;                  // STEGO_DEBUG_KNN: 1 skip the selection, 2 skip the MFMAs (measurement only)
+    int nblk, NS;               // NS = max partial lists (segments) per query block
+    long long units_total, units_per_wg;      // work units = (query block, database tile) pairs, split evenly over the WGs
+    int debug;                  // STEGO_DEBUG_KNN: 1 skip the selection, 2 skip the MFMAs, 4 count slow-path entries
+    unsigned long long* counters;   // [2] (debug 4): row pairs that took the slow path, insertion iterations
 };
 
 // ---------------------------------------------------------------------------------------------- prep
@@ -137,12 +140,56 @@ __device__ __forceinline__ void knn_mma_chunk_areg(const f16x8 (&ah)[KC / 16], c
     }
 }
 
-constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 192 VGPRs
-
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+
+struct KnnRow { float v; int i; };
+
+// Slow path of the selection for one register row pair: insert every candidate of the 4 column blocks into the two
+// sorted lists (one per half-wave).  Deliberately NOT inlined: 16 inlined copies per tile made the kernel ~75 KB of
+// code (the instruction cache is 64 KB per CU pair); the fast path (one compare + ballot) stays inline.
+__device__ __attribute__((noinline)) KnnRow knn_insert_rows(float a0, float a1, float a2, float a3, int cvmask, float lv, int li,
+                                                           int k, int col0)
+{
+    const int lane = threadIdx.x & 63, slot = lane & 31;
+    const bool upper = lane >= 32;
+    float thr = upper ? readlane_f(lv, 32 + k - 1) : readlane_f(lv, k - 1);
+#pragma unroll 1
+    for (int ni = 0; ni < 4; ++ni) {
+        const float a = ni == 0 ? a0 : (ni == 1 ? a1 : (ni == 2 ? a2 : a3));
+        const bool cvn = (cvmask >> ni) & 1;
+        unsigned long long done = 0ull;
+        unsigned long long m = __ballot(cvn && a > thr);
+        while (m != 0ull) {
+            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+            const int c0 = mlo ? __builtin_ctz(mlo) : 0, c1 = mhi ? __builtin_ctz(mhi) : 0;    // first candidate per half
+            const float x0 = readlane_f(a, c0), x1 = readlane_f(a, 32 + c1);
+            const bool have = upper ? mhi != 0u : mlo != 0u;
+            const float x = upper ? x1 : x0;
+            const int cl = upper ? c1 : c0;
+            const int xi = col0 + 32 * ni + cl;
+            // position = number of entries >= x in my half; everything behind it moves down one slot
+            const unsigned long long ge = __ballot(lv >= x);
+            const int pos = upper ? __builtin_popcount((unsigned)(ge >> 32)) : __builtin_popcount((unsigned)ge);
+            const float upv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lv), 0x138, 0xf, 0xf, false));
+            const int upi = __builtin_amdgcn_update_dpp(0, li, 0x138, 0xf, 0xf, false);             // wave_shr:1
+            if (have) {
+                if (slot == pos) { lv = x; li = xi; }
+                else if (slot > pos) { lv = upv; li = upi; }
+            }
+            done |= (mlo ? 1ull << c0 : 0ull) | (mhi ? 1ull << (32 + c1) : 0ull);
+            thr = upper ? readlane_f(lv, 32 + k - 1) : readlane_f(lv, k - 1);
+            m = __ballot(cvn && a > thr) & ~done;
+        }
+    }
+    KnnRow r;
+    r.v = lv; r.i = li;
+    return r;
+}
+
+constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 192 VGPRs
 
 // grid = (query blocks, NS); block = 256.  AREG: LDS = 2 stages x B chunk, A in registers (D <= 384);
 // otherwise 2 stages x (A chunk + B chunk).
@@ -153,20 +200,30 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NCH = prm.NCH, k = prm.k;
-    const int qblk = (int)(prm.q_begin / TP) + blockIdx.x;            // q_begin is a multiple of 128 (host-checked)
-    const int slice = blockIdx.y;
-    const int tile0 = slice * prm.tiles_per_slice;
-    const int tile1 = min(prm.nblk, tile0 + prm.tiles_per_slice);
     const unsigned char* img = static_cast<const unsigned char*>(prm.img);
+    const int slot = lane & 31;
+    const bool upper = lane >= 32;
+    // Persistent workgroup: an even share of the (query block, database tile) units, walked query block by query
+    // block.  With one workgroup per (query block, slice) the grid was 3.05 rounds of the chip for N = 100 k and every
+    // slice re-warmed its lists; here every CU gets the same number of tiles and a query block is cut at most where
+    // two workgroups meet (its partial lists go to consecutive slots and are merged afterwards).
+    const long long u_begin = (long long)blockIdx.x * prm.units_per_wg;
+    const long long u_end = min(prm.units_total, u_begin + prm.units_per_wg);
+    for (long long u = u_begin; u < u_end;) {
+    const int qb = (int)(u / prm.nblk);                                // query block relative to q_begin
+    const int tile0 = (int)(u - (long long)qb * prm.nblk);
+    const int tile1 = (int)min((long long)prm.nblk, tile0 + (u_end - u));
+    u += tile1 - tile0;
+    const int seg = (int)(((long long)qb * prm.nblk + tile0) / prm.units_per_wg - ((long long)qb * prm.nblk) / prm.units_per_wg);
+    const int qblk = (int)(prm.q_begin / TP) + qb;                     // q_begin is a multiple of 128 (host-checked)
     const unsigned char* Aimg = img + (size_t)qblk * NCH * KNN_SIDE;
+    __syncthreads();                                                   // the previous segment is done with the stage buffers
 
     // running top-k: register index rr <-> query rows  32 wave + (rr&3) + 8 (rr>>2) + 4 (lane>>5)
     float lv[16];
     int li[16];
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) { lv[rr] = -INFINITY; li[rr] = -1; }
-    const int slot = lane & 31;
-    const bool upper = lane >= 32;
 
     const int nstage = (tile1 - tile0) * NCH;
     constexpr int STAGE = AREG ? KNN_SIDE : 2 * KNN_SIDE;
@@ -221,66 +278,46 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
         bool cv[4];                                    // column of this lane in block ni exists (only the last tile has holes)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) cv[ni] = col0 + 32 * ni + slot < prm.N;
+        const int cvmask = (cv[0] ? 1 : 0) | (cv[1] ? 2 : 0) | (cv[2] ? 4 : 0) | (cv[3] ? 8 : 0);
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             // everything wave-uniform goes through SGPRs (v_readlane / s_ff1 / s_bcnt1): the first version used
             // ds_bpermute shuffles here and the selection cost more than the MFMAs (32 of 55 ms at N = 100 k)
-            float thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);      // current k-th best of my row
+            const float thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);      // current k-th best of my row
             const bool any4 = (cv[0] && acc[0][rr] > thr) || (cv[1] && acc[1][rr] > thr) || (cv[2] && acc[2][rr] > thr) ||
                               (cv[3] && acc[3][rr] > thr);
-            if (__ballot(any4) == 0ull) continue;                          // the common case
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                // the accumulators stay READ-ONLY here (consumed candidates are tracked in a scalar mask): writing
-                // -inf into them made every branch join copy all 64 accumulators between AGPRs and VGPRs
-                unsigned long long done = 0ull;
-                unsigned long long m = __ballot(cv[ni] && acc[ni][rr] > thr);
-                while (m != 0ull) {
-                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-                    const int c0 = mlo ? __builtin_ctz(mlo) : 0, c1 = mhi ? __builtin_ctz(mhi) : 0;    // first candidate per half
-                    const float x0 = readlane_f(acc[ni][rr], c0), x1 = readlane_f(acc[ni][rr], 32 + c1);
-                    const bool have = upper ? mhi != 0u : mlo != 0u;
-                    const float x = upper ? x1 : x0;
-                    const int cl = upper ? c1 : c0;
-                    const int xi = (int)(col0 + 32 * ni + cl);
-                    // position = number of entries >= x in my half; everything behind it moves down one slot
-                    const unsigned long long ge = __ballot(lv[rr] >= x);
-                    const int pos = upper ? __builtin_popcount((unsigned)(ge >> 32)) : __builtin_popcount((unsigned)ge);
-                    const float upv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lv[rr]), 0x138, 0xf, 0xf, false));
-                    const int upi = __builtin_amdgcn_update_dpp(0, li[rr], 0x138, 0xf, 0xf, false);         // wave_shr:1
-                    if (have) {
-                        if (slot == pos) { lv[rr] = x; li[rr] = xi; }
-                        else if (slot > pos) { lv[rr] = upv; li[rr] = upi; }
-                    }
-                    done |= (mlo ? 1ull << c0 : 0ull) | (mhi ? 1ull << (32 + c1) : 0ull);
-                    thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);
-                    m = __ballot(cv[ni] && acc[ni][rr] > thr) & ~done;
-                }
-            }
+            if (__ballot(any4) == 0ull || (prm.debug & 8)) continue;       // the common case (debug 8: never insert)
+            if ((prm.debug & 4) && lane == 0) atomicAdd(prm.counters, 1ull);
+            const KnnRow nr = knn_insert_rows(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], cvmask, lv[rr], li[rr], k, (int)col0);
+            lv[rr] = nr.v;
+            li[rr] = nr.i;
         }
     }
-    // ---- write the partial lists of this slice (sorted descending)
-    const long long qrow_base = (long long)blockIdx.x * TP + 32 * wave;       // relative to q_begin
-    const long long nq_pad = (long long)gridDim.x * TP;
+    // ---- write the partial lists of this segment (sorted descending)
+    const long long qrow_base = (long long)qb * TP + 32 * wave;               // relative to q_begin
+    const long long nq_pad = ((prm.q_count + TP - 1) / TP) * TP;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const long long qr = qrow_base + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
         if (slot < k) {
-            prm.part_val[((size_t)slice * nq_pad + qr) * k + slot] = lv[rr];
-            prm.part_idx[((size_t)slice * nq_pad + qr) * k + slot] = li[rr];
+            prm.part_val[((size_t)seg * nq_pad + qr) * k + slot] = lv[rr];
+            prm.part_idx[((size_t)seg * nq_pad + qr) * k + slot] = li[rr];
         }
     }
+    }       // segments of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------- merge
-// one half-wave per query row: lane s < NS walks slice s's sorted list; k rounds of arg-max over the heads.
+// one half-wave per query row: lane s < NS walks segment s's sorted list; k rounds of arg-max over the heads.
 __global__ void __launch_bounds__(NTHREADS) knn_merge_kernel(const KnnParams prm)
 {
     const int tid = threadIdx.x, lane = tid & 63, s = lane & 31;
     const long long q = (long long)blockIdx.x * (NTHREADS / 32) + (tid >> 5);
     if (q >= prm.q_count) return;
-    const int k = prm.k, NS = prm.NS;
+    const int k = prm.k;
     const long long nq_pad = (long long)((prm.q_count + TP - 1) / TP) * TP;
+    const long long ub = (q / TP) * (long long)prm.nblk;                 // first unit of this row's query block
+    const int NS = (int)((ub + prm.nblk - 1) / prm.units_per_wg - ub / prm.units_per_wg) + 1;     // its segments
     int p = 0;                                                   // my list's head
     const float* pv = prm.part_val + ((size_t)min(s, NS - 1) * nq_pad + q) * k;
     const int* pi = prm.part_idx + ((size_t)min(s, NS - 1) * nq_pad + q) * k;
@@ -289,7 +326,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_merge_kernel(const KnnParams prm
         int who = s;
         float best = v;
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {                      // arg-max (ties: lower slice first)
+        for (int m = 16; m >= 1; m >>= 1) {                      // arg-max (ties: lower segment first)
             const float ov = __shfl_xor(best, m, 32);
             const int ow = __shfl_xor(who, m, 32);
             if (ov > best || (ov == best && ow < who)) { best = ov; who = ow; }
@@ -304,15 +341,28 @@ __global__ void __launch_bounds__(NTHREADS) knn_merge_kernel(const KnnParams prm
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static int knn_slices(long long q_count, int nblk)
+static int knn_cus()
 {
-    // enough workgroups to fill the chip several times over, but slices of at least 8 tiles
-    const long long qb = (q_count + TP - 1) / TP;
-    int ns = (int)((8 * 256 + qb - 1) / qb);
-    if (ns > 32) ns = 32;
-    if (ns > (nblk + 7) / 8) ns = (nblk + 7) / 8;
-    if (ns < 1) ns = 1;
-    return ns;
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess &&
+             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+}
+
+// units per workgroup: an even split over the CUs, but never so fine that a query block has more than 32 segments
+static void knn_partition(long long q_count, int nblk, long long* units_total, long long* units_per_wg, int* max_segments)
+{
+    const long long nqb = (q_count + TP - 1) / TP;
+    const long long T = nqb * nblk;
+    long long U = (T + knn_cus() - 1) / knn_cus();
+    const long long umin = (nblk + 30) / 31;
+    if (U < umin) U = umin;
+    *units_total = T;
+    *units_per_wg = U;
+    *max_segments = (int)((nblk + U - 1) / U) + 1;
 }
 
 size_t knn_workspace_bytes(long long N, int D, int k, long long q_count)
@@ -320,11 +370,13 @@ size_t knn_workspace_bytes(long long N, int D, int k, long long q_count)
     const long long nblk = (N + TP - 1) / TP;
     const int NCH = (D + KC - 1) / KC;
     const long long nq_pad = ((q_count + TP - 1) / TP) * TP;
-    const int ns = knn_slices(q_count, (int)nblk);
+    long long T, U;
+    int ns;
+    knn_partition(q_count, (int)nblk, &T, &U, &ns);
     size_t b = (size_t)nblk * NCH * KNN_SIDE;
     b = (b + 255) & ~(size_t)255;
     b += (size_t)ns * nq_pad * k * 8;
-    return b + 256;
+    return b + 512;
 }
 
 hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, int normalize, long long q_begin,
@@ -335,8 +387,7 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     prm.q_begin = q_begin; prm.q_count = q_count; prm.out_idx = out_idx; prm.out_val = out_val;
     prm.nblk = (int)((N + TP - 1) / TP);
     prm.NCH = (D + KC - 1) / KC;
-    prm.NS = knn_slices(q_count, prm.nblk);
-    prm.tiles_per_slice = (prm.nblk + prm.NS - 1) / prm.NS;
+    knn_partition(q_count, prm.nblk, &prm.units_total, &prm.units_per_wg, &prm.NS);
     {
         const char* e = getenv("STEGO_DEBUG_KNN");
         prm.debug = e ? atoi(e) : 0;
@@ -347,6 +398,7 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     size_t off = ((size_t)prm.nblk * prm.NCH * KNN_SIDE + 255) & ~(size_t)255;
     prm.part_val = reinterpret_cast<float*>(w + off);
     prm.part_idx = reinterpret_cast<int*>(w + off + (size_t)prm.NS * nq_pad * k * 4);
+    prm.counters = reinterpret_cast<unsigned long long*>(w + off + (size_t)prm.NS * nq_pad * k * 8);      // 256 B of slack
 
     hipLaunchKernelGGL(knn_prep_kernel, dim3(prm.nblk), dim3(NTHREADS), 0, stream, prm);
     const bool areg = prm.NCH <= KNN_AREG_CHUNKS;
@@ -359,7 +411,7 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
         if (e != hipSuccess) return e;
         attr[areg] = true;
     }
-    const dim3 grid((unsigned)(nq_pad / TP), prm.NS);
+    const dim3 grid((unsigned)((prm.units_total + prm.units_per_wg - 1) / prm.units_per_wg));
     if (areg) hipLaunchKernelGGL(knn_tile_kernel<true>, grid, dim3(NTHREADS), lds, stream, prm);
     else hipLaunchKernelGGL(knn_tile_kernel<false>, grid, dim3(NTHREADS), lds, stream, prm);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + NTHREADS / 32 - 1) / (NTHREADS / 32))), dim3(NTHREADS), 0,
