@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
                 }
         }
     }
-    __syncthreads();       // (vmcnt(0)) An/Bn landed, G complete
+    sync_after_lds_dma();  // An/Bn landed, G complete
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- dAn = G . Bn  and  dBn = G^T . An   on v_mfma_f32_16x16x4_f32

@@ -5,6 +5,17 @@
 
 namespace stego {
 
+// Workgroup barrier that first drains this wave's LDS-DMA copies.  global_load_lds writes LDS asynchronously and is
+// tracked by vmcnt; the workgroup-scope fence of __syncthreads() only promises lgkmcnt(0), so whether the compiler
+// also waits for vmcnt before the barrier depends on its alias analysis of the LDS reads that follow (it did in most
+// builds of these kernels, not in all).  Every barrier that publishes an async copy to other waves goes through here.
+__device__ __forceinline__ void sync_after_lds_dma()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

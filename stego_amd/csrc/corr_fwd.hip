@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
         zero_acc(accf);
         copies(0);
         for (int t = 0; t < NCH; ++t) {
-            __syncthreads();                     // B1(t): stage t complete (copies: vmcnt(0); gathered B: written before)
+            sync_after_lds_dma();                // B1(t): stage t complete (copies landed; gathered B: written before)
             copies(t + 1);                       // stage NCH = the code operands
             const unsigned char* Ab = stage + (t & 1) * stage_bytes;
             const unsigned char* Bb = sameAB ? Ab : Ab + FSIDE;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
                 mma_chunk_f16x3(reinterpret_cast<const half_t*>(Ab), reinterpret_cast<const half_t*>(Bb), accf, lane, wr, wc);
         }
         zero_acc(accc);
-        __syncthreads();                         // B1(NCH): code stage landed
+        sync_after_lds_dma();                    // B1(NCH): code stage landed
         const unsigned char* Ab = stage + (NCH & 1) * stage_bytes;
         const unsigned char* Bb = sameAB ? Ab : Ab + cside;
         mma_code_f32(reinterpret_cast<const float*>(Ab), reinterpret_cast<const float*>(Bb), prm.KQ, prm.LDK, accc, lane, wr, wc);

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
     for (int c = 0; c < NCH; ++c) {
-        __syncthreads();                                  // chunk c landed (vmcnt(0)); chunk c-1 is free
+        sync_after_lds_dma();                             // chunk c landed; chunk c-1 is free
         if (c + 1 < NCH) issue(c + 1);
         const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * (2 * DC_SIDE));
         const half_t* Bs = As + DC_SIDE / 2;

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
 #pragma unroll
             for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
                 if (c < NCH) {
-                    __syncthreads();                      // stage g landed (vmcnt(0)); stage g-1 is free
+                    sync_after_lds_dma();                 // stage g landed; stage g-1 is free
                     if (g + 1 < nstage) issue(g + 1);
                     if (!(prm.debug & 2)) knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const half_t*>(smem + (g & 1) * STAGE), acc, lane);
                     ++g;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
             }
         } else {
             for (int c = 0; c < NCH; ++c, ++g) {
-                __syncthreads();                          // stage g landed (vmcnt(0)); stage g-1 is free
+                sync_after_lds_dma();                     // stage g landed; stage g-1 is free
                 if (g + 1 < nstage) issue(g + 1);
                 const unsigned char* st = smem + (g & 1) * STAGE;
                 knn_mma_chunk(reinterpret_cast<const half_t*>(st), reinterpret_cast<const half_t*>(st + KNN_SIDE), acc, lane, wave);
