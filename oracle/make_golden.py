@@ -12,6 +12,7 @@ sample()/helper() with those explicit draws reproduces reference forward() bitwi
 """
 import os
 import sys
+from functools import partial
 
 import numpy as np
 import torch
@@ -187,6 +188,35 @@ def knn_case():
     print("knn_small", n, d, k)
 
 
+def vit_case():
+    """The reference backbone itself (src/dino/vision_transformer.py, imported unmodified): a 2-block, 1-head,
+    64-channel ViT with patch 8 on a NON-square 32x48 input (so interpolate_pos_encoding :171-193 runs), seeded
+    weights with the qkv / fc scales raised so that the softmax is peaked and the residual stream grows.
+    Stores the state dict, the input and feat[0] of get_intermediate_feat(n=1) (:225-237) - what
+    DinoFeaturizer.forward consumes at modules.py:88-97."""
+    ref_shim.load_reference_modules()                    # puts /root/reference/src on sys.path
+    from dino import vision_transformer as ref_vit       # noqa: the reference's file
+    torch.manual_seed(33)
+    model = ref_vit.VisionTransformer(img_size=[32], patch_size=8, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4,
+                                      qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    with torch.no_grad():
+        for name, prm in model.named_parameters():       # make every parameter non-trivial (biases / LN are 0 / 1 at init)
+            if prm.dim() == 1:
+                prm.add_(0.1 * torch.randn_like(prm))
+            if "qkv.weight" in name:
+                prm.mul_(12.0)
+            if "fc" in name and prm.dim() == 2:
+                prm.mul_(6.0)
+    model.eval()
+    img = torch.randn(2, 3, 32, 48)
+    with torch.no_grad():
+        feat, attn, qkv = model.get_intermediate_feat(img, n=1)
+    sd = {"sd." + k: v.numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "vit_tiny2.npz"), img=img.numpy(), feat=feat[0].numpy(),
+                        attn_rowmax=attn[0].max(-1)[0].numpy(), **sd)
+    print("vit_tiny2", tuple(feat[0].shape), "max softmax prob: mean %.3f" % attn[0].max(-1)[0].mean().item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -194,6 +224,7 @@ def main():
     primitives_case(M)
     seeded_e2e_case(M)
     knn_case()
+    vit_case()
     # small full-tensor cases (inputs stored); H != W catches x/y swaps, odd K/C catch padding bugs
     run_case(M, "small_default", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=1)
     run_case(M, "small_nopointwise", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=2, cfg_kw=dict(pointwise=False))

@@ -31,9 +31,20 @@ class StegoCorrDesc(Structure):
 
 # name -> (restype, argtypes); every symbol include/stego_corr.h declares
 _P = c_void_p
+class StegoVitDesc(Structure):
+    """include/stego_vit.h"""
+    _fields_ = [(n, c_int32) for n in ("B", "H", "W", "patch", "D", "depth", "heads", "hidden")]
+
+
 _D = POINTER(StegoCorrDesc)
 _M = POINTER(StegoMap)
+_V = POINTER(StegoVitDesc)
 SIGNATURES = {
+    "stego_vit_param_count": (c_int32, [_V]),
+    "stego_vit_weights_bytes": (c_size_t, [_V]),
+    "stego_vit_workspace_bytes": (c_size_t, [_V]),
+    "stego_vit_pack_weights": (c_int32, [_V, POINTER(ctypes.c_void_p), c_int32, _P, c_size_t, _P]),
+    "stego_vit_forward": (c_int32, [_V, _P, _P, _P, _P, c_size_t, _P]),
     "stego_abi_version": (c_int32, []),
     "stego_error_string": (ctypes.c_char_p, [c_int32]),
     "stego_corr_workspace_bytes": (c_size_t, [_D]),

@@ -1,0 +1,701 @@
+// Frozen DINO ViT forward for gfx950 (include/stego_vit.h): the producer of the feature maps the correspondence loss
+// reads.  Reference: src/dino/vision_transformer.py:69-130 (Attention / Mlp / Block), :123-133 (PatchEmbed),
+// :195-205 (prepare_tokens), :225-237 (get_intermediate_feat, n = 1), called from src/modules.py:83-107.
+//
+// Data flow (B images, M = B * ntok token rows, D channels):
+//   im2col -> patch GEMM (+bias +pos) -> fp32 residual stream [M][D]
+//   per block:  LN1 -> fp16 panels -> QKV GEMM (+bias) -> Q,K [b][head][token][64], V^T [b][head][64][token] (fp16)
+//               attention (flash style, S^T = K Q^T so that every per-query statistic lives in one lane)
+//               -> fp16 panels -> proj GEMM (+bias) accumulated into the residual
+//               LN2 -> panels -> FC1 GEMM (+bias, GELU) -> panels -> FC2 GEMM (+bias) accumulated into the residual
+//   final LN -> fp32 tokens [B][ntok][D]
+// "Panel" = the operand image every GEMM stages with linear LDS-DMA copies: [row block of 128][k chunk of 64]
+// [128 rows][72 halves] (64 data + 8 pad: 144-byte rows, conflict-free ds_read_b128), 18 KiB each.  Producers
+// (LayerNorm, attention, the GELU epilogue, im2col) write panels directly, so no GEMM ever re-lays-out its input.
+#include "../../include/stego_vit.h"
+#include "corr_common.h"
+
+namespace stego {
+namespace vit {
+
+constexpr int VP_ROWS = 128;
+constexpr int VP_KC = 64;
+constexpr int VP_LD = 72;
+constexpr int VP_BYTES = VP_ROWS * VP_LD * 2;        // 18432 = 18 x 1 KiB
+constexpr int GEMM_LDS = 4 * VP_BYTES;               // two stages x (A panel + W panel)
+constexpr float LOG2E = 1.4426950408889634f;
+
+enum { EPI_RESID = 0, EPI_EMBED = 1, EPI_GELU = 2, EPI_QKV = 3 };
+
+struct GemmParams {
+    const unsigned char* A;      // panels [mb][nkc]
+    const unsigned char* W;      // panels [nb][nkc]   (rows = output features: nn.Linear weight [out][in])
+    const float* bias;           // [N]
+    int M, N, nkc;
+    float* resid;                // RESID / EMBED: fp32 [rows][D]
+    int ldr;
+    unsigned char* outp;         // GELU: output panels [mb][out_nkc]
+    int out_nkc;
+    half_t* q;                   // QKV outputs
+    half_t* k;
+    half_t* vt;
+    int D, heads, ntok, ntok_pad, hw;
+    float inv_ntok, inv_hw, qscale;
+    const float* pos;            // EMBED: [ntok][D]
+};
+
+__device__ __forceinline__ void lds_copy_kib(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int lane)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + lane * 16),
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------- packing
+// fp32 [R][K] row-major -> panels [ceil(R/128)][K/64], rows beyond R zero.  One thread per 8 columns.
+__global__ void __launch_bounds__(256) vit_pack_kernel(const float* __restrict__ src, int R, int K, unsigned char* __restrict__ dst,
+                                                       int nrb, int nkc)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)nrb * 128 * nkc * 8;
+    if (t >= total) return;
+    const int g = (int)(t & 7);
+    const long long u = t >> 3;
+    const int kc = (int)(u % nkc);
+    const int row = (int)(u / nkc);
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+    if (row < R) {
+        const float* s = src + (size_t)row * K + kc * 64 + g * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+        v = f16x8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+    }
+    unsigned char* d = dst + ((size_t)(row >> 7) * nkc + kc) * VP_BYTES + (((row & 127) * VP_LD) + g * 8) * 2;
+    *reinterpret_cast<f16x8*>(d) = v;
+}
+
+// Patches as GEMM rows (the conv of PatchEmbed, vision_transformer.py:123-133, is a GEMM over k = (c, iy, ix)):
+// img fp32 [B][3][H][W] -> panels [ceil(B*hw/128)][3*ps*ps/64].  One thread per 8 consecutive ix.
+__global__ void __launch_bounds__(256) vit_im2col_kernel(const float* __restrict__ img, int B, int H, int W, int ps,
+                                                         unsigned char* __restrict__ dst, int nrb, int nkc)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)nrb * 128 * nkc * 8;
+    if (t >= total) return;
+    const int g = (int)(t & 7);
+    const long long u = t >> 3;
+    const int kc = (int)(u % nkc);
+    const int row = (int)(u / nkc);
+    const int w = W / ps, hw = (H / ps) * w;
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+    if (row < B * hw) {
+        const int b = row / hw, pi = row - b * hw, py = pi / w, px = pi - py * w;
+        const int k0 = kc * 64 + g * 8, pp = ps * ps;
+        const int c = k0 / pp, rem = k0 - c * pp, iy = rem / ps, ix = rem - iy * ps;
+        const float* s = img + (((size_t)b * 3 + c) * H + (size_t)py * ps + iy) * W + (size_t)px * ps + ix;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s), bb = *reinterpret_cast<const f32x4*>(s + 4);
+        v = f16x8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)bb[0], (half_t)bb[1], (half_t)bb[2], (half_t)bb[3]};
+    }
+    unsigned char* d = dst + ((size_t)(row >> 7) * nkc + kc) * VP_BYTES + (((row & 127) * VP_LD) + g * 8) * 2;
+    *reinterpret_cast<f16x8*>(d) = v;
+}
+
+// Row 0 of every image: cls_token + pos_embed[0] (prepare_tokens, vision_transformer.py:199-203).
+__global__ void __launch_bounds__(256) vit_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid,
+                                                      int B, int D, int ntok)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * D) return;
+    const int b = t / D, n = t - b * D;
+    resid[(size_t)b * ntok * D + n] = cls[n] + pos[n];
+}
+
+// ------------------------------------------------------------------------------------------------- LayerNorm
+// One wave per token row (D <= 768: up to 12 values per lane), fp32 statistics, biased variance (nn.LayerNorm).
+template <bool TO_PANEL>
+__global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int M, int D, float eps,
+                                                            unsigned char* __restrict__ outp, float* __restrict__ outf)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int ni = D >> 6;
+    const float* xr = x + (size_t)m * D;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        v[i] = i < ni ? xr[lane + 64 * i] : 0.f;
+        s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float dlt = i < ni ? v[i] - mean : 0.f;
+        q += dlt * dlt;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        if (i < ni) {
+            const int n = lane + 64 * i;
+            const float y = (v[i] - mean) * rstd * gamma[n] + beta[n];
+            if constexpr (TO_PANEL) {
+                unsigned char* d = outp + ((size_t)(m >> 7) * ni + i) * VP_BYTES + (((m & 127) * VP_LD) + lane) * 2;
+                *reinterpret_cast<half_t*>(d) = (half_t)y;
+            } else {
+                outf[(size_t)m * D + n] = y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- GEMM
+// C[m][n] = sum_k A[m][k] W[n][k]  (+ epilogue), 128 x 128 tile per workgroup, 4 waves x (64 x 64), fp16 operands on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate.  Both operands arrive as panels: one stage = two linear 18 KiB LDS-DMA
+// copies, double buffered; 72 KiB of LDS -> two workgroups per CU.  grid = (n blocks, m blocks): the workgroups that
+// share an A row block are adjacent in launch order, so it is fetched from HBM once.
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) vit_gemm_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nb = blockIdx.x, mb = blockIdx.y;
+    const unsigned char* Ap = p.A + (size_t)mb * p.nkc * VP_BYTES;
+    const unsigned char* Wp = p.W + (size_t)nb * p.nkc * VP_BYTES;
+    auto issue = [&](int c) {
+        unsigned char* dst = smem + (c & 1) * (2 * VP_BYTES);
+        for (int pc = wave; pc < VP_BYTES / 1024; pc += 4) {
+            lds_copy_kib(Ap + (size_t)c * VP_BYTES + pc * 1024, dst + pc * 1024, lane);
+            lds_copy_kib(Wp + (size_t)c * VP_BYTES + pc * 1024, dst + VP_BYTES + pc * 1024, lane);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue(0);
+    const int r = lane & 31, half = lane >> 5;
+    for (int c = 0; c < p.nkc; ++c) {
+        sync_after_lds_dma();                              // chunk c landed; chunk c-1's buffer is free
+        if (c + 1 < p.nkc) issue(c + 1);
+        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * (2 * VP_BYTES));
+        const half_t* Bs = As + VP_BYTES / 2;
+        const half_t* a0p = As + (64 * wr + r) * VP_LD + 8 * half;
+        const half_t* a1p = a0p + 32 * VP_LD;
+        const half_t* b0p = Bs + (64 * wc + r) * VP_LD + 8 * half;
+        const half_t* b1p = b0p + 32 * VP_LD;
+#pragma unroll
+        for (int kk = 0; kk < VP_KC; kk += 16) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(a0p + kk), a1 = *reinterpret_cast<const f16x8*>(a1p + kk);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(b0p + kk), b1 = *reinterpret_cast<const f16x8*>(b1p + kk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue straight from the accumulators.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = nb * 128 + 64 * wc + 32 * ni + r;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        int which = 0, head = 0, d = 0;
+        if constexpr (EPI == EPI_QKV) {
+            which = n / p.D;
+            const int within = n - which * p.D;
+            head = within >> 6;
+            d = within & 63;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 64 * wr + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int m = mb * 128 + row;
+                if (m >= p.M) continue;
+                const float v = acc[mi][ni][e] + bias;
+                if constexpr (EPI == EPI_RESID) {
+                    p.resid[(size_t)m * p.ldr + n] += v;
+                } else if constexpr (EPI == EPI_EMBED) {
+                    const int b = (int)(((float)m + 0.5f) * p.inv_hw);
+                    const int pi = m - b * p.hw;
+                    p.resid[((size_t)b * p.ntok + 1 + pi) * p.ldr + n] = v + p.pos[(size_t)(1 + pi) * p.D + n];
+                } else if constexpr (EPI == EPI_GELU) {
+                    const float g = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // nn.GELU (exact)
+                    unsigned char* o = p.outp + ((size_t)mb * p.out_nkc + (n >> 6)) * VP_BYTES + ((row * VP_LD) + (n & 63)) * 2;
+                    *reinterpret_cast<half_t*>(o) = (half_t)g;
+                } else {
+                    const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
+                    const int t = m - b * p.ntok;
+                    const size_t bh = (size_t)b * p.heads + head;
+                    if (which == 0) p.q[(bh * p.ntok_pad + t) * 64 + d] = (half_t)(v * p.qscale);
+                    else if (which == 1) p.k[(bh * p.ntok_pad + t) * 64 + d] = (half_t)v;
+                    else p.vt[(bh * 64 + d) * p.ntok_pad + t] = (half_t)v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- attention
+// softmax(Q K^T / sqrt(64)) V for one (image, head, 128-query block) per workgroup; each wave owns 32 queries.
+// The scores are computed TRANSPOSED, S^T = K Q^T (keys x queries): in the MFMA result layout a lane then holds one
+// query (column) and 16 of the 32 keys of a block in its registers, so the running max / sum / rescale of the online
+// softmax are per-lane scalars (one exchange with lane^32 per key block) and P^T can be fed back as the B operand of
+// O^T = V^T P^T without leaving the registers: the MFMA sums over k, so any k order works as long as both operands
+// use the same one - V^T is read in the order the accumulator registers happen to hold the keys.
+// K and V^T tiles (64 keys) are shared by the 4 waves through LDS: linear LDS-DMA copies whose SOURCE addresses are
+// permuted (16-byte chunk c of row r lands in slot c ^ ((r >> 1) & 7)) so that the fragment reads are conflict-free
+// without padding.  Q is pre-scaled by log2(e)/8 in the QKV epilogue: p = exp2(s - m).
+struct AttnParams {
+    const half_t* q;
+    const half_t* k;
+    const half_t* vt;
+    unsigned char* outp;         // panels [mb][D/64]: row = b*ntok + query, k chunk = head
+    int out_nkc, heads, ntok, ntok_pad;
+};
+
+__device__ __forceinline__ const unsigned char* swz16(const unsigned char* base, int row, int cb)
+{
+    return base + ((row * 8 + (cb ^ ((row >> 1) & 7))) << 4);
+}
+
+__global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][8192];       // [stage][K | V^T]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * p.heads + h;
+    const half_t* Kg = p.k + bh * p.ntok_pad * 64;
+    const half_t* Vg = p.vt + bh * 64 * p.ntok_pad;
+    const int li = lane & 31, half = lane >> 5;
+    const int q0 = qb * 128 + wave * 32;
+    const int nkb = p.ntok_pad >> 6;
+
+    auto issue = [&](int kb) {
+        for (int pc = wave; pc < 8; pc += 4) {
+            const int s = pc * 64 + lane;
+            const int row = s >> 3, cb = (s & 7) ^ ((row >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + ((size_t)(kb * 64 + row)) * 64 + cb * 8),
+                                             (__attribute__((address_space(3))) void*)(&smem[kb & 1][0][pc * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (size_t)row * p.ntok_pad + kb * 64 + cb * 8),
+                                             (__attribute__((address_space(3))) void*)(&smem[kb & 1][1][pc * 1024]), 16, 0, 0);
+        }
+    };
+    issue(0);
+
+    // Q fragments (B operand of S^T): lane (query li, k half) holds Q[q][8*(2s+half) .. +7]
+    f16x8 qf[4];
+    {
+        const int qrow = min(q0 + li, p.ntok_pad - 1);
+        const half_t* qp = p.q + (bh * p.ntok_pad + qrow) * 64 + 8 * half;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qp + 16 * s);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        sync_after_lds_dma();                              // tile kb landed; tile kb-1's buffer is free
+        if (kb + 1 < nkb) issue(kb + 1);
+        const unsigned char* Ks = &smem[kb & 1][0][0];
+        const unsigned char* Vs = &smem[kb & 1][1][0];
+        // ---- S^T = K Q^T for the 64 keys of this tile
+        f32x16 st[2];
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[kblk][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(swz16(Ks, 32 * kblk + li, 2 * s + half));
+                st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], st[kblk], 0, 0, 0);
+            }
+        }
+        if (kb == nkb - 1) {                               // keys beyond the sequence (the padding of the last tile)
+#pragma unroll
+            for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kb * 64 + 32 * kblk + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    st[kblk][e] = key < p.ntok ? st[kblk][e] : -INFINITY;
+                }
+        }
+        // ---- online softmax: this lane = one query; the other 16 keys of each block sit in lane ^ 32
+        float mloc = st[0][0];
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, st[kblk][e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(mrun, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        mrun = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                st[kblk][e] = __builtin_amdgcn_exp2f(st[kblk][e] - mnew);
+                psum += st[kblk][e];
+            }
+        lrun = lrun * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        // ---- O^T += V^T P^T, 16 keys per MFMA; registers 8j..8j+7 of a 32-key block hold (per k half)
+        //      keys 16j + {0..3} + 4*half and 16j + 8 + {0..3} + 4*half
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int kblk = step >> 1, j = step & 1;
+            f16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[kblk][8 * j + e];
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk) {
+                const int drow = 32 * dblk + li;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(swz16(Vs, drow, 2 * step) + 8 * half);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(swz16(Vs, drow, 2 * step + 1) + 8 * half);
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};
+                const f16x8 a = __builtin_bit_cast(f16x8, packed);
+                o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dblk], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store: O^T[d][q], this lane's query, 4 consecutive d per register group
+    lrun += __shfl_xor(lrun, 32, 64);
+    const float inv = 1.f / lrun;
+    const int qi = q0 + li;
+    if (qi < p.ntok) {
+        const int m = b * p.ntok + qi;
+        unsigned char* orow = p.outp + ((size_t)(m >> 7) * p.out_nkc + h) * VP_BYTES + ((m & 127) * VP_LD) * 2;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dblk + 8 * g + 4 * half;
+                const f16x2 v01 = {(half_t)(o[dblk][4 * g] * inv), (half_t)(o[dblk][4 * g + 1] * inv)};
+                const f16x2 v23 = {(half_t)(o[dblk][4 * g + 2] * inv), (half_t)(o[dblk][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + d0 * 2) = u32x2{__builtin_bit_cast(unsigned, v01), __builtin_bit_cast(unsigned, v23)};
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Layout {                    // byte offsets inside the packed weight blob
+    int ntok, hw, Kp;
+    size_t patch_w, patch_b, cls, pos;
+    struct Blk { size_t ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b; };
+    size_t blk0, blk_stride;       // blocks are identical in size
+    Blk rel;                       // offsets relative to a block's start
+    size_t norm_w, norm_b, total;
+};
+
+int nblk128(int n) { return (n + 127) / 128; }
+
+Layout make_layout(const StegoVitDesc& d)
+{
+    Layout L;
+    L.hw = (d.H / d.patch) * (d.W / d.patch);
+    L.ntok = L.hw + 1;
+    L.Kp = 3 * d.patch * d.patch;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
+    auto panels = [&](int rows, int K) { return (size_t)nblk128(rows) * (K / 64) * VP_BYTES; };
+    L.patch_w = take(panels(d.D, L.Kp));
+    L.patch_b = take((size_t)d.D * 4);
+    L.cls = take((size_t)d.D * 4);
+    L.pos = take((size_t)L.ntok * d.D * 4);
+    L.blk0 = o;
+    const size_t start = o;
+    L.rel.ln1_w = take((size_t)d.D * 4) - start;
+    L.rel.ln1_b = take((size_t)d.D * 4) - start;
+    L.rel.qkv_w = take(panels(3 * d.D, d.D)) - start;
+    L.rel.qkv_b = take((size_t)3 * d.D * 4) - start;
+    L.rel.proj_w = take(panels(d.D, d.D)) - start;
+    L.rel.proj_b = take((size_t)d.D * 4) - start;
+    L.rel.ln2_w = take((size_t)d.D * 4) - start;
+    L.rel.ln2_b = take((size_t)d.D * 4) - start;
+    L.rel.fc1_w = take(panels(d.hidden, d.D)) - start;
+    L.rel.fc1_b = take((size_t)d.hidden * 4) - start;
+    L.rel.fc2_w = take(panels(d.D, d.hidden)) - start;
+    L.rel.fc2_b = take((size_t)d.D * 4) - start;
+    L.blk_stride = o - start;
+    o = start + L.blk_stride * (size_t)d.depth;
+    L.norm_w = take((size_t)d.D * 4);
+    L.norm_b = take((size_t)d.D * 4);
+    L.total = o;
+    return L;
+}
+
+struct Workspace {
+    int M, mb, ntok_pad;
+    size_t resid, xa, ya, ha, q, k, vt, qkv_bytes, total;
+};
+
+Workspace make_workspace(const StegoVitDesc& d, const Layout& L)
+{
+    Workspace w;
+    w.M = d.B * L.ntok;
+    w.mb = nblk128(w.M);
+    w.ntok_pad = (L.ntok + 63) / 64 * 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
+    w.resid = take((size_t)w.M * d.D * 4);
+    w.xa = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
+    w.ya = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
+    const size_t ha_bytes = (size_t)w.mb * (d.hidden / 64) * VP_BYTES;
+    const size_t im_bytes = (size_t)nblk128(d.B * L.hw) * (L.Kp / 64) * VP_BYTES;       // im2col panels alias the MLP buffer
+    w.ha = take(ha_bytes > im_bytes ? ha_bytes : im_bytes);
+    const size_t one = (size_t)d.B * d.heads * w.ntok_pad * 64 * 2;
+    w.q = take(one);
+    w.k = take(one);
+    w.vt = take(one);
+    w.qkv_bytes = o - w.q;
+    w.total = o;
+    return w;
+}
+
+int check_desc(const StegoVitDesc* d)
+{
+    if (!d) return STEGO_ERR_NULL;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->D <= 0 || d->depth <= 0 || d->heads <= 0 || d->hidden <= 0) return STEGO_ERR_SHAPE;
+    if (d->patch != 8 && d->patch != 16) return STEGO_ERR_UNSUPPORTED;
+    if (d->H % d->patch || d->W % d->patch || d->W % 8) return STEGO_ERR_SHAPE;
+    if (d->D % 64 || d->D > 768 || d->hidden % 64 || d->heads * 64 != d->D) return STEGO_ERR_UNSUPPORTED;
+    const long long ntok = (long long)(d->H / d->patch) * (d->W / d->patch) + 1;
+    if ((long long)d->B * ntok >= (1ll << 20)) return STEGO_ERR_UNSUPPORTED;      // row index arithmetic (float reciprocal)
+    return STEGO_OK;
+}
+
+template <int EPI> hipError_t launch_gemm(const GemmParams& p, int mb, hipStream_t stream)
+{
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(nblk128(p.N), mb), dim3(256), GEMM_LDS, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t pack(const float* src, int R, int K, unsigned char* dst, hipStream_t stream)
+{
+    const int nrb = nblk128(R), nkc = K / 64;
+    const long long total = (long long)nrb * 128 * nkc * 8;
+    hipLaunchKernelGGL(vit_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, R, K, dst, nrb, nkc);
+    return hipGetLastError();
+}
+
+}  // namespace vit
+}  // namespace stego
+
+using namespace stego;
+using namespace stego::vit;
+
+#define VIT_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return STEGO_ERR_HIP + (int)e_; \
+    } while (0)
+
+extern "C" {
+
+int32_t stego_vit_param_count(const StegoVitDesc* d) { return d ? 4 + 12 * d->depth + 2 : 0; }
+
+size_t stego_vit_weights_bytes(const StegoVitDesc* d) { return check_desc(d) == STEGO_OK ? make_layout(*d).total : 0; }
+
+size_t stego_vit_workspace_bytes(const StegoVitDesc* d)
+{
+    if (check_desc(d) != STEGO_OK) return 0;
+    const Layout L = make_layout(*d);
+    return make_workspace(*d, L).total;
+}
+
+int stego_vit_pack_weights(const StegoVitDesc* d, const float* const* params, int32_t n_params, void* packed,
+                           size_t packed_bytes, stego_stream_t stream_)
+{
+    const int rc = check_desc(d);
+    if (rc != STEGO_OK) return rc;
+    if (!params || !packed) return STEGO_ERR_NULL;
+    if (n_params != stego_vit_param_count(d)) return STEGO_ERR_SHAPE;
+    for (int i = 0; i < n_params; ++i)
+        if (!params[i]) return STEGO_ERR_NULL;
+    const Layout L = make_layout(*d);
+    if (packed_bytes < L.total) return STEGO_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned char* base = static_cast<unsigned char*>(packed);
+    auto vec = [&](const float* src, size_t off, size_t count) {
+        return hipMemcpyAsync(base + off, src, count * 4, hipMemcpyDeviceToDevice, stream);
+    };
+    const int D = d->D;
+    int i = 0;
+    VIT_TRY(pack(params[i++], D, L.Kp, base + L.patch_w, stream));
+    VIT_TRY(vec(params[i++], L.patch_b, D));
+    VIT_TRY(vec(params[i++], L.cls, D));
+    VIT_TRY(vec(params[i++], L.pos, (size_t)L.ntok * D));
+    for (int l = 0; l < d->depth; ++l) {
+        const size_t s = L.blk0 + L.blk_stride * (size_t)l;
+        VIT_TRY(vec(params[i++], s + L.rel.ln1_w, D));
+        VIT_TRY(vec(params[i++], s + L.rel.ln1_b, D));
+        VIT_TRY(pack(params[i++], 3 * D, D, base + s + L.rel.qkv_w, stream));
+        VIT_TRY(vec(params[i++], s + L.rel.qkv_b, (size_t)3 * D));
+        VIT_TRY(pack(params[i++], D, D, base + s + L.rel.proj_w, stream));
+        VIT_TRY(vec(params[i++], s + L.rel.proj_b, D));
+        VIT_TRY(vec(params[i++], s + L.rel.ln2_w, D));
+        VIT_TRY(vec(params[i++], s + L.rel.ln2_b, D));
+        VIT_TRY(pack(params[i++], d->hidden, D, base + s + L.rel.fc1_w, stream));
+        VIT_TRY(vec(params[i++], s + L.rel.fc1_b, d->hidden));
+        VIT_TRY(pack(params[i++], D, d->hidden, base + s + L.rel.fc2_w, stream));
+        VIT_TRY(vec(params[i++], s + L.rel.fc2_b, D));
+    }
+    VIT_TRY(vec(params[i++], L.norm_w, D));
+    VIT_TRY(vec(params[i++], L.norm_b, D));
+    return STEGO_OK;
+}
+
+int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* img, float* tokens_out, void* workspace,
+                      size_t workspace_bytes, stego_stream_t stream_)
+{
+    const int rc = check_desc(d);
+    if (rc != STEGO_OK) return rc;
+    if (!packed || !img || !tokens_out || !workspace) return STEGO_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
+        (reinterpret_cast<uintptr_t>(packed) & 255))
+        return STEGO_ERR_ALIGN;
+    const Layout L = make_layout(*d);
+    const Workspace w = make_workspace(*d, L);
+    if (workspace_bytes < w.total) return STEGO_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const unsigned char* wb = static_cast<const unsigned char*>(packed);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    const int D = d->D, M = w.M;
+    const float eps = 1e-6f;                                 // norm_layer = partial(nn.LayerNorm, eps=1e-6) (vision_transformer.py:243)
+    auto fvec = [&](size_t off) { return reinterpret_cast<const float*>(wb + off); };
+    float* resid = reinterpret_cast<float*>(ws + w.resid);
+
+    // padding keys of V^T must be finite zeros (0 * garbage could be NaN); Q/K padding is cleared with them
+    VIT_TRY(hipMemsetAsync(ws + w.q, 0, w.qkv_bytes, stream));
+
+    GemmParams g{};
+    g.D = D;
+    g.heads = d->heads;
+    g.ntok = L.ntok;
+    g.ntok_pad = w.ntok_pad;
+    g.hw = L.hw;
+    g.inv_ntok = 1.f / (float)L.ntok;
+    g.inv_hw = 1.f / (float)L.hw;
+    g.qscale = 0.125f * LOG2E;
+    g.resid = resid;
+    g.ldr = D;
+    g.q = reinterpret_cast<half_t*>(ws + w.q);
+    g.k = reinterpret_cast<half_t*>(ws + w.k);
+    g.vt = reinterpret_cast<half_t*>(ws + w.vt);
+
+    // ---- prepare_tokens
+    {
+        const int Mp = d->B * L.hw, nrb = nblk128(Mp), nkc = L.Kp / 64;
+        const long long total = (long long)nrb * 128 * nkc * 8;
+        hipLaunchKernelGGL(vit_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, d->B, d->H, d->W,
+                           d->patch, ws + w.ha, nrb, nkc);
+        VIT_TRY(hipGetLastError());
+        GemmParams e = g;
+        e.A = ws + w.ha;
+        e.W = wb + L.patch_w;
+        e.bias = fvec(L.patch_b);
+        e.M = Mp;
+        e.N = D;
+        e.nkc = nkc;
+        e.pos = fvec(L.pos);
+        VIT_TRY(launch_gemm<EPI_EMBED>(e, nrb, stream));
+        hipLaunchKernelGGL(vit_cls_kernel, dim3((d->B * D + 255) / 256), dim3(256), 0, stream, fvec(L.cls), fvec(L.pos), resid, d->B,
+                           D, L.ntok);
+        VIT_TRY(hipGetLastError());
+    }
+    AttnParams a{};
+    a.q = g.q;
+    a.k = g.k;
+    a.vt = g.vt;
+    a.outp = ws + w.ya;
+    a.out_nkc = D / 64;
+    a.heads = d->heads;
+    a.ntok = L.ntok;
+    a.ntok_pad = w.ntok_pad;
+    const dim3 ln_grid((M + 3) / 4);
+    for (int l = 0; l < d->depth; ++l) {
+        const size_t s = L.blk0 + L.blk_stride * (size_t)l;
+        hipLaunchKernelGGL(vit_layernorm_kernel<true>, ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln1_w),
+                           fvec(s + L.rel.ln1_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        VIT_TRY(hipGetLastError());
+        GemmParams p1 = g;
+        p1.A = ws + w.xa;
+        p1.W = wb + s + L.rel.qkv_w;
+        p1.bias = fvec(s + L.rel.qkv_b);
+        p1.M = M;
+        p1.N = 3 * D;
+        p1.nkc = D / 64;
+        VIT_TRY(launch_gemm<EPI_QKV>(p1, w.mb, stream));
+        hipLaunchKernelGGL(vit_attn_kernel, dim3((L.ntok + 127) / 128, d->heads, d->B), dim3(256), 0, stream, a);
+        VIT_TRY(hipGetLastError());
+        GemmParams p2 = g;
+        p2.A = ws + w.ya;
+        p2.W = wb + s + L.rel.proj_w;
+        p2.bias = fvec(s + L.rel.proj_b);
+        p2.M = M;
+        p2.N = D;
+        p2.nkc = D / 64;
+        VIT_TRY(launch_gemm<EPI_RESID>(p2, w.mb, stream));
+        hipLaunchKernelGGL(vit_layernorm_kernel<true>, ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln2_w),
+                           fvec(s + L.rel.ln2_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        VIT_TRY(hipGetLastError());
+        GemmParams p3 = g;
+        p3.A = ws + w.xa;
+        p3.W = wb + s + L.rel.fc1_w;
+        p3.bias = fvec(s + L.rel.fc1_b);
+        p3.M = M;
+        p3.N = d->hidden;
+        p3.nkc = D / 64;
+        p3.outp = ws + w.ha;
+        p3.out_nkc = d->hidden / 64;
+        VIT_TRY(launch_gemm<EPI_GELU>(p3, w.mb, stream));
+        GemmParams p4 = g;
+        p4.A = ws + w.ha;
+        p4.W = wb + s + L.rel.fc2_w;
+        p4.bias = fvec(s + L.rel.fc2_b);
+        p4.M = M;
+        p4.N = D;
+        p4.nkc = d->hidden / 64;
+        VIT_TRY(launch_gemm<EPI_RESID>(p4, w.mb, stream));
+    }
+    hipLaunchKernelGGL(vit_layernorm_kernel<false>, ln_grid, dim3(256), 0, stream, resid, fvec(L.norm_w), fvec(L.norm_b), M, D, eps,
+                       (unsigned char*)nullptr, tokens_out);
+    VIT_TRY(hipGetLastError());
+    return STEGO_OK;
+}
+
+}  // extern "C"

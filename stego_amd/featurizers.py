@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dino_vit
+from . import dino_vit, vit_native
 
 
 class LambdaLayer(nn.Module):
@@ -49,6 +49,8 @@ class DinoFeaturizer(nn.Module):
         if torch.cuda.is_available():
             self.model.cuda()
         self.dropout = nn.Dropout2d(p=.1)
+        self._native = None           # vit_native.NativeViT, built on first use on a HIP device
+        self.backbone_path = None     # "native" | "torch": which path the last forward took
 
         weights = getattr(cfg, "pretrained_weights", None)
         if weights is not None:
@@ -75,12 +77,33 @@ class DinoFeaturizer(nn.Module):
         return nn.Sequential(nn.Conv2d(in_channels, in_channels, (1, 1)), nn.ReLU(),
                              nn.Conv2d(in_channels, self.dim, (1, 1)))
 
+    def _tokens(self, img, n):
+        """feat[0] (and qkv[0]) of get_intermediate_feat (modules.py:88-89).  On a HIP device the frozen backbone runs
+        on the hand-written kernels of include/stego_vit.h (fp16 matrix-core operands, fp32 accumulate); the torch
+        module is kept for the variants that path does not build: n > 1, feat_type 'KK' (needs the block's qkv),
+        cfg.native_backbone = False, or CPU tensors."""
+        native_ok = (img.is_cuda and n == 1 and self.feat_type == "feat" and img.dtype == torch.float32
+                     and getattr(self.cfg, "native_backbone", True) and vit_native.supported(self.model))
+        if native_ok:
+            if self._native is None:
+                self._native = vit_native.NativeViT(self.model)
+            self.backbone_path = "native"
+            return self._native.forward_tokens(img), None
+        self.backbone_path = "torch"
+        feat, _, qkv = self.model.get_intermediate_feat(img, n=n)
+        return feat[0], qkv[0]
+
+    def load_state_dict(self, *args, **kw):
+        out = super().load_state_dict(*args, **kw)
+        if self._native is not None:
+            self._native.invalidate()                 # re-pack the backbone weights on next use
+        return out
+
     def forward(self, img, n=1, return_class_feat=False):
         self.model.eval()
         with torch.no_grad():
             assert img.shape[2] % self.patch_size == 0 and img.shape[3] % self.patch_size == 0
-            feat, _, qkv = self.model.get_intermediate_feat(img, n=n)
-            feat, qkv = feat[0], qkv[0]
+            feat, qkv = self._tokens(img, n)
             fh, fw = img.shape[2] // self.patch_size, img.shape[3] // self.patch_size
             if return_class_feat:
                 return feat[:, :1, :].reshape(feat.shape[0], 1, 1, -1).permute(0, 3, 1, 2)

@@ -139,15 +139,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 # ------------------------------------------------------------------ C ABI (no compute)
 def _header_functions():
-    src = open(os.path.join(ROOT, "include", "stego_corr.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(stego_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        if h.endswith(".h"):
+            src = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, h)).read(), flags=re.S)
+            names |= set(re.findall(r"\b(stego_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
     lib = capi.load()
     names = _header_functions()
-    assert "stego_corr_fwd" in names and "stego_corr_bwd" in names
+    assert "stego_corr_fwd" in names and "stego_corr_bwd" in names and "stego_vit_forward" in names
     for n in names:
         assert hasattr(lib, n), "libstego_corr.so does not export %s" % n
         assert n in capi.SIGNATURES, "capi.py has no signature for %s" % n
