@@ -22,7 +22,6 @@ constexpr int VP_ROWS = 128;
 constexpr int VP_KC = 64;
 constexpr int VP_LD = 72;
 constexpr int VP_BYTES = VP_ROWS * VP_LD * 2;        // 18432 = 18 x 1 KiB
-constexpr int GEMM_LDS = 4 * VP_BYTES;               // two stages x (A panel + W panel)
 constexpr float LOG2E = 1.4426950408889634f;
 
 enum { EPI_RESID = 0, EPI_EMBED = 1, EPI_GELU = 2, EPI_QKV = 3 };
@@ -159,32 +158,53 @@ __global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------- GEMM
-// C[m][n] = sum_k A[m][k] W[n][k]  (+ epilogue), 128 x 128 tile per workgroup, 4 waves x (64 x 64), fp16 operands on
-// v_mfma_f32_32x32x16_f16, fp32 accumulate.  Both operands arrive as panels: one stage = two linear 18 KiB LDS-DMA
-// copies, double buffered; 72 KiB of LDS -> two workgroups per CU.  grid = (n blocks, m blocks): the workgroups that
-// share an A row block are adjacent in launch order, so it is fetched from HBM once.
+// C[m][n] = sum_k A[m][k] W[n][k]  (+ epilogue): 256 x 192 tile per workgroup (every N of a ViT is a multiple of
+// 192 = 3 x 64), 8 waves as 4 x 2, each 64 x 96 (2 x 3 MFMA blocks, 96 accumulator registers), fp16 operands on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate.  Both operands arrive as panels, so one 64-deep k stage is five linear
+// LDS-DMA copies (two A panels + 192 W rows, 63 KiB), double buffered: 126 KiB of LDS, one workgroup per CU.
+// The first version used 128 x 128 tiles (64 flop per staged byte): its k loop ran at the latency of the copies
+// (~1 us per 64-deep stage for 0.2 us of MFMA work, 230-330 TFLOP/s); this shape stages 97 flop per byte and gives
+// the MFMA stream of one stage about the time the next stage's copies need.
+// Workgroup -> tile map: the workgroups of one XCD (blockIdx % 8) walk the column tiles of the same row tiles, so an
+// A row tile is pulled into one L2 only (round-robin dispatch would send its column tiles to 8 different L2s).
+constexpr int GT_M = 256, GT_N = 192;
+constexpr int GT_STAGE = (GT_M + GT_N) * VP_LD * 2;       // 64512
+constexpr int GT_LDS = 2 * GT_STAGE;
+constexpr int GT_THREADS = 512;
+
 template <int EPI>
-__global__ void __launch_bounds__(256, 2) vit_gemm_kernel(const GemmParams p)
+__global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p, const int mtiles, const int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int nb = blockIdx.x, mb = blockIdx.y;
-    const unsigned char* Ap = p.A + (size_t)mb * p.nkc * VP_BYTES;
-    const unsigned char* Wp = p.W + (size_t)nb * p.nkc * VP_BYTES;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int mt = xcd + 8 * (slot / ntiles), nt = slot % ntiles;
+    if (mt >= mtiles) return;
+    const unsigned char* Ap = p.A + (size_t)(2 * mt) * p.nkc * VP_BYTES;        // row panels 2mt, 2mt+1
+    // the 192 W rows of column tile nt: rows [r0, 128) of panel p0, then the first 192 - (128 - r0) rows of panel p0 + 1
+    const int p0 = (GT_N * nt) >> 7, r0 = (GT_N * nt) & 127;
+    const unsigned char* W0 = p.W + (size_t)p0 * p.nkc * VP_BYTES + r0 * (VP_LD * 2);
+    const unsigned char* W1 = p.W + (size_t)(p0 + 1) * p.nkc * VP_BYTES;
+    const int w0_pieces = (128 - r0) * (VP_LD * 2) / 1024;                      // 18 or 9
     auto issue = [&](int c) {
-        unsigned char* dst = smem + (c & 1) * (2 * VP_BYTES);
-        for (int pc = wave; pc < VP_BYTES / 1024; pc += 4) {
-            lds_copy_kib(Ap + (size_t)c * VP_BYTES + pc * 1024, dst + pc * 1024, lane);
-            lds_copy_kib(Wp + (size_t)c * VP_BYTES + pc * 1024, dst + VP_BYTES + pc * 1024, lane);
+        unsigned char* dst = smem + (c & 1) * GT_STAGE;
+        const size_t ko = (size_t)c * VP_BYTES;
+        for (int pc = wave; pc < 63; pc += 8) {
+            const unsigned char* src;
+            if (pc < 18) src = Ap + ko + pc * 1024;
+            else if (pc < 36) src = Ap + (size_t)p.nkc * VP_BYTES + ko + (pc - 18) * 1024;
+            else if (pc - 36 < w0_pieces) src = W0 + ko + (pc - 36) * 1024;
+            else src = W1 + ko + (pc - 36 - w0_pieces) * 1024;
+            lds_copy_kib(src, dst + pc * 1024, lane);
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     issue(0);
@@ -192,62 +212,135 @@ __global__ void __launch_bounds__(256, 2) vit_gemm_kernel(const GemmParams p)
     for (int c = 0; c < p.nkc; ++c) {
         sync_after_lds_dma();                              // chunk c landed; chunk c-1's buffer is free
         if (c + 1 < p.nkc) issue(c + 1);
-        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * (2 * VP_BYTES));
-        const half_t* Bs = As + VP_BYTES / 2;
-        const half_t* a0p = As + (64 * wr + r) * VP_LD + 8 * half;
-        const half_t* a1p = a0p + 32 * VP_LD;
-        const half_t* b0p = Bs + (64 * wc + r) * VP_LD + 8 * half;
-        const half_t* b1p = b0p + 32 * VP_LD;
+        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * GT_STAGE);
+        const half_t* Bs = As + GT_M * VP_LD;
+        const half_t* ap = As + (64 * wr + r) * VP_LD + 8 * half;
+        const half_t* bp = Bs + (96 * wc + r) * VP_LD + 8 * half;
 #pragma unroll
         for (int kk = 0; kk < VP_KC; kk += 16) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(a0p + kk), a1 = *reinterpret_cast<const f16x8*>(a1p + kk);
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(b0p + kk), b1 = *reinterpret_cast<const f16x8*>(b1p + kk);
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap + kk), a1 = *reinterpret_cast<const f16x8*>(ap + 32 * VP_LD + kk);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(bp + kk), b1 = *reinterpret_cast<const f16x8*>(bp + 32 * VP_LD + kk);
+            const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + 64 * VP_LD + kk);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b2, acc[0][2], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[1][2], 0, 0, 0);
         }
     }
-    // ---- epilogue straight from the accumulators.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // ---- epilogue.  C/D layout of the accumulators: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    if constexpr (EPI == EPI_GELU || EPI == EPI_QKV) {
+        // fp16 outputs go through LDS (the stage buffers are free now) and leave in the layout of their consumer with
+        // wide, coalesced stores.  Storing straight from the accumulators (a lane owns one column: 2-byte stores, 64 B
+        // runs, or fully scattered for V^T) cost more than the whole k loop: 17-24 us of a 31-39 us tile.
+        __syncthreads();
+        half_t* T = reinterpret_cast<half_t*>(smem);
+        constexpr int GRP = GT_M * VP_LD;               // halves per 64-column group region (36 KiB)
+        constexpr int LDV = GT_M + 8;                   // V^T rows: 256 tokens + pad
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = nb * 128 + 64 * wc + 32 * ni + r;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        int which = 0, head = 0, d = 0;
-        if constexpr (EPI == EPI_QKV) {
-            which = n / p.D;
-            const int within = n - which * p.D;
-            head = within >> 6;
-            d = within & 63;
+        for (int ni = 0; ni < 3; ++ni) {
+            const int col = 96 * wc + 32 * ni + r, cg = col >> 6, cl = col & 63;
+            const int n = nt * GT_N + col;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            const int n0 = nt * GT_N + 64 * cg;         // first column of this lane's 64-column group (wave-uniform)
+            const int which = EPI == EPI_QKV ? n0 / p.D : 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 64 * wr + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const float v = acc[mi][ni][e] + bias;
+                    if constexpr (EPI == EPI_GELU) {
+                        // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below the
+                        // fp16 rounding of the result; ocml erff is ~3x the instructions)
+                        const float x = fabsf(v) * 0.70710678118654752f;
+                        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
+                        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+                        const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
+                        const float g = 0.5f * v * (1.f + copysignf(erfa, v));
+                        T[((row >> 7) * 3 + cg) * (VP_ROWS * VP_LD) + (row & 127) * VP_LD + cl] = (half_t)g;
+                    } else {
+                        if (which == 2) T[cg * GRP + cl * LDV + row] = (half_t)v;
+                        else T[cg * GRP + row * VP_LD + cl] = (half_t)(which == 0 ? v * p.qscale : v);
+                    }
+                }
         }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = 64 * wr + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
-                const int m = mb * 128 + row;
-                if (m >= p.M) continue;
-                const float v = acc[mi][ni][e] + bias;
-                if constexpr (EPI == EPI_RESID) {
-                    p.resid[(size_t)m * p.ldr + n] += v;
-                } else if constexpr (EPI == EPI_EMBED) {
-                    const int b = (int)(((float)m + 0.5f) * p.inv_hw);
-                    const int pi = m - b * p.hw;
-                    p.resid[((size_t)b * p.ntok + 1 + pi) * p.ldr + n] = v + p.pos[(size_t)(1 + pi) * p.D + n];
-                } else if constexpr (EPI == EPI_GELU) {
-                    const float g = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // nn.GELU (exact)
-                    unsigned char* o = p.outp + ((size_t)mb * p.out_nkc + (n >> 6)) * VP_BYTES + ((row * VP_LD) + (n & 63)) * 2;
-                    *reinterpret_cast<half_t*>(o) = (half_t)g;
-                } else {
-                    const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
-                    const int t = m - b * p.ntok;
-                    const size_t bh = (size_t)b * p.heads + head;
-                    if (which == 0) p.q[(bh * p.ntok_pad + t) * 64 + d] = (half_t)(v * p.qscale);
-                    else if (which == 1) p.k[(bh * p.ntok_pad + t) * 64 + d] = (half_t)v;
-                    else p.vt[(bh * 64 + d) * p.ntok_pad + t] = (half_t)v;
+        __syncthreads();
+        if constexpr (EPI == EPI_GELU) {
+            // the six [128][72] images are panels already: linear 16-byte copies
+            for (int img = 0; img < 6; ++img) {
+                const int pr = img / 3, kc = nt * 3 + img % 3;
+                if (kc >= p.out_nkc) continue;
+                unsigned char* dst = p.outp + ((size_t)(2 * mt + pr) * p.out_nkc + kc) * VP_BYTES;
+                const unsigned char* src = smem + img * VP_BYTES;
+                for (int i = tid; i < VP_BYTES / 16; i += GT_THREADS)
+                    *reinterpret_cast<f32x4*>(dst + i * 16) = *reinterpret_cast<const f32x4*>(src + i * 16);
+            }
+        } else {
+            for (int cg = 0; cg < 3; ++cg) {
+                const int n0 = nt * GT_N + 64 * cg;
+                if (n0 >= p.N) continue;
+                const int which = n0 / p.D, head = (n0 - which * p.D) >> 6;
+                if (which < 2) {                     // Q / K: [b][head][token][64], one 128-byte row per token
+                    half_t* dstb = which == 0 ? p.q : p.k;
+                    for (int i = tid; i < GT_M * 8; i += GT_THREADS) {
+                        const int row = i >> 3, ch = i & 7;
+                        const int m = mt * GT_M + row;
+                        if (m >= p.M) continue;
+                        const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
+                        const int t = m - b * p.ntok;
+                        half_t* dst = dstb + (((size_t)b * p.heads + head) * p.ntok_pad + t) * 64 + ch * 8;
+                        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(T + cg * GRP + row * VP_LD + ch * 8);
+                    }
+                } else {                             // V^T: [b][head][64][token]; lanes run along the tokens
+                    const int row = tid & (GT_M - 1);
+                    const int m = mt * GT_M + row;
+                    if (m < p.M) {
+                        const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
+                        const int t = m - b * p.ntok;
+                        half_t* dst = p.vt + (((size_t)b * p.heads + head) * 64) * p.ntok_pad + t;
+                        for (int d = tid >> 8; d < 64; d += GT_THREADS / GT_M)
+                            dst[(size_t)d * p.ntok_pad] = T[cg * GRP + d * LDV + row];
+                    }
                 }
             }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            const int n = nt * GT_N + 96 * wc + 32 * ni + r;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int mbase = mt * GT_M + 64 * wr + 32 * mi + 4 * half;
+                if constexpr (EPI == EPI_RESID) {
+                    // all 16 loads first: interleaved read-modify-writes through one pointer would be serialised by
+                    // the compiler (every load ordered behind the previous store), one memory round trip each
+                    float old[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        old[e] = m < p.M ? p.resid[(size_t)m * p.ldr + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        if (m < p.M) p.resid[(size_t)m * p.ldr + n] = old[e] + acc[mi][ni][e] + bias;
+                    }
+                } else {                              // EPI_EMBED: patch rows -> token rows 1.. of their image, + pos_embed
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        if (m >= p.M) continue;
+                        const int b = (int)(((float)m + 0.5f) * p.inv_hw);
+                        const int pi = m - b * p.hw;
+                        p.resid[((size_t)b * p.ntok + 1 + pi) * p.ldr + n] = acc[mi][ni][e] + bias + p.pos[(size_t)(1 + pi) * p.D + n];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -415,6 +508,9 @@ struct Layout {                    // byte offsets inside the packed weight blob
 };
 
 int nblk128(int n) { return (n + 127) / 128; }
+int ntiles192(int n) { return (n + 191) / 192; }
+int wpanels(int rows) { return nblk128(ntiles192(rows) * 192); }       // weight panels incl. the padding of the last column tile
+int apanels(int rows) { return (rows + 255) / 256 * 2; }               // activation panels: whole 256-row tiles
 
 Layout make_layout(const StegoVitDesc& d)
 {
@@ -424,7 +520,8 @@ Layout make_layout(const StegoVitDesc& d)
     L.Kp = 3 * d.patch * d.patch;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
-    auto panels = [&](int rows, int K) { return (size_t)nblk128(rows) * (K / 64) * VP_BYTES; };
+    // weight panels cover whole 192-row column tiles of the GEMM (rows beyond the matrix are zero)
+    auto panels = [&](int rows, int K) { return (size_t)wpanels(rows) * (K / 64) * VP_BYTES; };
     L.patch_w = take(panels(d.D, L.Kp));
     L.patch_b = take((size_t)d.D * 4);
     L.cls = take((size_t)d.D * 4);
@@ -460,7 +557,7 @@ Workspace make_workspace(const StegoVitDesc& d, const Layout& L)
 {
     Workspace w;
     w.M = d.B * L.ntok;
-    w.mb = nblk128(w.M);
+    w.mb = apanels(w.M);
     w.ntok_pad = (L.ntok + 63) / 64 * 64;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
@@ -468,7 +565,7 @@ Workspace make_workspace(const StegoVitDesc& d, const Layout& L)
     w.xa = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
     w.ya = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
     const size_t ha_bytes = (size_t)w.mb * (d.hidden / 64) * VP_BYTES;
-    const size_t im_bytes = (size_t)nblk128(d.B * L.hw) * (L.Kp / 64) * VP_BYTES;       // im2col panels alias the MLP buffer
+    const size_t im_bytes = (size_t)apanels(d.B * L.hw) * (L.Kp / 64) * VP_BYTES;       // im2col panels alias the MLP buffer
     w.ha = take(ha_bytes > im_bytes ? ha_bytes : im_bytes);
     const size_t one = (size_t)d.B * d.heads * w.ntok_pad * 64 * 2;
     w.q = take(one);
@@ -491,22 +588,24 @@ int check_desc(const StegoVitDesc* d)
     return STEGO_OK;
 }
 
-template <int EPI> hipError_t launch_gemm(const GemmParams& p, int mb, hipStream_t stream)
+template <int EPI> hipError_t launch_gemm(const GemmParams& p, hipStream_t stream)
 {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(nblk128(p.N), mb), dim3(256), GEMM_LDS, stream, p);
+    const int mtiles = (p.M + GT_M - 1) / GT_M, ntiles = ntiles192(p.N);
+    const int grid = 8 * ((mtiles + 7) / 8) * ntiles;
+    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(grid), dim3(GT_THREADS), GT_LDS, stream, p, mtiles, ntiles);
     return hipGetLastError();
 }
 
 hipError_t pack(const float* src, int R, int K, unsigned char* dst, hipStream_t stream)
 {
-    const int nrb = nblk128(R), nkc = K / 64;
+    const int nrb = wpanels(R), nkc = K / 64;
     const long long total = (long long)nrb * 128 * nkc * 8;
     hipLaunchKernelGGL(vit_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, R, K, dst, nrb, nkc);
     return hipGetLastError();
@@ -619,7 +718,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
 
     // ---- prepare_tokens
     {
-        const int Mp = d->B * L.hw, nrb = nblk128(Mp), nkc = L.Kp / 64;
+        const int Mp = d->B * L.hw, nrb = apanels(Mp), nkc = L.Kp / 64;
         const long long total = (long long)nrb * 128 * nkc * 8;
         hipLaunchKernelGGL(vit_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, d->B, d->H, d->W,
                            d->patch, ws + w.ha, nrb, nkc);
@@ -632,7 +731,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         e.N = D;
         e.nkc = nkc;
         e.pos = fvec(L.pos);
-        VIT_TRY(launch_gemm<EPI_EMBED>(e, nrb, stream));
+        VIT_TRY(launch_gemm<EPI_EMBED>(e, stream));
         hipLaunchKernelGGL(vit_cls_kernel, dim3((d->B * D + 255) / 256), dim3(256), 0, stream, fvec(L.cls), fvec(L.pos), resid, d->B,
                            D, L.ntok);
         VIT_TRY(hipGetLastError());
@@ -659,7 +758,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p1.M = M;
         p1.N = 3 * D;
         p1.nkc = D / 64;
-        VIT_TRY(launch_gemm<EPI_QKV>(p1, w.mb, stream));
+        VIT_TRY(launch_gemm<EPI_QKV>(p1, stream));
         hipLaunchKernelGGL(vit_attn_kernel, dim3((L.ntok + 127) / 128, d->heads, d->B), dim3(256), 0, stream, a);
         VIT_TRY(hipGetLastError());
         GemmParams p2 = g;
@@ -669,7 +768,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p2.M = M;
         p2.N = D;
         p2.nkc = D / 64;
-        VIT_TRY(launch_gemm<EPI_RESID>(p2, w.mb, stream));
+        VIT_TRY(launch_gemm<EPI_RESID>(p2, stream));
         hipLaunchKernelGGL(vit_layernorm_kernel<true>, ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln2_w),
                            fvec(s + L.rel.ln2_b), M, D, eps, ws + w.xa, (float*)nullptr);
         VIT_TRY(hipGetLastError());
@@ -682,7 +781,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p3.nkc = D / 64;
         p3.outp = ws + w.ha;
         p3.out_nkc = d->hidden / 64;
-        VIT_TRY(launch_gemm<EPI_GELU>(p3, w.mb, stream));
+        VIT_TRY(launch_gemm<EPI_GELU>(p3, stream));
         GemmParams p4 = g;
         p4.A = ws + w.ha;
         p4.W = wb + s + L.rel.fc2_w;
@@ -690,7 +789,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p4.M = M;
         p4.N = D;
         p4.nkc = d->hidden / 64;
-        VIT_TRY(launch_gemm<EPI_RESID>(p4, w.mb, stream));
+        VIT_TRY(launch_gemm<EPI_RESID>(p4, stream));
     }
     hipLaunchKernelGGL(vit_layernorm_kernel<false>, ln_grid, dim3(256), 0, stream, resid, fvec(L.norm_w), fvec(L.norm_b), M, D, eps,
                        (unsigned char*)nullptr, tokens_out);
