@@ -12,6 +12,9 @@
 // "Panel" = the operand image every GEMM stages with linear LDS-DMA copies: [row block of 128][k chunk of 64]
 // [128 rows][72 halves] (64 data + 8 pad: 144-byte rows, conflict-free ds_read_b128), 18 KiB each.  Producers
 // (LayerNorm, attention, the GELU epilogue, im2col) write panels directly, so no GEMM ever re-lays-out its input.
+#include <cstdlib>
+#include <type_traits>
+
 #include "../../include/stego_vit.h"
 #include "corr_common.h"
 
@@ -41,6 +44,7 @@ struct GemmParams {
     int D, heads, ntok, ntok_pad, hw;
     float inv_ntok, inv_hw, qscale;
     const float* pos;            // EMBED: [ntok][D]
+    int debug;                   // STEGO_DEBUG_VIT ablations: 1 = no MFMAs, 2 = no stage copies after the first, 4 = no epilogue
 };
 
 __device__ __forceinline__ void lds_copy_kib(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int lane)
@@ -169,11 +173,11 @@ __global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restr
 // A row tile is pulled into one L2 only (round-robin dispatch would send its column tiles to 8 different L2s).
 constexpr int GT_M = 256, GT_N = 192;
 constexpr int GT_STAGE = (GT_M + GT_N) * VP_LD * 2;       // 64512
-constexpr int GT_LDS = 2 * GT_STAGE;
+constexpr int GT_LDS = GT_STAGE;                         // ONE stage per workgroup, two workgroups per CU (see below)
 constexpr int GT_THREADS = 512;
 
 template <int EPI>
-__global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p, const int mtiles, const int ntiles)
+__global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParams p, const int mtiles, const int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -189,7 +193,7 @@ __global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p
     const unsigned char* W1 = p.W + (size_t)(p0 + 1) * p.nkc * VP_BYTES;
     const int w0_pieces = (128 - r0) * (VP_LD * 2) / 1024;                      // 18 or 9
     auto issue = [&](int c) {
-        unsigned char* dst = smem + (c & 1) * GT_STAGE;
+        unsigned char* dst = smem;
         const size_t ko = (size_t)c * VP_BYTES;
         for (int pc = wave; pc < 63; pc += 8) {
             const unsigned char* src;
@@ -207,12 +211,16 @@ __global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    issue(0);
     const int r = lane & 31, half = lane >> 5;
     for (int c = 0; c < p.nkc; ++c) {
-        sync_after_lds_dma();                              // chunk c landed; chunk c-1's buffer is free
-        if (c + 1 < p.nkc) issue(c + 1);
-        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * GT_STAGE);
+        // One stage per workgroup and no prefetch inside it: the copies of a stage are hidden by the OTHER workgroup of
+        // this CU, which is in its MFMAs or its epilogue meanwhile (two 63 KiB stages + the epilogue parks fit the LDS
+        // only this way; a double-buffered single workgroup per CU left the CU idle during every epilogue).
+        if (c > 0) __syncthreads();                        // everyone is done reading chunk c-1
+        if (c == 0 || !(p.debug & 2)) issue(c);
+        sync_after_lds_dma();                              // chunk c landed
+        if (p.debug & 1) continue;
+        const half_t* As = reinterpret_cast<const half_t*>(smem);
         const half_t* Bs = As + GT_M * VP_LD;
         const half_t* ap = As + (64 * wr + r) * VP_LD + 8 * half;
         const half_t* bp = Bs + (96 * wc + r) * VP_LD + 8 * half;
@@ -230,78 +238,89 @@ __global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p
         }
     }
     // ---- epilogue.  C/D layout of the accumulators: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    if ((p.debug & 4) && acc[0][0][0] != 12345.678f) return;
     if constexpr (EPI == EPI_GELU || EPI == EPI_QKV) {
-        // fp16 outputs go through LDS (the stage buffers are free now) and leave in the layout of their consumer with
-        // wide, coalesced stores.  Storing straight from the accumulators (a lane owns one column: 2-byte stores, 64 B
-        // runs, or fully scattered for V^T) cost more than the whole k loop: 17-24 us of a 31-39 us tile.
-        __syncthreads();
+        // fp16 outputs go through LDS (the stage buffer is free now) and leave in the layout of their consumer with
+        // wide, coalesced stores, 128 rows per pass.  Storing straight from the accumulators (a lane owns one column:
+        // 2-byte stores, 64 B runs, or fully scattered for V^T) cost more than the whole k loop.
         half_t* T = reinterpret_cast<half_t*>(smem);
-        constexpr int GRP = GT_M * VP_LD;               // halves per 64-column group region (36 KiB)
-        constexpr int LDV = GT_M + 8;                   // V^T rows: 256 tokens + pad
+        constexpr int GRP = VP_ROWS * VP_LD;            // halves per 64-column group region of one pass (18 KiB)
+        constexpr int LDV = VP_ROWS + 8;                // V^T rows: 128 tokens + pad
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();                            // stage buffer / previous pass's park region is free
+            if ((wr >> 1) == pass) {
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni) {
-            const int col = 96 * wc + 32 * ni + r, cg = col >> 6, cl = col & 63;
-            const int n = nt * GT_N + col;
-            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-            const int n0 = nt * GT_N + 64 * cg;         // first column of this lane's 64-column group (wave-uniform)
-            const int which = EPI == EPI_QKV ? n0 / p.D : 0;
+                for (int ni = 0; ni < 3; ++ni) {
+                    const int col = 96 * wc + 32 * ni + r, cg = col >> 6, cl = col & 63;
+                    const int n = nt * GT_N + col;
+                    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+                    const int n0 = nt * GT_N + 64 * cg;     // first column of this lane's 64-column group (wave-uniform)
+                    const int which = EPI == EPI_QKV ? n0 / p.D : 0;
+                    const float oscale = which == 0 && EPI == EPI_QKV ? p.qscale : 1.f;
+                    auto park = [&](auto transposed) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = 64 * wr + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    const float v = acc[mi][ni][e] + bias;
-                    if constexpr (EPI == EPI_GELU) {
-                        // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below the
-                        // fp16 rounding of the result; ocml erff is ~3x the instructions)
-                        const float x = fabsf(v) * 0.70710678118654752f;
-                        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
-                        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-                        const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
-                        const float g = 0.5f * v * (1.f + copysignf(erfa, v));
-                        T[((row >> 7) * 3 + cg) * (VP_ROWS * VP_LD) + (row & 127) * VP_LD + cl] = (half_t)g;
-                    } else {
-                        if (which == 2) T[cg * GRP + cl * LDV + row] = (half_t)v;
-                        else T[cg * GRP + row * VP_LD + cl] = (half_t)(which == 0 ? v * p.qscale : v);
-                    }
+                            for (int e = 0; e < 16; ++e) {
+                                const int lrow = 64 * (wr & 1) + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
+                                const float v = acc[mi][ni][e] + bias;
+                                if constexpr (EPI == EPI_GELU) {
+                                    // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far
+                                    // below the fp16 rounding of the result; ocml erff is ~3x the instructions)
+                                    const float x = fabsf(v) * 0.70710678118654752f;
+                                    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
+                                    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+                                    const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
+                                    const float g = 0.5f * v * (1.f + copysignf(erfa, v));
+                                    T[cg * GRP + lrow * VP_LD + cl] = (half_t)g;
+                                } else if constexpr (decltype(transposed)::value) {
+                                    T[cg * GRP + cl * LDV + lrow] = (half_t)v;               // V^T
+                                } else {
+                                    T[cg * GRP + lrow * VP_LD + cl] = (half_t)(v * oscale);   // Q (pre-scaled), K
+                                }
+                            }
+                    };
+                    if (EPI == EPI_QKV && which == 2) park(std::true_type{});
+                    else park(std::false_type{});
                 }
-        }
-        __syncthreads();
-        if constexpr (EPI == EPI_GELU) {
-            // the six [128][72] images are panels already: linear 16-byte copies
-            for (int img = 0; img < 6; ++img) {
-                const int pr = img / 3, kc = nt * 3 + img % 3;
-                if (kc >= p.out_nkc) continue;
-                unsigned char* dst = p.outp + ((size_t)(2 * mt + pr) * p.out_nkc + kc) * VP_BYTES;
-                const unsigned char* src = smem + img * VP_BYTES;
-                for (int i = tid; i < VP_BYTES / 16; i += GT_THREADS)
-                    *reinterpret_cast<f32x4*>(dst + i * 16) = *reinterpret_cast<const f32x4*>(src + i * 16);
             }
-        } else {
-            for (int cg = 0; cg < 3; ++cg) {
-                const int n0 = nt * GT_N + 64 * cg;
-                if (n0 >= p.N) continue;
-                const int which = n0 / p.D, head = (n0 - which * p.D) >> 6;
-                if (which < 2) {                     // Q / K: [b][head][token][64], one 128-byte row per token
-                    half_t* dstb = which == 0 ? p.q : p.k;
-                    for (int i = tid; i < GT_M * 8; i += GT_THREADS) {
-                        const int row = i >> 3, ch = i & 7;
-                        const int m = mt * GT_M + row;
-                        if (m >= p.M) continue;
-                        const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
-                        const int t = m - b * p.ntok;
-                        half_t* dst = dstb + (((size_t)b * p.heads + head) * p.ntok_pad + t) * 64 + ch * 8;
-                        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(T + cg * GRP + row * VP_LD + ch * 8);
-                    }
-                } else {                             // V^T: [b][head][64][token]; lanes run along the tokens
-                    const int row = tid & (GT_M - 1);
-                    const int m = mt * GT_M + row;
-                    if (m < p.M) {
-                        const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
-                        const int t = m - b * p.ntok;
-                        half_t* dst = p.vt + (((size_t)b * p.heads + head) * 64) * p.ntok_pad + t;
-                        for (int d = tid >> 8; d < 64; d += GT_THREADS / GT_M)
-                            dst[(size_t)d * p.ntok_pad] = T[cg * GRP + d * LDV + row];
+            __syncthreads();
+            if constexpr (EPI == EPI_GELU) {
+                // the three [128][72] images are panels already: linear 16-byte copies
+                for (int cg = 0; cg < 3; ++cg) {
+                    const int kc = nt * 3 + cg;
+                    if (kc >= p.out_nkc) continue;
+                    unsigned char* dst = p.outp + ((size_t)(2 * mt + pass) * p.out_nkc + kc) * VP_BYTES;
+                    const unsigned char* src = smem + cg * VP_BYTES;
+                    for (int i = tid; i < VP_BYTES / 16; i += GT_THREADS)
+                        *reinterpret_cast<f32x4*>(dst + i * 16) = *reinterpret_cast<const f32x4*>(src + i * 16);
+                }
+            } else {
+                for (int cg = 0; cg < 3; ++cg) {
+                    const int n0 = nt * GT_N + 64 * cg;
+                    if (n0 >= p.N) continue;
+                    const int which = n0 / p.D, head = (n0 - which * p.D) >> 6;
+                    if (which < 2) {                     // Q / K: [b][head][token][64], one 128-byte row per token
+                        half_t* dstb = which == 0 ? p.q : p.k;
+                        for (int i = tid; i < VP_ROWS * 8; i += GT_THREADS) {
+                            const int lrow = i >> 3, ch = i & 7;
+                            const int m = mt * GT_M + 128 * pass + lrow;
+                            if (m >= p.M) continue;
+                            const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
+                            const int t = m - b * p.ntok;
+                            half_t* dst = dstb + (((size_t)b * p.heads + head) * p.ntok_pad + t) * 64 + ch * 8;
+                            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(T + cg * GRP + lrow * VP_LD + ch * 8);
+                        }
+                    } else {                             // V^T: [b][head][64][token]; lanes run along the tokens
+                        const int lrow = tid & (VP_ROWS - 1);
+                        const int m = mt * GT_M + 128 * pass + lrow;
+                        if (m < p.M) {
+                            const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
+                            const int t = m - b * p.ntok;
+                            half_t* dst = p.vt + (((size_t)b * p.heads + head) * 64) * p.ntok_pad + t;
+                            for (int d = tid >> 7; d < 64; d += GT_THREADS / VP_ROWS)
+                                dst[(size_t)d * p.ntok_pad] = T[cg * GRP + d * LDV + lrow];
+                        }
                     }
                 }
             }
@@ -318,16 +337,20 @@ __global__ void __launch_bounds__(GT_THREADS) vit_gemm_kernel(const GemmParams p
                 if constexpr (EPI == EPI_RESID) {
                     // all 16 loads first: interleaved read-modify-writes through one pointer would be serialised by
                     // the compiler (every load ordered behind the previous store), one memory round trip each
-                    float old[16];
+                    // 8 loads at a time (16 would push the kernel past 128 VGPRs = two workgroups per CU)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = mbase + (e & 3) + 8 * (e >> 2);
-                        old[e] = m < p.M ? p.resid[(size_t)m * p.ldr + n] : 0.f;
-                    }
+                    for (int e0 = 0; e0 < 16; e0 += 8) {
+                        float old[8];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = mbase + (e & 3) + 8 * (e >> 2);
-                        if (m < p.M) p.resid[(size_t)m * p.ldr + n] = old[e] + acc[mi][ni][e] + bias;
+                        for (int e = 0; e < 8; ++e) {
+                            const int m = mbase + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            old[e] = m < p.M ? p.resid[(size_t)m * p.ldr + n] : 0.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int m = mbase + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            if (m < p.M) p.resid[(size_t)m * p.ldr + n] = old[e] + acc[mi][ni][e0 + e] + bias;
+                        }
                     }
                 } else {                              // EPI_EMBED: patch rows -> token rows 1.. of their image, + pos_embed
 #pragma unroll
@@ -702,6 +725,10 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     VIT_TRY(hipMemsetAsync(ws + w.q, 0, w.qkv_bytes, stream));
 
     GemmParams g{};
+    {
+        const char* e = getenv("STEGO_DEBUG_VIT");
+        g.debug = e ? atoi(e) : 0;
+    }
     g.D = D;
     g.heads = d->heads;
     g.ntok = L.ntok;
