@@ -117,12 +117,42 @@ class DinoFeaturizer(nn.Module):
                 raise ValueError("Unknown feat type:{}".format(self.feat_type))
 
         if self.proj_type is not None:
-            code = self.cluster1(self.dropout(image_feat))
-            if self.proj_type == "nonlinear":
-                code = code + self.cluster2(self.dropout(image_feat))
+            code = self._head(image_feat)
         else:
             code = image_feat
         return (self.dropout(image_feat) if self.cfg.dropout else image_feat), code
+
+    def _feature_noise(self, x):
+        """The channel mask of nn.Dropout2d, drawn exactly as ATen's feature dropout draws it (a [B,C,1,1] tensor filled
+        by bernoulli_(1-p), then divided by 1-p), so a seeded run consumes the generator like the reference's
+        self.dropout(image_feat) at modules.py:109-111."""
+        p = self.dropout.p
+        return x.new_empty(x.shape[0], x.shape[1], 1, 1).bernoulli_(1 - p).div_(1 - p)
+
+    def _head(self, image_feat):
+        """code = cluster1(dropout(f)) [+ cluster2(dropout(f))]  (modules.py:108-112).  The token features arrive as a
+        channels-last view, so the 1x1 convolutions are GEMMs over the token matrix: F.linear with the conv weights
+        viewed as [out, in] (same parameters, same state dict) instead of MIOpen convolutions on a strided NCHW view
+        (measured 2.3 -> see tools/bench_step.py); the code map leaves as a channels-last view too, the layout the loss
+        kernels read with one run per tap."""
+        if image_feat.stride(1) != 1:                      # e.g. feat_type 'KK': plain convolutions
+            code = self.cluster1(self.dropout(image_feat))
+            if self.proj_type == "nonlinear":
+                code = code + self.cluster2(self.dropout(image_feat))
+            return code
+        B, C = image_feat.shape[:2]
+        tok = image_feat.permute(0, 2, 3, 1)               # [B, h, w, C]
+
+        def drop(t):
+            return t * self._feature_noise(image_feat).view(B, 1, 1, C) if self.training else t
+
+        def lin(conv, t):
+            return F.linear(t, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+
+        code = lin(self.cluster1[0], drop(tok))
+        if self.proj_type == "nonlinear":
+            code = code + lin(self.cluster2[2], F.relu(lin(self.cluster2[0], drop(tok))))
+        return code.permute(0, 3, 1, 2)
 
 
 class ResizeAndClassify(nn.Module):

@@ -342,7 +342,8 @@ def test_unsupported_configs_fail_loudly():
         M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
 
 
-def test_training_loop_on_device_matches_cpu_oracle_step():
+@pytest.mark.parametrize("native_backbone", [False, True])
+def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
     """The drop-in surface end to end on the MI355X: LitUnsupervisedSegmenter.training_step (reference
     train_segmentation.py:112-245) with the HIP loss inside, against the same step computed on CPU with the
     oracle-backed backend double (same weights, same batch, same RNG draws fed explicitly)."""
@@ -351,8 +352,11 @@ def test_training_loop_on_device_matches_cpu_oracle_step():
     from stego_amd.train_segmentation import LitUnsupervisedSegmenter, SyntheticContrastiveDataset, load_config
     warnings.filterwarnings("ignore", message="DinoFeaturizer")
     ov = ["model_type=vit_tiny", "dino_patch_size=16", "res=64", "batch_size=4", "feature_samples=5", "neg_samples=2",
-          "dim=10", "dropout=False"]
+          "dim=10", "dropout=False", "native_backbone=%s" % native_backbone]
     cfg = load_config(overrides=ov)
+    # native_backbone=False isolates the loss path (fp32 torch backbone on both sides: 1e-3 bars); True runs the whole
+    # device step on the native kernels, whose fp16-operand backbone moves the features by ~5e-4 (tests/test_vit_native.py)
+    tol = 5.0 if native_backbone else 1.0
     torch.manual_seed(0)
     ref = LitUnsupervisedSegmenter(27, cfg).cpu()            # DinoFeaturizer puts its backbone on the GPU when one exists (modules.py:32)
     ref.net.dropout.p = 0.0                                   # no dropout noise: CPU and GPU RNG streams differ
@@ -360,6 +364,7 @@ def test_training_loop_on_device_matches_cpu_oracle_step():
     dev_model.net.dropout.p = 0.0
     dev_model.load_state_dict(ref.state_dict())
     dev_model.to(DEV)
+    ref_w0 = ref.net.cluster1[0].weight.detach().clone()
     ds = SyntheticContrastiveDataset(4, cfg.res, 27)
     batch = torch.utils.data.default_collate([ds[i] for i in range(4)])
     # identical RNG draws on both sides
@@ -381,9 +386,15 @@ def test_training_loop_on_device_matches_cpu_oracle_step():
     finally:
         M._backend = capi
     loss_dev = dev_model.training_step({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
-    assert abs(float(loss_dev) - float(loss_ref)) < 2e-3 * max(1.0, abs(float(loss_ref)))
+    assert dev_model.net.backbone_path == ("native" if native_backbone else "torch")
+    assert abs(float(loss_dev) - float(loss_ref)) < tol * 2e-3 * max(1.0, abs(float(loss_ref)))
     for k in ("loss/pos_intra", "loss/pos_inter", "loss/neg_inter"):
-        assert abs(float(dev_model.logged[k]) - float(ref.logged[k])) < 1e-3 * max(0.05, abs(float(ref.logged[k]))), k
+        assert abs(float(dev_model.logged[k]) - float(ref.logged[k])) < tol * 1e-3 * max(0.05, abs(float(ref.logged[k]))), k
     w_ref = ref.net.cluster1[0].weight.detach()
     w_dev = dev_model.net.cluster1[0].weight.detach().cpu()
-    assert torch.allclose(w_dev, w_ref, rtol=1e-3, atol=2e-4)          # one Adam step on the head, same direction
+    if not native_backbone:
+        assert torch.allclose(w_dev, w_ref, rtol=1e-3, atol=2e-4)      # one Adam step on the head, same direction
+    else:                                                              # Adam normalises the step: compare directions
+        d_ref = w_ref - ref_w0
+        d_dev = w_dev - ref_w0
+        assert float(torch.nn.functional.cosine_similarity(d_dev.flatten(), d_ref.flatten(), dim=0)) > 0.98

@@ -134,3 +134,31 @@ def test_featurizer_uses_native_backbone_and_feeds_the_loss_layout():
     cls = fz(img, return_class_feat=True)
     assert cls.shape == (2, 384, 1, 1)
     assert code.shape == (2, 70, 28, 28)
+
+
+# ------------------------------------------------------------------ the head that turns the tokens into `code` (CPU)
+@pytest.mark.parametrize("training", [False, True])
+def test_token_gemm_head_equals_the_reference_conv_head(training):
+    """DinoFeaturizer._head runs the 1x1 convolutions of modules.py:108-112 as GEMMs over the channels-last token
+    matrix; same parameters, same Dropout2d draws in the same order (the generator ends up in the same state)."""
+    from stego_amd import featurizers
+
+    class C:
+        dino_patch_size = 8; dino_feat_type = "feat"; model_type = "vit_tiny"; projection_type = "nonlinear"
+        dropout = True; pretrained_weights = None
+    torch.manual_seed(0)
+    fz = featurizers.DinoFeaturizer(70, C()).cpu()
+    fz.train(training)
+    x = torch.randn(3, 10, 11, 192).permute(0, 3, 1, 2)              # channels-last view, like the backbone's tokens
+    torch.manual_seed(5)
+    got = fz._head(x)
+    after_got = torch.rand(1)
+    torch.manual_seed(5)
+    ref = fz.cluster1(fz.dropout(x)) + fz.cluster2(fz.dropout(x))   # the reference's expression
+    after_ref = torch.rand(1)
+    assert got.shape == ref.shape and got.stride(1) == 1
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(after_got, after_ref)
+    g1 = torch.autograd.grad(got.sum(), fz.cluster2[0].weight, retain_graph=True)[0]
+    g2 = torch.autograd.grad(ref.sum(), fz.cluster2[0].weight)[0]
+    assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Where a training step's time goes (BASELINE config 2: B = 32 pairs of 224^2 images, ViT-S/8, dim 70):
+frozen backbone on img + img_pos -> segmentation head -> correspondence loss fwd+bwd -> head backward.
+Compares the native backbone with the torch backbone around the same (native) loss.  One JSON line."""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stego_amd import featurizers, modules
+
+
+class Cfg:
+    dino_patch_size = 8; dino_feat_type = "feat"; model_type = "vit_small"; projection_type = "nonlinear"
+    dropout = True; pretrained_weights = None; native_backbone = True
+    pointwise = True; zero_clamp = True; stabalize = False; use_salience = False
+    feature_samples = 11; neg_samples = 5; pos_intra_shift = .18; pos_inter_shift = .12; neg_inter_shift = .46
+    corr_precision = "f16x3"
+
+
+def timed(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters): fn()
+    t1.record(); torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cfg = Cfg()
+net = featurizers.DinoFeaturizer(70, cfg).to(dev)
+loss_fn = modules.ContrastiveCorrelationLoss(cfg)
+img = torch.randn(B, 3, 224, 224, device=dev); img_pos = torch.randn(B, 3, 224, 224, device=dev)
+both = torch.cat([img, img_pos])
+params = [p for p in net.parameters() if p.requires_grad]
+
+
+def step():
+    feats_all, code_all = net(both)                       # one 2B batch through the frozen backbone + head
+    feats, feats_pos = feats_all[:B], feats_all[B:]
+    code, code_pos = code_all[:B], code_all[B:]
+    out = loss_fn(feats, feats_pos, None, None, code, code_pos)
+    loss = .67 * out[0] + .25 * out[2] + .63 * out[4].mean()
+    for p in params: p.grad = None
+    loss.backward()
+
+
+res = {}
+for native in (True, False):
+    cfg.native_backbone = native
+    key = "native_backbone" if native else "torch_fp32_backbone"
+    with torch.no_grad():
+        bb = timed(lambda: net._tokens(both, 1))
+    res[key] = {"step_ms": timed(step), "backbone_ms": bb, "path": net.backbone_path}
+cfg.native_backbone = True
+feats_all, code_all = net(both)
+code = code_all[:B].detach().requires_grad_(True); code_pos = code_all[B:].detach().requires_grad_(True)
+
+
+def loss_only():
+    out = loss_fn(feats_all[:B], feats_all[B:], None, None, code, code_pos)
+    (.67 * out[0] + .25 * out[2] + .63 * out[4].mean()).backward()
+
+
+res["loss_fwd_bwd_eager_ms"] = timed(loss_only, 30)
+print(json.dumps({"metric": "training step, B=%d pairs, ViT-S/8 224^2 (backbone on 2B images + head + correspondence loss fwd+bwd + head bwd)" % B,
+                  "unit": "ms", **res,
+                  "pairs_per_s_native": B / res["native_backbone"]["step_ms"] * 1e3,
+                  "pairs_per_s_torch_backbone": B / res["torch_fp32_backbone"]["step_ms"] * 1e3}))
