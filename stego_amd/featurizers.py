@@ -27,6 +27,29 @@ class LambdaLayer(nn.Module):
         return self.lambd(x)
 
 
+class _TokenLinear(torch.autograd.Function):
+    """F.linear over a [B, h, w, C] token tensor whose weight gradient is reduced per image first:
+    dW = sum_b dY_b^T X_b as one batched GEMM (K = h*w per image) + a sum over the batch, instead of one GEMM with
+    K = B*h*w = 50 176 and a 70..384-wide output, for which the BLAS library picks a 45 TFLOP/s kernel (1.2 ms per step
+    for the three weight gradients of the head, tools/bench_step.py).  Same math, fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B = x.shape[0]
+        g3 = g.reshape(B, -1, g.shape[-1])
+        gx = g.matmul(w) if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(g3.transpose(1, 2), x.reshape(B, -1, x.shape[-1])).sum(0) if ctx.needs_input_grad[1] else None
+        gb = g3.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 class DinoFeaturizer(nn.Module):
     """Frozen DINO ViT + trainable 1x1-conv segmentation head.  forward(img) -> (feats, code) with
     feats a channels-last strided VIEW [B,C,h,w] of the tokens - the layout the loss kernels want."""
@@ -147,7 +170,7 @@ class DinoFeaturizer(nn.Module):
             return t * self._feature_noise(image_feat).view(B, 1, 1, C) if self.training else t
 
         def lin(conv, t):
-            return F.linear(t, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+            return _TokenLinear.apply(t, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
 
         code = lin(self.cluster1[0], drop(tok))
         if self.proj_type == "nonlinear":
