@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--sets", type=int, default=4, help="input sets rotated (4 x 91 MB > 256 MB Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise RCCL and run the per-step all-reduce even with one rank (exercises the N > 1 path)")
     ap.add_argument("--fwd-only", action="store_true", help="time the forward alone (reported in config)")
     ap.add_argument("--layout", default="cl", choices=["cl", "nchw"],
                     help="cl = channels-last strided views as DinoFeaturizer emits (default); nchw = contiguous NCHW")
@@ -181,8 +183,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
+        if args.force_collective and "RANK" not in os.environ:      # single-process self-test of the N > 1 code path
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
@@ -244,6 +248,8 @@ def main():
                 launch = "eager (graph capture failed: %s)" % type(e).__name__
                 torch.cuda.synchronize()
 
+        pending = [None]
+
         def step(k):
             i = k % args.sets
             if graphs is not None:
@@ -251,14 +257,25 @@ def main():
             else:
                 step_compute(i)
             if dist is not None:
-                dist.all_reduce(grad_buf)               # gradients of the segmentation head only (backbone frozen)
+                # gradients of the segmentation head only (backbone frozen): one flat bucket per step.  async_op: RCCL's
+                # stream first waits for this step's kernels, then the all-reduce runs while the next step computes - in
+                # training it overlaps the next step's backbone forward the same way; every all-reduce is complete
+                # before the clock stops (drain()).
+                pending[0] = dist.all_reduce(grad_buf, async_op=True)
+
+        def drain():
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
 
         for k in range(warmup):
             step(k)
+        drain()
         barrier()
         t0 = time.perf_counter()
         for k in range(steps):
             step(k)
+        drain()
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
