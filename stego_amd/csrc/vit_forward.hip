@@ -383,6 +383,7 @@ struct AttnParams {
     const half_t* vt;
     unsigned char* outp;         // panels [mb][D/64]: row = b*ntok + query, k chunk = head
     int out_nkc, heads, ntok, ntok_pad;
+    int nqb, units;              // query blocks per (image, head); number of (image, head) pairs
 };
 
 __device__ __forceinline__ const unsigned char* swz16(const unsigned char* base, int row, int cb)
@@ -395,8 +396,14 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][8192];       // [stage][K | V^T]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const size_t bh = (size_t)b * p.heads + h;
+    // The query blocks of one (image, head) run on ONE XCD (blockIdx % 8), next to each other in launch order, so its K / V^T
+    // are pulled into one L2 once: with a plain (qb, h, b) grid the 7 blocks of a head went to 7 different L2s and the
+    // kernel fetched 599 MB for 116 MB of q, k, v (rocprofv3 FETCH_SIZE), i.e. it ran at the HBM rate.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = xcd + 8 * (slot / p.nqb), qb = slot % p.nqb;
+    if (unit >= p.units) return;
+    const int b = unit / p.heads, h = unit - b * p.heads;
+    const size_t bh = (size_t)unit;
     const half_t* Kg = p.k + bh * p.ntok_pad * 64;
     const half_t* Vg = p.vt + bh * 64 * p.ntok_pad;
     const int li = lane & 31, half = lane >> 5;
@@ -772,6 +779,8 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     a.heads = d->heads;
     a.ntok = L.ntok;
     a.ntok_pad = w.ntok_pad;
+    a.nqb = (L.ntok + 127) / 128;
+    a.units = d->B * d->heads;
     const dim3 ln_grid((M + 3) / 4);
     for (int l = 0; l < d->depth; ++l) {
         const size_t s = L.blk0 + L.blk_stride * (size_t)l;
@@ -786,7 +795,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p1.N = 3 * D;
         p1.nkc = D / 64;
         VIT_TRY(launch_gemm<EPI_QKV>(p1, stream));
-        hipLaunchKernelGGL(vit_attn_kernel, dim3((L.ntok + 127) / 128, d->heads, d->B), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(vit_attn_kernel, dim3(8 * ((a.units + 7) / 8) * a.nqb), dim3(256), 0, stream, a);
         VIT_TRY(hipGetLastError());
         GemmParams p2 = g;
         p2.A = ws + w.ya;

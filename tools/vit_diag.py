@@ -5,7 +5,6 @@ def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm()
 for arch, patch, H, W, B, depth in [("vit_base", 8, 224, 224, 1, 12), ("vit_base", 8, 224, 224, 1, 4), ("vit_small", 8, 224, 224, 2, 12),
                                     ("vit_tiny", 16, 96, 96, 5, 12)]:
     torch.manual_seed(5)
-    model = dino_vit.ARCHS[arch](patch_size=patch, depth=depth).cuda().eval() if False else None
     kw = dict(vit_base=dict(embed_dim=768, num_heads=12), vit_small=dict(embed_dim=384, num_heads=6), vit_tiny=dict(embed_dim=192, num_heads=3))[arch]
     model = dino_vit.VisionTransformer(patch_size=patch, depth=depth, **kw).cuda().eval()
     with torch.no_grad():
