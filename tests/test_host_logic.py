@@ -175,3 +175,49 @@ def test_library_validates_before_enqueueing():
     assert lib.stego_corr_fwd(ctypes.byref(d0), *args_null) == 2          # STEGO_ERR_SHAPE
     assert b"unsupported" in lib.stego_error_string(3)
     assert lib.stego_error_string(0) == b"ok"
+
+
+# ------------------------------------------------------------------ salience-guided coordinates (cfg.use_salience)
+def test_salience_coords_follow_the_reference_draw_order():
+    """modules.py:355-365 + sample_nonzero_locations :298-311: per image one randint over its non-zero salience pixels
+    (or over the whole map if there are none), then rand, rand, rand(mask) - same generator, same order.  When the
+    reference sources are present (build container) the imported reference function is the comparison, otherwise the
+    expected values are restated from those lines."""
+    from oracle import ref_shim
+    cfg = _cfg()
+    cfg.use_salience = True
+    cfg.feature_samples = 5
+    B, H = 3, 12
+    g = torch.Generator().manual_seed(3)
+    sal = (torch.rand(B, H, H, generator=g) > 0.7).float()
+    sal[1] = 0                                                   # an image without salient pixels: uniform randint fallback
+    sal_pos = (torch.rand(B, H, H, generator=g) > 0.5).float()
+    feats = torch.zeros(B, 4, 6, 6)
+    loss = M.ContrastiveCorrelationLoss(cfg)
+
+    torch.manual_seed(11)
+    c1, c2 = loss.draw_coords(feats, sal, sal_pos)
+    after = torch.rand(1)
+
+    torch.manual_seed(11)
+    shape = [B, 5, 5, 2]
+    if ref_shim.available():
+        snl = ref_shim.load_reference_modules().sample_nonzero_locations
+    else:
+        def snl(t, target_size):                                 # restatement of :298-311
+            nz = torch.nonzero(t)
+            coords = torch.zeros(target_size, dtype=nz.dtype)
+            n = target_size[1] * target_size[2]
+            for i in range(t.shape[0]):
+                sel = nz[nz[:, 0] == i]
+                pick = torch.randint(t.shape[1], size=(n, 2)) if sel.shape[0] == 0 else sel[torch.randint(len(sel), size=(n,)), 1:]
+                coords[i] = pick.reshape(target_size[1], target_size[2], 2)
+            return torch.flip(coords.to(torch.float32) / t.shape[1] * 2 - 1, dims=[-1])
+    n1, n2 = snl(sal, shape), snl(sal_pos, shape)
+    r1 = torch.rand(shape) * 2 - 1
+    r2 = torch.rand(shape) * 2 - 1
+    mask = (torch.rand(shape[:-1]) > .1).unsqueeze(-1).to(torch.float32)
+    e1, e2 = n1 * mask + r1 * (1 - mask), n2 * mask + r2 * (1 - mask)
+    assert torch.equal(c1, e1) and torch.equal(c2, e2)
+    assert torch.equal(after, torch.rand(1))                     # generator left in the same state
+    assert c1.min() >= -1 and c1.max() <= 1

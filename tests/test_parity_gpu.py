@@ -334,6 +334,35 @@ def test_on_device_rng_path_equals_explicit_draws():
     assert not (perms == torch.arange(B, device=DEV)).any()
 
 
+def test_salience_path_on_device_matches_oracle():
+    """cfg.use_salience (modules.py:355-365): coordinates come from the salience maps (torch, reference order) and go
+    through the same kernels; compared with the CPU oracle fed the very same coordinates."""
+    B, C, H, W, K = 4, 64, 10, 10, 12
+    cfg = O.CorrCfg(feature_samples=5, neg_samples=2)
+    cfg.use_salience = True
+    g = torch.Generator(device=DEV).manual_seed(8)
+    f = torch.randn(B, C, H, W, device=DEV, generator=g)
+    fp = torch.randn(B, C, H, W, device=DEV, generator=g)
+    c = torch.randn(B, K, H, W, device=DEV, generator=g)
+    cp = torch.randn(B, K, H, W, device=DEV, generator=g)
+    sal = (torch.rand(B, 40, 40, device=DEV, generator=g) > 0.6).float()
+    sal_pos = (torch.rand(B, 40, 40, device=DEV, generator=g) > 0.6).float()
+    sal[2] = 0
+    loss = M.ContrastiveCorrelationLoss(cfg)
+    torch.manual_seed(21)
+    out = loss(f, fp, sal, sal_pos, c, cp)
+    torch.manual_seed(21)
+    coords1, coords2 = loss.draw_coords(f, sal, sal_pos)
+    perms = torch.stack([M.super_perm(B, f.device) for _ in range(2)])
+    assert coords1.abs().max() <= 1 and coords2.abs().max() <= 1
+    ref = O.corr_loss_forward(f.cpu().numpy(), fp.cpu().numpy(), c.cpu().numpy(), cp.cpu().numpy(), coords1.cpu().numpy(),
+                              coords2.cpu().numpy(), perms.cpu().numpy(), cfg)
+    assert_close(out[1].cpu().numpy(), ref.pos_intra_cd, what="pos_intra_cd")
+    assert_close(out[3].cpu().numpy(), ref.pos_inter_cd, what="pos_inter_cd")
+    assert_close(out[4].cpu().numpy(), ref.neg_inter_loss, what="neg_inter_loss")
+    assert_close(out[5].cpu().numpy(), ref.neg_inter_cd, what="neg_inter_cd")
+
+
 def test_unsupported_configs_fail_loudly():
     cfg = O.CorrCfg(feature_samples=12, neg_samples=1)      # 144 sample points > 128
     f = torch.randn(2, 16, 8, 8, device=DEV)
