@@ -239,7 +239,7 @@ def main():
                 graphs = []
                 for i in range(args.sets):
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr):
+                    with torch.cuda.graph(gr, capture_error_mode="thread_local"):     # RCCL's watchdog thread must not break a capture
                         step_compute(i)
                     graphs.append(gr)
                 launch = "hipgraph"
