@@ -437,24 +437,22 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
         for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
 
-    for (int kb = 0; kb < nkb; ++kb) {
+    auto tile = [&](const int kb, auto last_tile) {
         sync_after_lds_dma();                              // tile kb landed; tile kb-1's buffer is free
         if (kb + 1 < nkb) issue(kb + 1);
         const unsigned char* Ks = &smem[kb & 1][0][0];
         const unsigned char* Vs = &smem[kb & 1][1][0];
         // ---- S^T = K Q^T for the 64 keys of this tile
         f32x16 st[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kblk = 0; kblk < 2; ++kblk) {
+        for (int s = 0; s < 4; ++s)                        // the two 32-key accumulators alternate: no MFMA waits for the
 #pragma unroll
-            for (int e = 0; e < 16; ++e) st[kblk][e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int kblk = 0; kblk < 2; ++kblk) {         // result of the one issued just before it
                 const f16x8 a = *reinterpret_cast<const f16x8*>(swz16(Ks, 32 * kblk + li, 2 * s + half));
-                st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], st[kblk], 0, 0, 0);
+                st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], s == 0 ? zero16 : st[kblk], 0, 0, 0);
             }
-        }
-        if (kb == nkb - 1) {                               // keys beyond the sequence (the padding of the last tile)
+        if constexpr (decltype(last_tile)::value) {       // keys beyond the sequence (the padding of the last tile)
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
@@ -505,7 +503,9 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
                 o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dblk], 0, 0, 0);
             }
         }
-    }
+    };
+    for (int kb = 0; kb + 1 < nkb; ++kb) tile(kb, std::false_type{});
+    tile(nkb - 1, std::true_type{});
     // ---- normalise and store: O^T[d][q], this lane's query, 4 consecutive d per register group
     lrun += __shfl_xor(lrun, 32, 64);
     const float inv = 1.f / lrun;
