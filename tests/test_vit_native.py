@@ -52,6 +52,15 @@ def test_vit_abi_validates_on_host():
     assert lib.stego_vit_forward(ctypes.byref(bad), None, None, None, None, 0, None) == 3   # STEGO_ERR_UNSUPPORTED
     odd = capi.StegoVitDesc(4, 220, 224, 8, 384, 12, 6, 1536)
     assert lib.stego_vit_forward(ctypes.byref(odd), None, None, None, None, 0, None) == 2   # STEGO_ERR_SHAPE
+    # argument checks come before any enqueue: (host) dummy pointers are never dereferenced
+    raw = ctypes.create_string_buffer(4096)
+    base = (ctypes.addressof(raw) + 255) // 256 * 256
+    assert lib.stego_vit_forward(ctypes.byref(d), base, base, base, base, 1024, None) == 4        # STEGO_ERR_WORKSPACE
+    assert lib.stego_vit_forward(ctypes.byref(d), base, base + 4, base, base, ws, None) == 5      # STEGO_ERR_ALIGN (img)
+    n = lib.stego_vit_param_count(ctypes.byref(d))
+    arr = (ctypes.c_void_p * n)(*([base] * n))
+    assert lib.stego_vit_pack_weights(ctypes.byref(d), arr, n - 1, base, wb, None) == 2           # wrong parameter count
+    assert lib.stego_vit_pack_weights(ctypes.byref(d), arr, n, base, 16, None) == 4               # blob too small
 
 
 def test_native_vit_refuses_cpu_tensors():
