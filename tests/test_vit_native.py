@@ -171,3 +171,34 @@ def test_token_gemm_head_equals_the_reference_conv_head(training):
     g1 = torch.autograd.grad(got.sum(), fz.cluster2[0].weight, retain_graph=True)[0]
     g2 = torch.autograd.grad(ref.sum(), fz.cluster2[0].weight)[0]
     assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_featurizer_variants_the_native_path_does_not_build_use_the_torch_module():
+    from stego_amd import featurizers
+
+    class C:
+        dino_patch_size = 16; dino_feat_type = "KK"; model_type = "vit_tiny"; projection_type = None
+        dropout = False; pretrained_weights = None
+    fz = featurizers.DinoFeaturizer(70, C()).cuda().eval()
+    img = torch.randn(2, 3, 64, 64, device="cuda")
+    feats, code = fz(img)
+    assert fz.backbone_path == "torch" and feats.shape == (2, 192, 4, 4)        # heads * head_dim channels of the keys
+    C.dino_feat_type = "feat"
+    C.native_backbone = False
+    fz2 = featurizers.DinoFeaturizer(70, C()).cuda().eval()
+    fz2(img)
+    assert fz2.backbone_path == "torch"
+    C.native_backbone = True
+    fz3 = featurizers.DinoFeaturizer(70, C()).cuda().eval()
+    fz3.load_state_dict(fz2.state_dict())
+    a, _ = fz3(img)
+    b, _ = fz2(img)
+    assert fz3.backbone_path == "native"
+    assert _rel(a.cpu(), b.cpu()) < 5e-3
+    # new weights invalidate the packed copy
+    with torch.no_grad():
+        sd = {k: v * 1.5 if "blocks.0.attn.qkv.weight" in k else v for k, v in fz3.state_dict().items()}
+    fz3.load_state_dict(sd)
+    fz2.load_state_dict(sd)
+    assert _rel(fz3(img)[0].cpu(), fz2(img)[0].cpu()) < 5e-3
