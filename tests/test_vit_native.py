@@ -202,3 +202,26 @@ def test_featurizer_variants_the_native_path_does_not_build_use_the_torch_module
     fz3.load_state_dict(sd)
     fz2.load_state_dict(sd)
     assert _rel(fz3(img)[0].cpu(), fz2(img)[0].cpu()) < 5e-3
+
+
+def test_parameter_order_and_shapes_match_the_header_contract():
+    """include/stego_vit.h lists the fp32 tensors stego_vit_pack_weights takes; vit_native._params_of must hand them over
+    in that order with those shapes, including a position table already resized to the input (bicubic, :171-193)."""
+    lib = capi.load()
+    model = dino_vit.vit_small(patch_size=8).eval()
+    H, W = 224, 256                                               # not the training size: pos-embed gets interpolated
+    ps = vit_native._params_of(model, H, W)
+    d = capi.StegoVitDesc(2, H, W, 8, 384, 12, 6, 1536)
+    assert len(ps) == lib.stego_vit_param_count(ctypes.byref(d)) == 150
+    ntok = 1 + (H // 8) * (W // 8)
+    assert [tuple(p.shape) for p in ps[:4]] == [(384, 192), (384,), (384,), (ntok, 384)]
+    blk = [(384,), (384,), (1152, 384), (1152,), (384, 384), (384,), (384,), (384,), (1536, 384), (1536,), (384, 1536), (384,)]
+    for layer in range(12):
+        assert [tuple(p.shape) for p in ps[4 + 12 * layer: 16 + 12 * layer]] == blk, layer
+    assert [tuple(p.shape) for p in ps[-2:]] == [(384,), (384,)]
+    assert all(p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+    # the class-token row of the table is untouched by the resize, the patch rows are not the original ones
+    assert torch.equal(ps[3][0], model.pos_embed[0, 0])
+    probe = torch.empty(1, ntok, 384)
+    assert torch.allclose(ps[3], model.interpolate_pos_encoding(probe, H, W)[0])
+    assert vit_native.supported(model) and not vit_native.supported(dino_vit.VisionTransformer(patch_size=8, embed_dim=96, depth=1, num_heads=3))
