@@ -141,3 +141,32 @@ def test_knn_rejects_bad_arguments():
         capi.knn_topk(x, k=65)                                       # k > N
     with pytest.raises(RuntimeError):
         capi.knn_topk(x.cpu(), k=5)                                  # no CPU path
+
+
+@pytest.mark.gpu
+def test_precompute_pipeline_native_backbone_to_neighbour_table():
+    """precompute_knns.py end to end on the device: DinoFeaturizer (native backbone) -> get_feats :15-21 ->
+    compute_nearest_neighbors :86-96; against the same pipeline with the torch fp32 backbone."""
+    import torch
+    from stego_amd import featurizers, precompute_knns as P
+
+    class C:
+        dino_patch_size = 16; dino_feat_type = "feat"; model_type = "vit_tiny"; projection_type = None
+        dropout = False; pretrained_weights = None; native_backbone = True
+    torch.manual_seed(3)
+    fz = featurizers.DinoFeaturizer(20, C()).cuda().eval()
+    model = torch.nn.Sequential(fz, featurizers.LambdaLayer(lambda p: p[0]))
+    g = torch.Generator().manual_seed(4)
+    base = torch.randn(40, 3, 64, 64, generator=g)
+    imgs = torch.cat([base, base[:8] + 0.01 * torch.randn(8, 3, 64, 64, generator=g)])     # 8 near-duplicates
+    loader = [{"img": imgs[i:i + 16]} for i in range(0, 48, 16)]
+    feats = P.get_feats(model, loader)
+    assert fz.backbone_path == "native" and feats.shape == (48, 192)
+    assert torch.allclose(feats.norm(dim=1), torch.ones(48, device=feats.device), atol=1e-5)
+    nns = P.compute_nearest_neighbors(feats, k=5).cpu()
+    assert torch.equal(nns[:, 0], torch.arange(48))                                       # rank 0 = the row itself
+    assert torch.equal(nns[40:, 1], torch.arange(8))                                      # the near-duplicates find their originals
+    C.native_backbone = False
+    feats_ref = P.get_feats(model, loader)
+    assert fz.backbone_path == "torch"
+    assert float((feats - feats_ref).norm() / feats_ref.norm()) < 5e-3
