@@ -370,18 +370,23 @@ def main():
             "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,
         }
+    # RCCL (NCCL_DEBUG=VERSION on the bench boxes) writes its banner through C stdio, which would otherwise be flushed at
+    # exit, after the result: every rank pushes it out before the last barrier, rank 0 prints the record after it, so
+    # the JSON line is the last line of the job's stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        # RCCL (NCCL_DEBUG=VERSION on the bench boxes) writes its banner through C stdio, which would otherwise be
-        # flushed at exit, after the result: push it out first so that the JSON record is the last line of stdout
-        import ctypes
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:       # noqa: BLE001
             pass
-        sys.stdout.flush()
+    if rank == 0:
         print(json.dumps(rec), flush=True)
 
 
