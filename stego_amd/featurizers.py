@@ -74,6 +74,8 @@ class DinoFeaturizer(nn.Module):
         self.dropout = nn.Dropout2d(p=.1)
         self._native = None           # vit_native.NativeViT, built on first use on a HIP device
         self.backbone_path = None     # "native" | "torch": which path the last forward took
+        # new weights (also when loaded through a parent module's load_state_dict) -> re-pack the backbone on next use
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module._native and module._native.invalidate())
 
         weights = getattr(cfg, "pretrained_weights", None)
         if weights is not None:
@@ -116,11 +118,6 @@ class DinoFeaturizer(nn.Module):
         feat, _, qkv = self.model.get_intermediate_feat(img, n=n)
         return feat[0], qkv[0]
 
-    def load_state_dict(self, *args, **kw):
-        out = super().load_state_dict(*args, **kw)
-        if self._native is not None:
-            self._native.invalidate()                 # re-pack the backbone weights on next use
-        return out
 
     def forward(self, img, n=1, return_class_feat=False):
         self.model.eval()

@@ -78,6 +78,16 @@ def sharded_nearest_neighbors(local_feats, k=30, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+def nns_filename(model_type, dataset_name, image_set, crop_type, res):
+    """The cache file name data.py:503-511 looks up (precompute_knns.py:66-67)."""
+    return "nns_{}_{}_{}_{}_{}.npz".format(model_type, dataset_name, image_set, crop_type, res)
+
+
+def load_nns(path):
+    """int64 [N, k] neighbour table (data.py:511: np.load(...)["nns"])."""
+    return torch.from_numpy(np.load(path)["nns"])
+
+
 def save_nns(path, nns):
     """Same on-disk format as the reference (:96): a compressed npz with the single key ``nns``."""
     np.savez_compressed(path, nns=nns.cpu().numpy() if torch.is_tensor(nns) else np.asarray(nns))

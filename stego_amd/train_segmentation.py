@@ -84,6 +84,41 @@ class LitUnsupervisedSegmenter(nn.Module):
         self._optims = None
         self._reducer = None
 
+    # ---- checkpoints in the layout Lightning writes for the reference (train_segmentation.py:106 save_hyperparameters,
+    #      :487 ModelCheckpoint) and that eval_segmentation.py:67 / demo_segmentation.py:41 read back with
+    #      LitUnsupervisedSegmenter.load_from_checkpoint: a torch-pickled dict with `state_dict` (same keys: the module tree
+    #      above is the reference's) and `hyper_parameters = {n_classes, cfg}`
+    def checkpoint_dict(self, epoch=0):
+        cfg = {k: v for k, v in vars(self.cfg).items()} if not isinstance(self.cfg, dict) else dict(self.cfg)
+        ck = {"epoch": int(epoch), "global_step": int(self.global_step), "pytorch-lightning_version": "1.2.10",
+              "state_dict": self.state_dict(), "hyper_parameters": {"n_classes": self.n_classes, "cfg": cfg}}
+        if self._optims is not None:
+            ck["optimizer_states"] = [o.state_dict() for o in self._optims]
+        return ck
+
+    def save_checkpoint(self, path, epoch=0):
+        torch.save(self.checkpoint_dict(epoch), path)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", strict=True, **cfg_overrides):
+        """Accepts this build's checkpoints and the reference's Lightning ones (whose `cfg` is an OmegaConf DictConfig
+        or a plain dict: anything with .items()).  Keys this build does not have (e.g. torchmetrics buffers) are
+        reported, not fatal, with strict=False."""
+        ck = torch.load(path, map_location=map_location, weights_only=False)
+        hp = ck["hyper_parameters"]
+        cfg = hp["cfg"]
+        cfg = types.SimpleNamespace(**{k: v for k, v in (cfg.items() if hasattr(cfg, "items") else vars(cfg).items())})
+        for k, v in cfg_overrides.items():
+            setattr(cfg, k, v)
+        model = cls(int(hp["n_classes"]), cfg)
+        result = model.load_state_dict(ck["state_dict"], strict=strict)
+        model.global_step = int(ck.get("global_step", 0))
+        if "optimizer_states" in ck:
+            for o, sd in zip(model.optimizers(), ck["optimizer_states"]):
+                o.load_state_dict(sd)
+        model.load_result = result
+        return model
+
     # ---- the slice of the LightningModule protocol the reference uses
     def forward(self, x):
         return self.net(x)[1]

@@ -192,3 +192,39 @@ def test_trainer_fit_history_cpu():
     finally:
         from stego_amd import capi
         M._backend = capi
+
+
+def test_checkpoint_roundtrip_in_the_lightning_layout(tmp_path):
+    """`.ckpt` = {state_dict, hyper_parameters: {n_classes, cfg}, ...} as written by Lightning for the
+    reference (train_segmentation.py:106,:487) and read by eval_segmentation.py:67."""
+    cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "batch_size=2", "dim=12"])
+    torch.manual_seed(1)
+    m = LitUnsupervisedSegmenter(5, cfg).cpu()
+    m.optimizers()
+    m.global_step = 7
+    path = tmp_path / "model.ckpt"
+    m.save_checkpoint(str(path), epoch=3)
+    raw = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert {"state_dict", "hyper_parameters", "epoch", "global_step", "optimizer_states"} <= set(raw)
+    assert raw["hyper_parameters"]["n_classes"] == 5 and raw["hyper_parameters"]["cfg"]["dim"] == 12
+    assert "net.cluster1.0.weight" in raw["state_dict"] and "cluster_probe.clusters" in raw["state_dict"]
+    m2 = LitUnsupervisedSegmenter.load_from_checkpoint(str(path))
+    assert m2.n_classes == 5 and m2.cfg.dim == 12 and m2.global_step == 7
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu()), k1
+    # a reference-style checkpoint: cfg as a mapping object, extra torchmetrics-like buffers in the state dict
+    raw["state_dict"]["cluster_metrics.stats"] = torch.zeros(3)
+    torch.save(raw, str(path))
+    m3 = LitUnsupervisedSegmenter.load_from_checkpoint(str(path), strict=False, native_backbone=False)
+    assert m3.cfg.native_backbone is False and "cluster_metrics.stats" in m3.load_result.unexpected_keys
+
+
+def test_neighbour_file_name_and_format(tmp_path):
+    from stego_amd import precompute_knns as P
+    name = P.nns_filename("vit_small", "cocostuff27", "train", "five", 224)
+    assert name == "nns_vit_small_cocostuff27_train_five_224.npz"          # precompute_knns.py:66-67, data.py:503-511
+    nns = torch.arange(12, dtype=torch.int64).reshape(4, 3)
+    P.save_nns(str(tmp_path / name), nns)
+    assert torch.equal(P.load_nns(str(tmp_path / name)), nns)
+    import numpy as np
+    assert list(np.load(str(tmp_path / name)).keys()) == ["nns"]

@@ -225,3 +225,23 @@ def test_parameter_order_and_shapes_match_the_header_contract():
     probe = torch.empty(1, ntok, 384)
     assert torch.allclose(ps[3], model.interpolate_pos_encoding(probe, H, W)[0])
     assert vit_native.supported(model) and not vit_native.supported(dino_vit.VisionTransformer(patch_size=8, embed_dim=96, depth=1, num_heads=3))
+
+
+def test_loading_weights_invalidates_the_packed_backbone_even_through_a_parent_module():
+    from stego_amd import featurizers
+
+    class C:
+        dino_patch_size = 16; dino_feat_type = "feat"; model_type = "vit_tiny"; projection_type = None
+        dropout = False; pretrained_weights = None
+
+    class Fake:
+        n = 0
+
+        def invalidate(self):
+            self.n += 1
+    fz = featurizers.DinoFeaturizer(10, C()).cpu()
+    fz._native = Fake()
+    parent = torch.nn.Sequential(fz)
+    parent.load_state_dict(parent.state_dict())          # e.g. LitUnsupervisedSegmenter.load_state_dict(checkpoint)
+    fz.load_state_dict(fz.state_dict())
+    assert fz._native.n == 2
