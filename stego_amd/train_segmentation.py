@@ -161,9 +161,12 @@ class LitUnsupervisedSegmenter(nn.Module):
         cfg = self.cfg
         with torch.no_grad():
             img, img_pos, label = batch["img"], batch["img_pos"], batch["label"]
-        feats, code = self.net(img)
+        # cfg.cache_backbone_tokens: img / img_pos of a dataset index are the same pixels every epoch -> their frozen-backbone
+        # tokens come from the HBM table after the first epoch (featurizers.TokenCache)
+        caching = getattr(cfg, "cache_backbone_tokens", False) and getattr(self.net, "token_cache", None) is not None
+        feats, code = self.net(img, cache_index=batch["ind"] if caching else None)
         if cfg.correspondence_weight > 0:
-            feats_pos, code_pos = self.net(img_pos)
+            feats_pos, code_pos = self.net(img_pos, cache_index=batch["ind_pos"] if caching else None)
         log_args = dict(sync_dist=False, rank_zero_only=True)
         if cfg.use_true_labels:
             signal = one_hot_feats(label + 1, self.n_classes + 1)
@@ -295,6 +298,8 @@ class Trainer:
         model.train()
         if self.world > 1:
             model.setup_distributed()
+        if getattr(model.cfg, "cache_backbone_tokens", False) and hasattr(model.net, "enable_token_cache"):
+            model.net.enable_token_cache(len(loader.dataset), (model.cfg.res, model.cfg.res), self.device)
         step = 0
         history = []
         while step < self.max_steps:

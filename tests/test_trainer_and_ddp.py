@@ -228,3 +228,29 @@ def test_neighbour_file_name_and_format(tmp_path):
     assert torch.equal(P.load_nns(str(tmp_path / name)), nns)
     import numpy as np
     assert list(np.load(str(tmp_path / name)).keys()) == ["nns"]
+
+
+def test_token_cache_serves_the_frozen_backbone_from_memory():
+    """featurizers.TokenCache: the second visit of a dataset index does not run the backbone; values = the direct
+    forward up to the fp16 storage; the trainer wires it through batch['ind'] / batch['ind_pos']."""
+    cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "batch_size=4", "dim=12",
+                                 "feature_samples=3", "neg_samples=1", "cache_backbone_tokens=True", "max_steps=4", "dropout=False"])
+    torch.manual_seed(2)
+    m = LitUnsupervisedSegmenter(5, cfg).cpu()
+    net = m.net
+    calls = []
+    orig = net._tokens
+    net._tokens = lambda img, n: (calls.append(img.shape[0]), orig(img, n))[1]
+    cache = net.enable_token_cache(8, (32, 32), torch.device("cpu"))
+    net.eval()
+    img = torch.randn(8, 3, 32, 32)
+    idx = torch.arange(8)
+    f_direct, _ = net(img)
+    assert calls == [8]
+    f1, _ = net(img[:5], cache_index=idx[:5])               # 5 misses
+    f2, _ = net(img[2:], cache_index=idx[2:])               # rows 2..4 hit, 5..7 miss
+    assert calls == [8, 5, 3] and cache.misses == 8 and cache.complete
+    f3, _ = net(img, cache_index=idx)                       # all hits: the backbone is not called
+    assert calls == [8, 5, 3]
+    assert torch.allclose(f3, f_direct, rtol=2e-3, atol=2e-3) and torch.allclose(f1, f_direct[:5], rtol=2e-3, atol=2e-3)
+    assert f3.stride(1) == 1                                # still the channels-last view the loss kernels want

@@ -65,7 +65,24 @@ def loss_only():
 
 
 res["loss_fwd_bwd_eager_ms"] = timed(loss_only, 30)
+
+# the same step with the backbone tokens of the (fixed-crop) dataset served from HBM (featurizers.TokenCache)
+cache = net.enable_token_cache(2 * B, (224, 224), dev)
+idx = torch.arange(2 * B, device=dev)
+
+
+def step_cached():
+    feats_all, code_all = net(both, cache_index=idx)
+    out = loss_fn(feats_all[:B], feats_all[B:], None, None, code_all[:B], code_all[B:])
+    loss = .67 * out[0] + .25 * out[2] + .63 * out[4].mean()
+    for p in params: p.grad = None
+    loss.backward()
+
+
+res["cached_tokens"] = {"step_ms": timed(step_cached, 30), "misses": cache.misses,
+                        "table_MB": cache.tokens.numel() * 2 / 1e6}
 print(json.dumps({"metric": "training step, B=%d pairs, ViT-S/8 224^2 (backbone on 2B images + head + correspondence loss fwd+bwd + head bwd)" % B,
                   "unit": "ms", **res,
                   "pairs_per_s_native": B / res["native_backbone"]["step_ms"] * 1e3,
-                  "pairs_per_s_torch_backbone": B / res["torch_fp32_backbone"]["step_ms"] * 1e3}))
+                  "pairs_per_s_torch_backbone": B / res["torch_fp32_backbone"]["step_ms"] * 1e3,
+                  "pairs_per_s_cached_tokens": B / res["cached_tokens"]["step_ms"] * 1e3}))
