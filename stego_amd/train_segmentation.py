@@ -164,9 +164,9 @@ class LitUnsupervisedSegmenter(nn.Module):
         # cfg.cache_backbone_tokens: img / img_pos of a dataset index are the same pixels every epoch -> their frozen-backbone
         # tokens come from the HBM table after the first epoch (featurizers.TokenCache)
         caching = getattr(cfg, "cache_backbone_tokens", False) and getattr(self.net, "token_cache", None) is not None
-        feats, code = self.net(img, cache_index=batch["ind"] if caching else None)
+        feats, code = self.net(img, cache_index=batch["ind"]) if caching else self.net(img)
         if cfg.correspondence_weight > 0:
-            feats_pos, code_pos = self.net(img_pos, cache_index=batch["ind_pos"] if caching else None)
+            feats_pos, code_pos = self.net(img_pos, cache_index=batch["ind_pos"]) if caching else self.net(img_pos)
         log_args = dict(sync_dist=False, rank_zero_only=True)
         if cfg.use_true_labels:
             signal = one_hot_feats(label + 1, self.n_classes + 1)
