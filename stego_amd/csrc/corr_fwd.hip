@@ -421,10 +421,14 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
     __syncthreads();                              // tap table visible
 
     const bool gatherB = !sameAB;
+    // debug bit 16 (experiment): every image walks the channel chunks from its own start, so that the tiles in flight
+    // do not all hit the same 256-byte residue of every pixel at the same time (L2 / fabric channel spreading)
+    const int rot = (prm.debug & 16) ? b % NCH : 0;
+    auto chunk_of = [&](int t) { int tt = t + rot; return tt >= NCH ? tt - NCH : tt; };
     auto copies = [&](int t) {                    // async LDS copies of stage t: A features / both code operands
         unsigned char* dst = stage + (t & 1) * stage_bytes;
         if (t < NCH) {
-            issue_copy(fsA + (size_t)t * FSIDE, dst, FSIDE / 1024, wave, lane);
+            issue_copy(fsA + (size_t)chunk_of(t) * FSIDE, dst, FSIDE / 1024, wave, lane);
         } else {
             issue_copy(csA, dst, cside / 1024, wave, lane);
             if (!sameAB) issue_copy(csB, dst + cside, cside / 1024, wave, lane);
@@ -471,9 +475,9 @@ __global__ void __launch_bounds__(TILE_THREADS) corr_tile_kernel(const CorrParam
         // Channels beyond C exist only in the generic path (V == 1, the host takes V == 4 only when C % 64 == 0):
         // such a lane re-reads the last channel and its values are zeroed at commit.  Prefetches past the last
         // chunk re-read it and are never committed.
-        auto chunk_ptr = [&](int t) { return V == 4 ? imgB + (long long)min(t * KC, prm.C - KC) * scB : imgB; };
-        auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(t * KC + gslot, prm.C - 1) * scB; };
-        auto chunk_ok = [&](int t) { return V == 4 || t * KC + gslot < prm.C; };
+        auto chunk_ptr = [&](int t) { return V == 4 ? imgB + (long long)min(chunk_of(min(t, NCH - 1)) * KC, prm.C - KC) * scB : imgB; };
+        auto lane_ofs = [&](int t) { return V == 4 ? lane_off : min(chunk_of(min(t, NCH - 1)) * KC + gslot, prm.C - 1) * scB; };
+        auto chunk_ok = [&](int t) { return V == 4 || chunk_of(min(t, NCH - 1)) * KC + gslot < prm.C; };
         if (gatherB) {
             gather_issue<V>(g, chunk_ptr(0), tapo, lane_ofs(0), gprow, 0, ITEMS);
             gather_commit<V, PREC>(g, tapw, chunk_ok(0), stage + FSIDE, ss, bsc, gslot, gprow, 0, ITEMS);

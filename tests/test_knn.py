@@ -132,6 +132,39 @@ def test_knn_vits8_width_8k_rows_against_oracle():
 
 
 @gpu
+def test_knn_cfg5_100k_rows_sampled_against_exact_topk():
+    """BASELINE config 5 at its real size: N = 100 000 ViT-S/8 feature vectors (D = 384), k = 30 (precompute_knns.py:86-96).
+    The fp64 oracle over all 10^10 pairs is out of reach, so 2 048 sampled query rows are checked exactly: the returned
+    neighbours must carry the exact top-30 similarities (they may differ from torch.topk only inside a tie band, which
+    SURVEY 8c allows), be sorted, duplicate-free, and rank 0 must be the row itself (data.py:524 skips it)."""
+    n, d, k = 100000, 384, 30
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    centers = torch.randn(256, d, generator=g, device=DEV)
+    x = centers[torch.randint(0, 256, (n,), generator=g, device=DEV)] + 0.7 * torch.randn(n, d, generator=g, device=DEV)
+    x = torch.nn.functional.normalize(x, dim=1).contiguous()
+    from stego_amd import capi
+    idx, sims = capi.knn_topk(x, k=k, return_sims=True)
+    torch.cuda.synchronize()
+    idx, sims = idx.cpu().numpy(), sims.cpu().numpy()
+    xc = x.cpu().double()
+    assert idx.shape == (n, k) and idx.min() >= 0 and idx.max() < n
+    np.testing.assert_array_equal(idx[:, 0], np.arange(n))                       # self first, every row
+    rows = np.random.default_rng(7).choice(n, 2048, replace=False)
+    differing = 0
+    for blk in np.array_split(rows, 8):
+        s = xc[blk] @ xc.T                                                       # exact (fp64) similarities of the sampled rows
+        ref_val, ref_idx = torch.topk(s, k, dim=1)
+        got_val = torch.gather(s, 1, torch.from_numpy(idx[blk]))
+        np.testing.assert_allclose(got_val.numpy(), ref_val.numpy(), rtol=0, atol=5e-6)      # tie band only
+        assert (np.diff(got_val.numpy(), axis=1) <= 5e-6).all()
+        np.testing.assert_allclose(sims[blk], got_val.numpy(), rtol=0, atol=2e-5)
+        srt = np.sort(idx[blk], axis=1)
+        assert (np.diff(srt, axis=1) > 0).all()
+        differing += int((np.sort(ref_idx.numpy(), axis=1) != srt).any(axis=1).sum())
+    assert differing <= 2048 // 50, differing
+
+
+@gpu
 def test_knn_rejects_bad_arguments():
     from stego_amd import capi
     x = torch.randn(64, 16, device=DEV)
