@@ -82,6 +82,11 @@ typedef struct StegoCorrDesc {
 int stego_abi_version(void);
 const char* stego_error_string(int code);
 
+/* Measurement / ablation knobs for tools (never needed by a caller of the product path).  The library reads
+ * STEGO_DEBUG, STEGO_DEBUG_SAMPLE, STEGO_DEBUG_BWD, STEGO_DEBUG_VIT, STEGO_DEBUG_KNN, STEGO_FWD_VARIANT from the
+ * environment ONCE, when it is loaded (no getenv in any call); this overrides knob `which` (0..5 in that order). */
+int stego_debug_set(int32_t which, int32_t value);
+
 /* Buffer sizes (bytes; depend only on the descriptor; 0 for an invalid/unsupported descriptor).
  *   workspace : scratch of one forward call (sampled operand images + per-tile partial sums)
  *   saved_ctx : what the forward leaves for the backward of the CODE side (normalised sampled codes,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "stego_vit_pack_weights": (c_int32, [_V, POINTER(ctypes.c_void_p), c_int32, _P, c_size_t, _P]),
     "stego_vit_forward": (c_int32, [_V, _P, _P, _P, _P, c_size_t, _P]),
     "stego_abi_version": (c_int32, []),
+    "stego_debug_set": (c_int32, [c_int32, c_int32]),
     "stego_error_string": (ctypes.c_char_p, [c_int32]),
     "stego_corr_workspace_bytes": (c_size_t, [_D]),
     "stego_corr_saved_ctx_bytes": (c_size_t, [_D]),
@@ -93,6 +94,15 @@ def load():
         raise RuntimeError("stego_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib
+
+
+KNOBS = {"STEGO_DEBUG": 0, "STEGO_DEBUG_SAMPLE": 1, "STEGO_DEBUG_BWD": 2, "STEGO_DEBUG_VIT": 3, "STEGO_DEBUG_KNN": 4,
+         "STEGO_FWD_VARIANT": 5}
+
+
+def debug_set(name, value):
+    """Measurement knob of the library (tools only; the library reads the environment once, at load)."""
+    _check(load().stego_debug_set(KNOBS[name], int(value)))
 
 
 def _check(rc):

@@ -5,11 +5,14 @@
 
 #include "../../include/stego_corr.h"
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
+bool fused_supported(const FusedParams& prm, int precision);
+hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, hipStream_t stream, hipEvent_t* ev);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
@@ -63,7 +66,7 @@ int check_desc(const StegoCorrDesc* d, bool helper)
 // ---- buffer geometry (all derived from the descriptor)
 struct Geometry {
     int n_roles, nset, NCH, KQ, LDK;
-    size_t stats_bytes, fs_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
+    size_t stats_bytes, sync_bytes, fs_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
 };
 
 Geometry geometry(const StegoCorrDesc* d, bool helper)
@@ -75,28 +78,23 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.KQ = (d->K + 7) & ~7;
     g.LDK = g.KQ + 4;
     const size_t n_tiles = (size_t)(helper ? 1 : 2 + d->n_neg) * d->B;
-    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * 64, 256);      // tail: debug stamps (8 per tile)
+    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * 128, 256);     // tail: debug stamps (16 per tile)
     const size_t fside = d->precision == STEGO_PREC_F16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
     g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only
     g.cs_bytes = round_up((size_t)g.nset * TP * g.LDK * sizeof(float) + 1024, 256);
     g.nrm_bytes = round_up((size_t)g.nset * TP * sizeof(float), 256);
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
-    g.ws_bytes = g.stats_bytes + g.fs_bytes + g.ctx_bytes;
+    // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
+    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8, 256);    // counters 256 B apart (ANCHOR_CNT_STRIDE)
+    g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.ctx_bytes;
     g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
     return g;
 }
 
 int hip_rc(hipError_t e) { return e == hipSuccess ? STEGO_OK : STEGO_ERR_HIP + (int)e; }
 
-// Measurement knobs (read per call so a bench can flip them): STEGO_DEBUG / STEGO_DEBUG_BWD = ablation
-// bit masks (see CorrParams::debug / BwdParams::debug), STEGO_FWD_VARIANT = 0 fused-gather cross-check
-// kernel (f32 only), 1 (default) sample + dense tile kernels.
-int env_int(const char* name, int dflt)
-{
-    const char* v = std::getenv(name);
-    return v && *v ? std::atoi(v) : dflt;
-}
+// Measurement knobs: host_util.h (read from the environment once at load; tools flip them with stego_debug_set).
 
 int fill_bwd_ctx(const StegoCorrDesc* d, bool helper, const void* saved_ctx, void* workspace, size_t workspace_bytes,
                  BwdParams* prm)
@@ -120,6 +118,9 @@ int fill_bwd_ctx(const StegoCorrDesc* d, bool helper, const void* saved_ctx, voi
 struct FwdPlan {
     CorrParams tile;
     SampleParams samp;
+    FusedParams fused;
+    size_t sync_bytes;
+    bool use_fused;
     int precision;
 };
 
@@ -154,7 +155,8 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     prm.saved_w = saved_w; prm.saved_mean = saved_mean; prm.loss_means = loss_means;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     prm.stats = reinterpret_cast<float*>(ws);
-    unsigned char* fs = ws + g.stats_bytes;
+    unsigned char* sync = ws + g.stats_bytes;
+    unsigned char* fs = sync + g.sync_bytes;
     unsigned char* ctx = saved_ctx ? static_cast<unsigned char*>(saved_ctx) : fs + g.fs_bytes;
     prm.fs = fs;
     prm.cs = reinterpret_cast<const float*>(ctx);
@@ -171,7 +173,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     prm.shift[0] = d->pos_intra_shift;
     prm.shift[1] = helper ? d->pos_intra_shift : d->pos_inter_shift;
     prm.shift[2] = helper ? d->pos_intra_shift : d->neg_inter_shift;
-    prm.debug = env_int("STEGO_DEBUG", 0);
+    prm.debug = knob(KNOB_DEBUG);
 
     SampleParams sp{};
     sp.feats = prm.feats; sp.feats_pos = prm.feats_pos; sp.code = prm.code; sp.code_pos = prm.code_pos;
@@ -183,18 +185,45 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     sp.tapw = reinterpret_cast<float4*>(ctx + g.cs_bytes + g.nrm_bytes + g.tap_bytes);
     sp.B = d->B; sp.C = d->C; sp.K = d->K; sp.H = d->H; sp.W = d->W; sp.S = prm.S; sp.P = prm.P;
     sp.n_roles = g.n_roles; sp.feat_roles = 1; sp.NCH = g.NCH; sp.KQ = g.KQ; sp.LDK = g.LDK; sp.mode = prm.mode;
-    sp.debug = env_int("STEGO_DEBUG_SAMPLE", 0);
+    sp.debug = knob(KNOB_DEBUG_SAMPLE);
 
     prm.tapyx = sp.tapyx; prm.tapw = sp.tapw;
     out->tile = prm;
     out->samp = sp;
     out->precision = d->precision;
+
+    // the fused single-launch forward (corr_fused.hip) covers forward() on channels-last maps of the ViT widths;
+    // everything else (helper mode, generic strides, other widths) takes the three-launch path
+    FusedParams fp{};
+    fp.feats = prm.feats; fp.feats_pos = prm.feats_pos; fp.code = prm.code; fp.code_pos = prm.code_pos;
+    fp.coords1 = coords1; fp.coords2 = coords2; fp.perms = prm.perms;
+    fp.intra_cd = prm.intra_cd; fp.inter_cd = prm.inter_cd; fp.neg_loss = prm.neg_loss; fp.neg_cd = prm.neg_cd;
+    fp.saved_w = saved_w; fp.saved_mean = saved_mean; fp.loss_means = loss_means;
+    fp.stats = prm.stats;
+    fp.anchor_cnt = reinterpret_cast<unsigned*>(sync);
+    fp.gran = reinterpret_cast<unsigned long long*>(sync + (size_t)d->B * 256);
+    fp.fs = fs;
+    fp.cs = sp.cs; fp.nrm = sp.nrm; fp.tapyx = sp.tapyx; fp.tapw = sp.tapw;
+    fp.fs_bytes = (unsigned)g.fs_bytes; fp.cs_bytes = (unsigned)g.cs_bytes;
+    fp.NCH = g.NCH; fp.KQ = g.KQ; fp.LDK = g.LDK;
+    fp.B = prm.B; fp.C = prm.C; fp.K = prm.K; fp.H = prm.H; fp.W = prm.W; fp.S = prm.S; fp.P = prm.P;
+    fp.n_neg = prm.n_neg; fp.n_sets = prm.n_sets;
+    fp.pointwise = prm.pointwise;
+    fp.debug = prm.debug;
+    fp.cmin = prm.cmin; fp.cmax = prm.cmax;
+    fp.shift[0] = prm.shift[0]; fp.shift[1] = prm.shift[1]; fp.shift[2] = prm.shift[2];
+    out->fused = fp;
+    out->sync_bytes = g.sync_bytes;
+    const int variant = knob(KNOB_FWD_VARIANT);              // -1 (default) automatic, 1 three launches, 2 fused
+    out->use_fused = !helper && variant != 1 && g.fs_bytes < ((size_t)1 << 31) && g.cs_bytes < ((size_t)1 << 31) &&
+                     fused_supported(fp, d->precision);
     return STEGO_OK;
 }
 
 hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [4] */)
 {
     hipError_t e;
+    if (pl.use_fused) return launch_corr_fused(pl.fused, pl.precision, pl.sync_bytes, s, ev);
     if (ev) (void)hipEventRecord(ev[0], s);
     if ((e = launch_corr_sample(pl.samp, pl.precision, s)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], s);
@@ -210,6 +239,13 @@ hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [
 extern "C" {
 
 int stego_abi_version(void) { return STEGO_ABI_VERSION; }
+
+int stego_debug_set(int32_t which, int32_t value)
+{
+    if (which < 0 || which >= KNOB_COUNT) return STEGO_ERR_SHAPE;
+    set_knob(which, value);
+    return STEGO_OK;
+}
 
 const char* stego_error_string(int code)
 {
@@ -330,7 +366,7 @@ int stego_corr_bwd(const StegoCorrDesc* d, const int64_t* perms, const float* sa
     prm.d_code = d_code; prm.d_code_pos = d_code_pos;
     prm.B = d->B; prm.K = d->K; prm.H = d->H; prm.W = d->W; prm.S = d->S; prm.P = d->S * d->S;
     prm.n_neg = d->n_neg; prm.n_sets = 2 + d->n_neg; prm.mode = 0;
-    prm.debug = env_int("STEGO_DEBUG_BWD", 0);
+    prm.debug = knob(KNOB_DEBUG_BWD);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
     return hip_rc(launch_corr_bwd(prm, static_cast<hipStream_t>(stream)));
@@ -362,7 +398,7 @@ int stego_corr_helper_bwd(const StegoCorrDesc* d, const float* saved_w, const fl
     prm.d_code = d_c1; prm.d_code_pos = d_c2;
     prm.B = d->B; prm.K = d->K; prm.H = d->H; prm.W = d->W; prm.S = d->W; prm.P = d->H * d->W;
     prm.n_neg = 0; prm.n_sets = 1; prm.mode = 1;
-    prm.debug = env_int("STEGO_DEBUG_BWD", 0);
+    prm.debug = knob(KNOB_DEBUG_BWD);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
     return hip_rc(launch_corr_bwd(prm, static_cast<hipStream_t>(stream)));

@@ -20,6 +20,7 @@
 //
 // Reference: autograd through src/modules.py:335-347, 369-391.
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 
@@ -673,13 +674,8 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
 #define STEGO_BWD_CASE(N)                                                                                         \
     case N: {                                                                                                     \
-        static int have = 0;                                                                                      \
-        if (have < lds) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>),           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
-            if (e != hipSuccess) return e;                                                                        \
-            have = lds;                                                                                           \
-        }                                                                                                         \
+        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>), lds);        \
+        if (ea != hipSuccess) return ea;                                                                          \
         hipLaunchKernelGGL((corr_bwd_tile_kernel<N>), grid, block, lds, stream, prm);                             \
         break;                                                                                                    \
     }
@@ -714,13 +710,8 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         RT = (prm.H + n_bands - 1) / n_bands;                 // even bands
         const int acc_bytes = ((RT * row_bytes + 15) & ~15) + 4 * 64 * 4 + 256;     // band + per-lane dummy cells
         const int lds = acc_bytes + UNS_MAX_CONTRIB * 4 + UNS_MAX_RT * UNS_ROW_CAP * (int)sizeof(UnsRowEntry) + 64;
-        static int have = 0;
-        if (have < lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_unsample_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            have = lds;
-        }
+        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_unsample_kernel), lds);
+        if (ea != hipSuccess) return ea;
         const dim3 grid(2 * prm.B * n_bands), block(UNS_THREADS);
         hipLaunchKernelGGL(corr_unsample_kernel, grid, block, lds, stream, prm, RT, n_bands, acc_bytes);
     }

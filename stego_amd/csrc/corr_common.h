@@ -118,6 +118,39 @@ struct BwdParams {
     float cmin, cmax;
 };
 
+// Fused forward (corr_fused.hip): one launch + a scalar kernel.
+struct FusedParams {
+    MapV feats, feats_pos, code, code_pos;
+    const float* coords1;
+    const float* coords2;
+    const long long* perms;                    // [n_neg][B]
+    float* intra_cd;                           // [B][P*P]
+    float* inter_cd;                           // [B][P*P]
+    float* neg_loss;                           // [n_neg*B][P*P]
+    float* neg_cd;                             // [n_neg*B][P*P]
+    float* saved_w;                            // [n_sets*B][P*P] or null
+    float* saved_mean;                         // [n_sets] or null
+    float* loss_means;                         // [2]
+    float* stats;                              // [n_sets*B][4]: sum fd, sum lp, sum clamp, 1 = old_mean applied in-kernel
+    unsigned* anchor_cnt;                      // [B] points published per anchor           } zeroed before the launch
+    unsigned long long* gran;                  // [n_sets*B] {tag = 1, sum fd} granules     }
+    unsigned char* fs;                         // anchor feature operand images [B][NCH][FSIDE]
+    float* cs;                                 // normalised sampled codes of every set [nset][128][LDK]
+    float* nrm;                                // [nset][128] code norms
+    int4* tapyx;                               // [nset][128]
+    float4* tapw;                              // [nset][128]
+    unsigned fs_bytes, cs_bytes;               // sizes of the fs / cs regions (buffer descriptors)
+    int NCH, KQ, LDK;
+    int B, C, K, H, W, S, P, n_neg, n_sets;
+    int n_owner;                               // workgroups [0, n_owner) share phase 1
+    int pointwise;
+    int debug;                                 // 32 never rendezvous (always repair), 64 owners skip phase 1 (always help),
+                                               // 256 phase stamps
+    int timeout_ticks;                         // bound of every spin, 100 MHz ticks
+    float cmin, cmax;
+    float shift[3];
+};
+
 // Bilinear taps of ATen grid_sampler_2d (bilinear, padding_mode=border, align_corners=True),
 // which is what the reference's sample() (modules.py:287-288) lowers to.
 // Returns pixel coordinates packed as (y<<16)|x per tap and the 4 corner weights (nw,ne,sw,se).

@@ -14,6 +14,7 @@
 //                       products, fp32 accumulate), the tile is stored straight from the accumulators (each wave
 //                       instruction writes 128-byte row segments).  Output-write bound at C = 384.
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 
@@ -214,13 +215,8 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
     const int vec = cl(a) && cl(b) ? 1 : 0;
     hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * (prm.nbA + prm.nbB))), dim3(NTHREADS), 0, stream, prm, vec);
     const int lds = 4 * DC_SIDE;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tile_kernel), lds);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
     return hipGetLastError();
 }

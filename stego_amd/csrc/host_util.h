@@ -1,0 +1,22 @@
+// Host-side helpers shared by the launchers: per-device caches (thread-safe), environment knobs read once.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace stego {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember what each
+// (device, kernel) pair already has, under a mutex (one process may drive several GPUs from several threads, as the
+// reference's DataParallel feature extraction does, precompute_knns.py:59).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
+// number of compute units of the current device (cached per device)
+int device_cu_count();
+
+// Measurement / ablation knobs: STEGO_DEBUG, STEGO_DEBUG_SAMPLE, STEGO_DEBUG_BWD, STEGO_DEBUG_VIT, STEGO_DEBUG_KNN, STEGO_FWD_VARIANT.
+// Read from the environment once, when the library is loaded; stego_debug_set() (C ABI, tools only) overrides them
+// afterwards.  The product path never calls getenv.
+enum { KNOB_DEBUG = 0, KNOB_DEBUG_SAMPLE, KNOB_DEBUG_BWD, KNOB_DEBUG_VIT, KNOB_DEBUG_KNN, KNOB_FWD_VARIANT, KNOB_COUNT };
+int knob(int which);
+void set_knob(int which, int value);
+
+}  // namespace stego

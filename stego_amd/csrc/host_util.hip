@@ -1,0 +1,70 @@
+// Per-device caches and measurement knobs (see host_util.h).
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "host_util.h"
+
+namespace stego {
+
+namespace {
+std::mutex g_mutex;
+std::map<std::pair<int, const void*>, int> g_lds;       // (device, kernel) -> dynamic LDS limit already set
+std::map<int, int> g_cus;                                // device -> compute units
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+struct Knobs {
+    int v[KNOB_COUNT];
+    Knobs()
+    {
+        v[KNOB_DEBUG] = env_int("STEGO_DEBUG", 0);
+        v[KNOB_DEBUG_SAMPLE] = env_int("STEGO_DEBUG_SAMPLE", 0);
+        v[KNOB_DEBUG_BWD] = env_int("STEGO_DEBUG_BWD", 0);
+        v[KNOB_DEBUG_VIT] = env_int("STEGO_DEBUG_VIT", 0);
+        v[KNOB_DEBUG_KNN] = env_int("STEGO_DEBUG_KNN", 0);
+        v[KNOB_FWD_VARIANT] = env_int("STEGO_FWD_VARIANT", -1);
+    }
+};
+Knobs g_knobs;      // initialised when the library is loaded
+}  // namespace
+
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int& have = g_lds[std::make_pair(dev, kernel)];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
+int device_cu_count()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_cus.find(dev);
+    if (it != g_cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_cus[dev] = n;
+    return n;
+}
+
+int knob(int which) { return (which >= 0 && which < KNOB_COUNT) ? g_knobs.v[which] : 0; }
+
+void set_knob(int which, int value)
+{
+    if (which >= 0 && which < KNOB_COUNT) g_knobs.v[which] = value;
+}
+
+}  // namespace stego

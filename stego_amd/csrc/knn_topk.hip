@@ -24,6 +24,7 @@
 // Ties: torch.topk leaves the order of equal values unspecified; so does this.
 #include <cstdlib>
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 
@@ -341,16 +342,7 @@ __global__ void __launch_bounds__(NTHREADS) knn_merge_kernel(const KnnParams prm
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static int knn_cus()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        n = (hipGetDevice(&dev) == hipSuccess &&
-             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return n;
-}
+static int knn_cus() { return device_cu_count(); }
 
 // units per workgroup: an even split over the CUs, but never so fine that a query block has more than 32 segments
 static void knn_partition(long long q_count, int nblk, long long* units_total, long long* units_per_wg, int* max_segments)
@@ -388,10 +380,7 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     prm.nblk = (int)((N + TP - 1) / TP);
     prm.NCH = (D + KC - 1) / KC;
     knn_partition(q_count, prm.nblk, &prm.units_total, &prm.units_per_wg, &prm.NS);
-    {
-        const char* e = getenv("STEGO_DEBUG_KNN");
-        prm.debug = e ? atoi(e) : 0;
-    }
+    prm.debug = knob(KNOB_DEBUG_KNN);
     const long long nq_pad = ((q_count + TP - 1) / TP) * TP;
     unsigned char* w = static_cast<unsigned char*>(ws);
     prm.img = w;
@@ -403,14 +392,9 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
     hipLaunchKernelGGL(knn_prep_kernel, dim3(prm.nblk), dim3(NTHREADS), 0, stream, prm);
     const bool areg = prm.NCH <= KNN_AREG_CHUNKS;
     const int lds = areg ? 2 * KNN_SIDE : 4 * KNN_SIDE;
-    static bool attr[2] = {false, false};
-    if (!attr[areg]) {
-        hipError_t e = hipFuncSetAttribute(areg ? reinterpret_cast<const void*>(&knn_tile_kernel<true>)
-                                                : reinterpret_cast<const void*>(&knn_tile_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr[areg] = true;
-    }
+    hipError_t ea = ensure_dynamic_lds(areg ? reinterpret_cast<const void*>(&knn_tile_kernel<true>)
+                                            : reinterpret_cast<const void*>(&knn_tile_kernel<false>), lds);
+    if (ea != hipSuccess) return ea;
     const dim3 grid((unsigned)((prm.units_total + prm.units_per_wg - 1) / prm.units_per_wg));
     if (areg) hipLaunchKernelGGL(knn_tile_kernel<true>, grid, dim3(NTHREADS), lds, stream, prm);
     else hipLaunchKernelGGL(knn_tile_kernel<false>, grid, dim3(NTHREADS), lds, stream, prm);

@@ -17,6 +17,7 @@
 
 #include "../../include/stego_vit.h"
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 namespace vit {
@@ -620,13 +621,8 @@ int check_desc(const StegoVitDesc* d)
 
 template <int EPI> hipError_t launch_gemm(const GemmParams& p, hipStream_t stream)
 {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    hipError_t ea = stego::ensure_dynamic_lds(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI>), GT_LDS);
+    if (ea != hipSuccess) return ea;
     const int mtiles = (p.M + GT_M - 1) / GT_M, ntiles = ntiles192(p.N);
     const int grid = 8 * ((mtiles + 7) / 8) * ntiles;
     hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(grid), dim3(GT_THREADS), GT_LDS, stream, p, mtiles, ntiles);
@@ -732,10 +728,7 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     VIT_TRY(hipMemsetAsync(ws + w.q, 0, w.qkv_bytes, stream));
 
     GemmParams g{};
-    {
-        const char* e = getenv("STEGO_DEBUG_VIT");
-        g.debug = e ? atoi(e) : 0;
-    }
+    g.debug = stego::knob(stego::KNOB_DEBUG_VIT);
     g.D = D;
     g.heads = d->heads;
     g.ntok = L.ntok;

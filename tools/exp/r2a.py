@@ -16,7 +16,7 @@ def main():
     desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
     ref = None
     for debug in [int(x) for x in sys.argv[1:]] or [0, 16, 0, 16]:
-        os.environ["STEGO_DEBUG"] = str(debug)
+        capi.debug_set("STEGO_DEBUG", debug)
         ts = [0.0, 0.0, 0.0]; n = 0
         for r in range(6):
             for d in sets:
