@@ -66,7 +66,8 @@ int check_desc(const StegoCorrDesc* d, bool helper)
 // ---- buffer geometry (all derived from the descriptor)
 struct Geometry {
     int n_roles, nset, NCH, KQ, LDK;
-    size_t stats_bytes, sync_bytes, fs_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
+    int NCH2, NKC, kper;            // fused forward: C / 32 feature stages, code K-chunks of kper channels
+    size_t stats_bytes, sync_bytes, fs_bytes, csf_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
 };
 
 Geometry geometry(const StegoCorrDesc* d, bool helper)
@@ -78,16 +79,23 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.KQ = (d->K + 7) & ~7;
     g.LDK = g.KQ + 4;
     const size_t n_tiles = (size_t)(helper ? 1 : 2 + d->n_neg) * d->B;
-    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * 128, 256);     // tail: debug stamps (16 per tile)
+    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * (128 + 1024), 256);     // tail: debug stamps (16 + 128 per tile)
     const size_t fside = d->precision == STEGO_PREC_F16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
-    g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only
+    g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only (three-launch layout)
+    // fused forward: anchor operands as ring stages of 16 KB (32 channels: fp16 hi + lo, or fp32), codes as K-chunks
+    g.NCH2 = (d->C + 31) / 32;
+    g.NKC = (g.KQ + 31) / 32;
+    g.kper = (((g.KQ + g.NKC - 1) / g.NKC) + 7) & ~7;
+    const size_t fs_ring = round_up((size_t)d->B * g.NCH2 * 16384 + 1024, 256);
+    if (fs_ring > g.fs_bytes) g.fs_bytes = fs_ring;
+    g.csf_bytes = round_up((size_t)d->B * g.NKC * 16384 + 1024, 256);
     g.cs_bytes = round_up((size_t)g.nset * TP * g.LDK * sizeof(float) + 1024, 256);
     g.nrm_bytes = round_up((size_t)g.nset * TP * sizeof(float), 256);
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
     g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8, 256);    // counters 256 B apart (ANCHOR_CNT_STRIDE)
-    g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.ctx_bytes;
+    g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.csf_bytes + g.ctx_bytes;
     g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
     return g;
 }
@@ -157,7 +165,8 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     prm.stats = reinterpret_cast<float*>(ws);
     unsigned char* sync = ws + g.stats_bytes;
     unsigned char* fs = sync + g.sync_bytes;
-    unsigned char* ctx = saved_ctx ? static_cast<unsigned char*>(saved_ctx) : fs + g.fs_bytes;
+    unsigned char* csf = fs + g.fs_bytes;
+    unsigned char* ctx = saved_ctx ? static_cast<unsigned char*>(saved_ctx) : csf + g.csf_bytes;
     prm.fs = fs;
     prm.cs = reinterpret_cast<const float*>(ctx);
     prm.NCH = g.NCH; prm.KQ = g.KQ; prm.LDK = g.LDK;
@@ -203,9 +212,10 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     fp.anchor_cnt = reinterpret_cast<unsigned*>(sync);
     fp.gran = reinterpret_cast<unsigned long long*>(sync + (size_t)d->B * 256);
     fp.fs = fs;
+    fp.csf = csf;
     fp.cs = sp.cs; fp.nrm = sp.nrm; fp.tapyx = sp.tapyx; fp.tapw = sp.tapw;
-    fp.fs_bytes = (unsigned)g.fs_bytes; fp.cs_bytes = (unsigned)g.cs_bytes;
-    fp.NCH = g.NCH; fp.KQ = g.KQ; fp.LDK = g.LDK;
+    fp.fs_bytes = (unsigned)g.fs_bytes; fp.csf_bytes = (unsigned)g.csf_bytes; fp.cs_bytes = (unsigned)g.cs_bytes;
+    fp.NCH2 = g.NCH2; fp.NKC = g.NKC; fp.kper = g.kper; fp.KQ = g.KQ; fp.LDK = g.LDK;
     fp.B = prm.B; fp.C = prm.C; fp.K = prm.K; fp.H = prm.H; fp.W = prm.W; fp.S = prm.S; fp.P = prm.P;
     fp.n_neg = prm.n_neg; fp.n_sets = prm.n_sets;
     fp.pointwise = prm.pointwise;

@@ -134,13 +134,15 @@ struct FusedParams {
     float* stats;                              // [n_sets*B][4]: sum fd, sum lp, sum clamp, 1 = old_mean applied in-kernel
     unsigned* anchor_cnt;                      // [B] points published per anchor           } zeroed before the launch
     unsigned long long* gran;                  // [n_sets*B] {tag = 1, sum fd} granules     }
-    unsigned char* fs;                         // anchor feature operand images [B][NCH][FSIDE]
-    float* cs;                                 // normalised sampled codes of every set [nset][128][LDK]
+    unsigned char* fs;                         // anchor feature operand stages [B][NCH2][16 KB] (ring format H, or F in f32 mode)
+    unsigned char* csf;                        // anchor code operand stages    [B][NKC][16 KB]  (ring format F)
+    float* cs;                                 // normalised sampled codes of every set [nset][128][LDK] (the backward's context)
     float* nrm;                                // [nset][128] code norms
     int4* tapyx;                               // [nset][128]
     float4* tapw;                              // [nset][128]
-    unsigned fs_bytes, cs_bytes;               // sizes of the fs / cs regions (buffer descriptors)
-    int NCH, KQ, LDK;
+    unsigned fs_bytes, csf_bytes, cs_bytes;    // sizes of the fs / csf / cs regions (buffer descriptors)
+    int NCH2, NKC, kper;                       // C / 32 feature stages; code stages of kper (multiple of 8, <= 32) channels
+    int KQ, LDK;
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int n_owner;                               // workgroups [0, n_owner) share phase 1
     int pointwise;

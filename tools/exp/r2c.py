@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Race hunt: repeat the fused forward on one input, report which tiles / rows / columns differ from the three-launch result."""
+import os, sys, json
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from stego_amd import capi
+
+dev = torch.device("cuda:0")
+cfg = bench.Cfg()
+C, H, W, K = bench.WORKLOADS["vits8_224"]
+B, S, n_neg = 32, 11, 5
+P = S * S
+sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 1000 + i, dev) for i in range(4)]
+d = sets[0]
+prec = capi.PREC_F16X3 if (len(sys.argv) < 2 or sys.argv[1] == "f16x3") else capi.PREC_F32
+desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
+def run(d=None):
+    d = d or sets[0]
+    out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+    torch.cuda.synchronize()
+    return out
+capi.debug_set("STEGO_FWD_VARIANT", 1)
+refs = [run(x) for x in sets]
+capi.debug_set("STEGO_FWD_VARIANT", 2)
+capi.debug_set("STEGO_DEBUG", int(os.environ.get("DEBUG", 0)))
+nbad = 0
+for rep in range(int(os.environ.get("REPS", 30))):
+    out = run(sets[rep % 4]); ref = refs[rep % 4]
+    w = out[5][0].reshape(7, B, P, P); wr = ref[5][0].reshape(7, B, P, P)
+    cd = torch.cat([out[1].reshape(1, B, P, P), out[2].reshape(1, B, P, P), out[4].reshape(n_neg, B, P, P)]); cdr = torch.cat([ref[1].reshape(1, B, P, P), ref[2].reshape(1, B, P, P), ref[4].reshape(n_neg, B, P, P)])
+    ew = (w - wr).abs(); ec = (cd - cdr).abs()
+    badw = (ew > 1e-5); badc = (ec > 1e-5)
+    nanw = torch.isnan(w).reshape(7, B, -1).any(-1); nanc = torch.isnan(cd).reshape(7, B, -1).any(-1)
+    if nanw.any() or nanc.any(): print('NaN tiles w:', torch.nonzero(nanw).tolist()[:8], 'cd:', torch.nonzero(nanc).tolist()[:8])
+    badw = badw | torch.isnan(w); badc = badc | torch.isnan(cd)
+    if badw.any() or badc.any():
+        nbad += 1
+        tiles = torch.nonzero(badw.reshape(7, B, -1).any(-1) | badc.reshape(7, B, -1).any(-1)).tolist()
+        msg = []
+        for p, b in tiles[:6]:
+            rows = torch.nonzero(badw[p, b].any(1)).flatten().tolist(); cols = torch.nonzero(badw[p, b].any(0)).flatten().tolist()
+            crow = torch.nonzero(badc[p, b].any(1)).flatten().tolist(); ccol = torch.nonzero(badc[p, b].any(0)).flatten().tolist()
+            colerr = ew[p, b].max(0).values; rowerr = ew[p, b].max(1).values
+            qb = int(colerr.argmax())
+            shift = (.18, .12, .46)[min(p, 2)]
+            # fd of the reference column (w = fd - rowmean - shift; rowmean of the reference from its own w: mean_j w = -shift)
+            wr_t = wr[p, b].double(); w_t = w[p, b].double()
+            fd_ref_col = (wr_t[:, qb] + shift)          # up to the (common) row mean
+            err_col = (w_t[:, qb] - wr_t[:, qb])
+            A = torch.stack([fd_ref_col, torch.ones_like(fd_ref_col)], 1)
+            sol = torch.linalg.lstsq(A, err_col.unsqueeze(1)).solution.flatten()
+            resid = float((A @ sol - err_col).abs().max())
+            topc = torch.topk(colerr, 6); topr = torch.topk(rowerr, 4)
+            msg.append(dict(p=p, b=b, n_w_rows=len(rows), n_w_cols=len(cols), top_cols=[(int(i), round(float(v), 6)) for v, i in zip(topc.values, topc.indices)],
+                            fit_alpha=round(float(sol[0]), 6), fit_const=round(float(sol[1]), 6), fit_resid=round(resid, 7), median_col_err=float(colerr.median())))
+        print(json.dumps(dict(rep=rep, n_tiles=len(tiles), detail=msg)), flush=True)
+print("bad repeats: %d" % nbad)

@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Race forensics: for a bad column q of a bad tile, find which 32-channel stage of the B operand was wrong and what it was replaced by."""
+import os, sys, json
+import torch, torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from stego_amd import capi
+dev = torch.device("cuda:0")
+cfg = bench.Cfg()
+C, H, W, K = bench.WORKLOADS["vits8_224"]
+B, S, n_neg = 32, 11, 5
+P = S * S
+sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 1000 + i, dev) for i in range(4)]
+desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+def run(d):
+    out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+    torch.cuda.synchronize()
+    return out
+def sample(t, coords):
+    return F.grid_sample(t, coords.permute(0, 2, 1, 3), padding_mode='border', align_corners=True)
+capi.debug_set("STEGO_FWD_VARIANT", 1)
+refs = [run(x) for x in sets]
+capi.debug_set("STEGO_FWD_VARIANT", 2)
+capi.debug_set("STEGO_DEBUG", int(os.environ.get("DEBUG", 0)))
+found = 0
+for rep in range(int(os.environ.get("REPS", 3000))):
+    si = rep % 4
+    d = sets[si]
+    out = run(d); ref = refs[si]
+    w = out[5][0].reshape(7, B, P, P).double(); wr = ref[5][0].reshape(7, B, P, P).double()
+    ew = (w - wr).abs()
+    if not (ew > 1e-5).any():
+        continue
+    tiles = torch.nonzero((ew > 1e-5).reshape(7, B, -1).any(-1)).tolist()
+    for p, b in tiles[:2]:
+        colerr = ew[p, b].max(0).values
+        q = int(colerr.argmax())
+        err = (w[p, b, :, q] - wr[p, b, :, q])                       # over the 121 anchor points
+        # operands as the reference defines them
+        fa = sample(d["feats"][b:b + 1].contiguous(), d["coords1"][b:b + 1]).reshape(C, P).double()
+        fa = fa / fa.norm(dim=0, keepdim=True).clamp_min(1e-10)         # [C, P] normalised anchors
+        if p == 1:
+            img = d["feats_pos"][b:b + 1]
+        else:
+            img = d["feats"][int(d["perms"][p - 2, b]):int(d["perms"][p - 2, b]) + 1]
+        fb = sample(img.contiguous(), d["coords2"][b:b + 1]).reshape(C, P).double()       # raw B samples [C, P]
+        nb = fb[:, q].norm()
+        best = None
+        fd_true = (fa.t() @ (fb[:, q] / nb))
+        allres = []
+        for s in range(C // 32):
+            A = torch.cat([fa[32 * s:32 * s + 32, :].t(), fd_true.unsqueeze(1)], 1)     # [P, 33]: stage error + a scale term
+            sol = torch.linalg.lstsq(A.cpu(), (err.unsqueeze(1) * (1 + 1.0 / P)).cpu()).solution.flatten().to(A.device)
+            allres.append(round(float((A @ sol - err).norm() / err.norm()), 3))
+        print("combined stage+scale residuals per stage:", allres, "err_norm", float(err.norm()), "err_max", float(err.abs().max()))
+        for s in range(C // 32):
+            A = torch.cat([fa[32 * s:32 * s + 32, :].t(), fd_true.unsqueeze(1)], 1)
+            sol = torch.linalg.lstsq(A.cpu(), (err.unsqueeze(1) * (1 + 1.0 / P)).cpu()).solution.flatten().to(A.device)
+            res = float((A @ sol - err).norm() / err.norm())
+            if best is None or res < best[1]:
+                best = (s, res, sol[:32], float(sol[32]))
+        print("best stage", best[0], "residual", round(best[1], 4), "scale term", best[3])
+        best = best[:3]
+        s, res, delta = best
+        delta = delta * nb                                              # = (what was used) - (true raw b) over the stage's 32 channels
+        truth = fb[32 * s:32 * s + 32, q]
+        used = truth + delta
+        cands = {"zero": torch.zeros_like(truth)}
+        for ds_ in (-4, -2, -1, 1, 2, 4):
+            if 0 <= s + ds_ < C // 32: cands["stage%+d same point" % ds_] = fb[32 * (s + ds_):32 * (s + ds_) + 32, q]
+        for dq in (-16, -8, -2, -1, 1, 2, 8, 16, 32, -32):
+            if 0 <= q + dq < P: cands["same stage point%+d" % dq] = fb[32 * s:32 * s + 32, q + dq]
+        for osi in range(4):                                            # the same tile position of the other input sets (stale LDS of an earlier launch)
+            if osi == si: continue
+            od = sets[osi]
+            oimg = od["feats_pos"][b:b + 1] if p == 1 else od["feats"][int(od["perms"][p - 2, b]):int(od["perms"][p - 2, b]) + 1]
+            ofb = sample(oimg.contiguous(), od["coords2"][b:b + 1]).reshape(C, P).double()
+            for ds_ in (0, -4, 4):
+                if 0 <= s + ds_ < C // 32: cands["set%d stage%+d same point (raw)" % (osi, ds_)] = ofb[32 * (s + ds_):32 * (s + ds_) + 32, q]
+        # brute force: which single tap register (16 B per lane) content would explain delta?
+        def taps_of(qq):
+            hh, ww = qq // S, qq % S
+            cx, cy = [float(v) for v in d["coords2"][b, ww, hh]]
+            ix = min(max((cx + 1) * 0.5 * (W - 1), 0.0), W - 1.0); iy = min(max((cy + 1) * 0.5 * (H - 1), 0.0), H - 1.0)
+            x0, y0 = int(ix), int(iy); x1, y1 = min(x0 + 1, W - 1), min(y0 + 1, H - 1)
+            wx1, wy1 = ix - x0, iy - y0
+            return [((y0, x0), (1 - wx1) * (1 - wy1)), ((y0, x1), wx1 * (1 - wy1)), ((y1, x0), (1 - wx1) * wy1), ((y1, x1), wx1 * wy1)]
+        im = img[0].double()                                            # [C, H, W]
+        mine = taps_of(q)
+        # all pixel vectors of all stages: [12, 32, H, W]
+        imst = im.reshape(C // 32, 32, H, W)
+        tap_scores = []
+        dn = float(delta.norm()) + 1e-30
+        for k, ((yy, xx), wk) in enumerate(mine):
+            if wk == 0: continue
+            cur = imst[s, :, yy, xx]
+            cand = wk * (imst - cur.reshape(1, 32, 1, 1))              # [12, 32, H, W]: register k held pixel (y,x) of stage s'
+            sc = (cand - delta.reshape(1, 32, 1, 1)).norm(dim=1) / dn   # [12, H, W]
+            v, idx = sc.reshape(-1).min(0)
+            s2, rem = divmod(int(idx), H * W); y2, x2 = divmod(rem, W)
+            tap_scores.append((round(float(v), 4), "tap%d (w=%.3f, pixel %d,%d) held pixel (%d,%d) of stage %d" % (k, wk, yy, xx, y2, x2, s2)))
+        # hypothesis W: ALL stages of this point were blended with other (legit) bilinear weights w' of the same 4 pixels:
+        # fd_bad[:, q] = A^T (T w') / ||T w'||  with T = the 4 tap pixels over all C channels.  Solve u = w' / ||T w'|| by least squares,
+        # then ||T u|| must come out as 1 and sum(u) * ||T w'|| as 1 if the hypothesis holds.
+        Tall = torch.stack([im[:, yy, xx] for (yy, xx), _ in mine], 1)          # [C, 4]
+        fd_ref_col = fa.t() @ (fb[:, q] / nb)
+        fd_bad_col = fd_ref_col + err * (1 + 1.0 / P)
+        M = fa.t() @ Tall                                                       # [P, 4]
+        u = torch.linalg.lstsq(M.cpu(), fd_bad_col.unsqueeze(1).cpu()).solution.flatten().to(M.device)
+        resW = float((M @ u - fd_bad_col).norm() / err.norm())
+        tnorm = float((Tall @ u).norm())
+        wprime = (u / u.sum())
+        wsol = wprime; wres = resW
+        tap_scores.sort()
+        if res < 0.02:
+            Ts = torch.stack([imst[s, :, yy, xx] for (yy, xx), _ in mine], 1)      # [32, 4]
+            ws = torch.linalg.lstsq(Ts.cpu(), used.unsqueeze(1).cpu()).solution.flatten()
+            wres = float((Ts.cpu() @ ws - used.cpu()).norm() / delta.cpu().norm())
+            print("  PERFECT CASE stage-local weights fit:", [round(float(x), 3) for x in ws], "true", [round(wk, 3) for _, wk in mine], "resid/delta", round(wres, 4))
+            print("  delta per channel:", [round(float(x), 2) for x in delta])
+            print("  truth per channel:", [round(float(x), 2) for x in truth])
+            # one VGPR (component e of one tap, 8 lanes = 8 channel groups) held something else: brute force over (tap, stage', comp', pixel)
+            dl = delta.reshape(8, 4)                                   # [g8, e]
+            e_bad = int(dl.abs().sum(0).argmax())
+            d8 = dl[:, e_bad]
+            im8 = im.reshape(C // 32, 8, 4, H, W)                      # [s', g8, e', y, x]
+            outl = []
+            for k, ((yy, xx), wk) in enumerate(mine):
+                if wk == 0: continue
+                cur = im8[s, :, e_bad, yy, xx]                        # [8]
+                cand = wk * (im8 - cur.reshape(1, 8, 1, 1, 1))        # [s', 8, e', y, x]
+                sc = (cand - d8.reshape(1, 8, 1, 1, 1)).norm(dim=1) / d8.norm()      # [s', e', y, x]
+                v, idx = sc.reshape(-1).min(0)
+                s2, rem = divmod(int(idx), 4 * H * W); e2, rem = divmod(rem, H * W); y2, x2 = divmod(rem, W)
+                outl.append((round(float(v), 4), "tap%d w=%.3f pix(%d,%d) comp %d held stage %d comp %d pix (%d,%d)" % (k, wk, yy, xx, e_bad, s2, e2, y2, x2)))
+                # or zero / or the other set of the previous launch (sets[(si - 1) % 4])
+                od = sets[(si - 1) % 4]
+                oimg = od["feats_pos"][b:b + 1] if p == 1 else od["feats"][int(od["perms"][p - 2, b]):int(od["perms"][p - 2, b]) + 1]
+                oim8 = oimg[0].double().reshape(C // 32, 8, 4, H, W)
+                cand = wk * (oim8 - cur.reshape(1, 8, 1, 1, 1))
+                sc = (cand - d8.reshape(1, 8, 1, 1, 1)).norm(dim=1) / d8.norm()
+                v, idx = sc.reshape(-1).min(0)
+                s2, rem = divmod(int(idx), 4 * H * W); e2, rem = divmod(rem, H * W); y2, x2 = divmod(rem, W)
+                outl.append((round(float(v), 4), "PREV LAUNCH same perm image: tap%d held stage %d comp %d pix (%d,%d)" % (k, s2, e2, y2, x2)))
+                zc = (wk * (0 - cur) - d8).norm() / d8.norm()
+                outl.append((round(float(zc), 4), "tap%d held zero" % k))
+            outl.sort()
+            print("  single VGPR hypothesis:", outl[:4])
+            alls = []
+            for s2 in range(C // 32):
+                for q2 in range(P):
+                    v = fb[32 * s2:32 * s2 + 32, q2]
+                    alls.append((float((used - v).norm() / delta.norm()), s2, q2))
+            alls.sort()
+            print("  closest (stage, point) sample vectors to what was used:", [(round(a, 3), b_, c_) for a, b_, c_ in alls[:4]])
+        big = [(int(i), round(float(delta[i]), 3), round(float(truth[i]), 3)) for i in torch.nonzero(delta.abs() > 0.05 * truth.abs().max()).flatten().tolist()]
+        scores = sorted(((float((used - v).norm() / (used.norm() + 1e-30)), k) for k, v in cands.items()))
+        print(json.dumps(dict(rep=rep, set=si, p=p, b=b, q=q, stage=s, fit_residual=round(res, 4), used_norm=round(float(used.norm()), 4), true_norm=round(float(truth.norm()), 4),
+                              delta_norm=round(float(delta.norm()), 4), tap_register_hypothesis=tap_scores[:2], true_weights=[round(wk, 3) for _, wk in mine], fitted_weights=[round(float(x), 3) for x in wsol], residual_over_err=round(wres, 4), norm_check=round(tnorm, 4))), flush=True)
+        found += 1
+    if found >= 40: break
+print("done, forensics on %d columns" % found)

@@ -45,6 +45,10 @@ for prec in (capi.PREC_F16X3,):
         print("prec=%d debug=%d  (us since the first workgroup started; p0 / p50 / p100 over %d workgroups)" % (prec, dbg, nt))
         for k in (0, 8, 9, 10, 1, 6, 7, 2, 3, 4, 5):
             print("   %-26s %7.2f %7.2f %7.2f" % ((names[k],) + tuple(np.percentile(rel[:, k], [0, 50, 100]))))
+        loop = rel[:, 3] - rel[:, 2]
+        print("   ring loop (anchor ready -> E0) percentiles 0/10/25/50/75/90/100:", np.round(np.percentile(loop, [0, 10, 25, 50, 75, 90, 100]), 1))
+        print("   ring loop mean by XCD (workgroup %% 8):", [round(float(loop[x::8].mean()), 1) for x in range(8)])
+        print("   ring loop mean by slot (workgroup // 8) quartiles:", [round(float(loop[8 * a: 8 * a + 56].mean()), 1) for a in (0, 7, 14, 21)])
         if os.environ.get("DUMP"):
             np.save(os.path.join(ROOT, "gpurun_out", "stamps_fused.npy"), rel)
         capi.debug_set("STEGO_DEBUG", 0)
