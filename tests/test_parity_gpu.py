@@ -266,43 +266,6 @@ def test_split_fp16_error_bound_on_adversarial_inputs():
     dict(B=2, C=8, H=3, W=70, K=6, S=4, n_neg=1),       # W > 64: the backward's band (LDS) unsample fallback
     dict(B=2, C=64, H=40, W=40, K=70, S=11, n_neg=2),   # 32 < W <= 64: 4 pixel tiles per row in the unsample kernel
 ])
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
-def test_fused_forward_stress_rotating_inputs_against_three_launch_path(precision):
-    """The fused forward overlaps two wave teams through an LDS ring, in-launch hand-offs between workgroups and asynchronous
-    copies.  A race there shows up rarely and only when consecutive launches see DIFFERENT data (stale bytes of an
-    identical previous launch are the right bytes): rotate four input sets for 400 launches and compare every output with
-    the three-launch path (separate sampling / tile / finalize kernels, no in-launch hand-off) of the same library."""
-    import bench
-    dev = torch.device("cuda:0")
-    C, H, W, K = bench.WORKLOADS["vits8_224"]
-    B, S, n_neg = 32, 11, 5
-    cfg = bench.Cfg()
-    sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 4000 + i, dev) for i in range(4)]
-    prec = capi.PREC_F16X3 if precision == "f16x3" else capi.PREC_F32
-    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
-
-    def run(d):
-        out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
-        torch.cuda.synchronize()
-        return out
-
-    try:
-        capi.debug_set("STEGO_FWD_VARIANT", 1)
-        refs = [[t.clone() for t in (o[0],) + tuple(o[1:5]) + (o[5][0],)] for o in (run(d) for d in sets)]
-        capi.debug_set("STEGO_FWD_VARIANT", 0)
-        worst = 0.0
-        for rep in range(400):
-            o = run(sets[rep % 4])
-            got = (o[0],) + tuple(o[1:5]) + (o[5][0],)
-            for g, r in zip(got, refs[rep % 4]):
-                assert not torch.isnan(g).any()
-                worst = max(worst, float((g - r).abs().max()))
-            assert worst < 2e-6, (rep, worst)
-    finally:
-        capi.debug_set("STEGO_FWD_VARIANT", 0)
-
-
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_edge_shapes(shape, precision):
     d = O.synth_inputs(seed=5, **shape)
@@ -525,3 +488,39 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
         d_ref = w_ref - ref_w0
         d_dev = w_dev - ref_w0
         assert float(torch.nn.functional.cosine_similarity(d_dev.flatten(), d_ref.flatten(), dim=0)) > 0.98
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_fused_forward_stress_rotating_inputs_against_three_launch_path(precision):
+    """The fused forward overlaps two wave teams through an LDS ring, in-launch hand-offs between workgroups and asynchronous
+    copies.  A race there shows up rarely and only when consecutive launches see DIFFERENT data (stale bytes of an
+    identical previous launch are the right bytes): rotate four input sets for 400 launches and compare every output with
+    the three-launch path (separate sampling / tile / finalize kernels, no in-launch hand-off) of the same library."""
+    import bench
+    dev = torch.device("cuda:0")
+    C, H, W, K = bench.WORKLOADS["vits8_224"]
+    B, S, n_neg = 32, 11, 5
+    cfg = bench.Cfg()
+    sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 4000 + i, dev) for i in range(4)]
+    prec = capi.PREC_F16X3 if precision == "f16x3" else capi.PREC_F32
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
+
+    def run(d):
+        out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        capi.debug_set("STEGO_FWD_VARIANT", 1)
+        refs = [[t.clone() for t in (o[0],) + tuple(o[1:5]) + (o[5][0],)] for o in (run(d) for d in sets)]
+        capi.debug_set("STEGO_FWD_VARIANT", 0)
+        worst = 0.0
+        for rep in range(400):
+            o = run(sets[rep % 4])
+            got = (o[0],) + tuple(o[1:5]) + (o[5][0],)
+            for g, r in zip(got, refs[rep % 4]):
+                assert not torch.isnan(g).any()
+                worst = max(worst, float((g - r).abs().max()))
+            assert worst < 2e-6, (rep, worst)
+    finally:
+        capi.debug_set("STEGO_FWD_VARIANT", 0)
