@@ -102,13 +102,26 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
 /*
  * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws made by the
  * caller in the reference's order (coords1 :366, coords2 :367, super_perm x n_neg :383).
- * Three launches on `stream`:
- *   1. sample_norm_kernel: every (role,image) set - anchor @coords1, positive @coords2, negatives
- *      orig[perm] @coords2 - bilinearly sampled (sample, :287-288: border, align_corners) and
- *      L2-normalised (norm, :275-276) once;
- *   2. corr_tile_kernel: per (pair-set,image) both correlation tensors (tensor_correlation, :283-284)
- *      on MFMA, the pointwise row centring (:332), clamp*(fd-shift) (:337-345), per-tile partial sums;
- *   3. corr_finalize_kernel: the batch-global mean (old_mean, :331,:333) and the two .mean()s (:393,:395).
+ *
+ * Channels-last maps of the ViT widths (C = 384 / 768, K even) take the FUSED path: ONE kernel launch
+ * (corr_fused_kernel) in which every workgroup owns one (pair-set, image) tile:
+ *   - the anchor sets (@coords1) are sampled (sample, :287-288: border, align_corners) and L2-normalised
+ *     (norm, :275-276) once, by the workgroups of the XCD that caches their image, and handed to the tiles that
+ *     need them through write-through stores + a counter (no kernel boundary);
+ *   - the positive / negative sets (@coords2, orig[perm]) are gathered straight into an LDS ring by a team of
+ *     gather waves while a team of MFMA waves runs both correlation tensors (tensor_correlation, :283-284);
+ *   - the pointwise row centring (:332), clamp*(fd-shift) (:337-345) and the batch-global old_mean (:331,:333: a
+ *     rendezvous of the 32 tiles of a pair-set inside the launch) finish in the same workgroup;
+ *   - the last workgroup to finish writes the two .mean()s (:393,:395) and the saved means.
+ * Anything else (NCHW maps, other widths, odd K) takes three launches: sample_norm_kernel, corr_tile_kernel,
+ * corr_finalize_kernel - same results.
+ *
+ * Workspace and hand-off words.  The fused path keeps a few hundred bytes of counters in the workspace that must be
+ * ZERO when a launch starts; every launch leaves them zero again.  stego_corr_fwd() zeroes them itself (one extra
+ * memset node in front of the kernel, ~5 us): it accepts any workspace memory.  A caller that keeps its workspace
+ * calls stego_corr_workspace_prepare() once after allocating it (and again after a launch that FAILED), and then
+ * stego_corr_fwd_prepared(): same arguments and results, one launch.  A workspace serves one call at a time
+ * (stream order is enough).
  *
  *   feats, feats_pos : [B,C,H,W]   (orig_feats, orig_feats_pos; never differentiated)
  *   code, code_pos   : [B,K,H,W]   (orig_code, orig_code_pos)
@@ -125,6 +138,17 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
  *                      backward needs (the feature side is no_grad in the reference, :326).
  */
 int stego_corr_fwd(const StegoCorrDesc* desc,
+                   const StegoMap* feats, const StegoMap* feats_pos,
+                   const StegoMap* code, const StegoMap* code_pos,
+                   const float* coords1, const float* coords2, const int64_t* perms,
+                   float* loss_means,
+                   float* pos_intra_cd, float* pos_inter_cd,
+                   float* neg_inter_loss, float* neg_inter_cd,
+                   float* saved_w, float* saved_mean, void* saved_ctx,
+                   void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+int stego_corr_workspace_prepare(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes, stego_stream_t stream);
+int stego_corr_fwd_prepared(const StegoCorrDesc* desc,
                    const StegoMap* feats, const StegoMap* feats_pos,
                    const StegoMap* code, const StegoMap* code_pos,
                    const float* coords1, const float* coords2, const int64_t* perms,

@@ -58,6 +58,8 @@ SIGNATURES = {
     "stego_knn_topk": (c_int32, [_P, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64,
                                  _P, _P, _P, c_size_t, _P]),
     "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
+    "stego_corr_fwd_prepared": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
+    "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
                                + [c_int32, POINTER(c_float)]),
     "stego_corr_bwd_workspace_bytes": (c_size_t, [_D]),
@@ -107,6 +109,7 @@ def debug_set(name, value):
 
 def _check(rc):
     if rc != 0:
+        _WS_CACHE.clear()            # a kept workspace may hold dirty hand-off words after a failed launch
         msg = load().stego_error_string(rc).decode()
         raise RuntimeError("libstego_corr error %d: %s" % (rc, msg))
 
@@ -150,7 +153,34 @@ def _empty_bytes(n, dev):
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
 
 
-def _fwd_buffers(lib, desc, dev, need_grad, flat=False):
+# Forward workspaces are kept (per device, stream and descriptor): the fused forward hands data between workgroups through
+# a few counters in the workspace that must be zero when a launch starts and that every launch leaves zero again.  A kept
+# workspace is prepared once (stego_corr_workspace_prepare) and then costs neither an allocation nor a memset per call.
+_WS_CACHE = {}
+_WS_CACHE_MAX = 16
+
+
+def reset_workspaces():
+    """Forget the kept forward workspaces (call after a launch that failed: its counters may be dirty)."""
+    _WS_CACHE.clear()
+
+
+def _prepared_ws(lib, desc, dev):
+    n = int(lib.stego_corr_workspace_bytes(byref(desc)))
+    stream = _stream()
+    key = (dev.index, int(stream or 0), n, bytes(desc))
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        if len(_WS_CACHE) >= _WS_CACHE_MAX:
+            _WS_CACHE.pop(next(iter(_WS_CACHE)))
+        ws = _empty_bytes(n, dev)
+        with torch.cuda.device(dev):
+            _check(lib.stego_corr_workspace_prepare(byref(desc), _ptr(ws), ws.numel(), stream))
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def _fwd_buffers(lib, desc, dev, need_grad, flat=False, keep_ws=False):
     B, S, n_neg = desc.B, desc.S, desc.n_neg
     f32 = dict(dtype=torch.float32, device=dev)
     shp = (S ** 4,) if flat else (S, S, S, S)
@@ -162,7 +192,7 @@ def _fwd_buffers(lib, desc, dev, need_grad, flat=False):
     saved_w = torch.empty((2 + n_neg) * B, S ** 4, **f32) if need_grad else None
     saved_mean = torch.empty(2 + n_neg, **f32) if need_grad else None
     saved_ctx = _empty_bytes(lib.stego_corr_saved_ctx_bytes(byref(desc)), dev) if need_grad else None
-    ws = _empty_bytes(lib.stego_corr_workspace_bytes(byref(desc)), dev)
+    ws = _prepared_ws(lib, desc, dev) if keep_ws else _empty_bytes(lib.stego_corr_workspace_bytes(byref(desc)), dev)
     return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean, saved_ctx, ws
 
 
@@ -176,10 +206,10 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
     coords2 = _dense(coords2, torch.float32)
     perms = _dense(perms, torch.int64) if desc.n_neg else None
     (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved_w, saved_mean, saved_ctx, ws) = _fwd_buffers(
-        lib, desc, dev, need_grad)
+        lib, desc, dev, need_grad, keep_ws=True)
     mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
     with torch.cuda.device(dev):
-        _check(lib.stego_corr_fwd(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
+        _check(lib.stego_corr_fwd_prepared(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp),
                                   _ptr(coords1), _ptr(coords2), _ptr(perms),
                                   _ptr(loss_means), _ptr(intra_cd), _ptr(inter_cd), _ptr(neg_loss), _ptr(neg_cd),
                                   _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx), _ptr(ws), ws.numel(), _stream()))

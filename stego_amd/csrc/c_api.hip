@@ -12,7 +12,8 @@ hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 bool fused_supported(const FusedParams& prm, int precision);
-hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, hipStream_t stream, hipEvent_t* ev);
+hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, bool prepared, hipStream_t stream, hipEvent_t* ev);
+hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStream_t stream);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
@@ -94,7 +95,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
-    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8, 256);    // counters 256 B apart (ANCHOR_CNT_STRIDE)
+    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8, 256) + 256;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
     g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.csf_bytes + g.ctx_bytes;
     g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
     return g;
@@ -211,6 +212,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     fp.stats = prm.stats;
     fp.anchor_cnt = reinterpret_cast<unsigned*>(sync);
     fp.gran = reinterpret_cast<unsigned long long*>(sync + (size_t)d->B * 256);
+    fp.done_cnt = reinterpret_cast<unsigned*>(sync + g.sync_bytes - 256);
     fp.fs = fs;
     fp.csf = csf;
     fp.cs = sp.cs; fp.nrm = sp.nrm; fp.tapyx = sp.tapyx; fp.tapw = sp.tapw;
@@ -230,10 +232,10 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     return STEGO_OK;
 }
 
-hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [4] */)
+hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [4] */, bool prepared = false)
 {
     hipError_t e;
-    if (pl.use_fused) return launch_corr_fused(pl.fused, pl.precision, pl.sync_bytes, s, ev);
+    if (pl.use_fused) return launch_corr_fused(pl.fused, pl.precision, pl.sync_bytes, prepared, s, ev);
     if (ev) (void)hipEventRecord(ev[0], s);
     if ((e = launch_corr_sample(pl.samp, pl.precision, s)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], s);
@@ -320,6 +322,33 @@ int stego_corr_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap
     return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr));
 }
 
+int stego_corr_workspace_prepare(const StegoCorrDesc* d, void* workspace, size_t workspace_bytes, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    int rc = check_desc(d, false);
+    if (rc) return rc;
+    if (!workspace) return STEGO_ERR_NULL;
+    const Geometry g = geometry(d, false);
+    if (workspace_bytes < g.ws_bytes) return STEGO_ERR_WORKSPACE;
+    // the hand-off words sit right behind the per-tile sums (plan_fwd carves the same way)
+    return hip_rc(hipMemsetAsync(static_cast<unsigned char*>(workspace) + g.stats_bytes, 0, g.sync_bytes,
+                                 static_cast<hipStream_t>(stream)));
+}
+
+int stego_corr_fwd_prepared(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code,
+                            const StegoMap* code_pos, const float* coords1, const float* coords2, const int64_t* perms,
+                            float* loss_means, float* pos_intra_cd, float* pos_inter_cd, float* neg_inter_loss,
+                            float* neg_inter_cd, float* saved_w, float* saved_mean, void* saved_ctx, void* workspace,
+                            size_t workspace_bytes, stego_stream_t stream)
+{
+    FwdPlan pl;
+    int rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
+                      pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
+                      workspace_bytes, &pl);
+    if (rc) return rc;
+    return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr, true));
+}
+
 int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos,
                            const StegoMap* code, const StegoMap* code_pos, const float* coords1, const float* coords2,
                            const int64_t* perms, float* loss_means, float* pos_intra_cd, float* pos_inter_cd,
@@ -339,8 +368,9 @@ int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const 
     for (int i = 0; i < 4; ++i)
         if ((e = hipEventCreate(&ev[i])) != hipSuccess) return hip_rc(e);
     double acc[3] = {0.0, 0.0, 0.0};
+    if (pl.use_fused) e = prepare_corr_fused(pl.fused, pl.sync_bytes, s);
     for (int i = 0; i < iters && e == hipSuccess; ++i) {
-        e = run_fwd(pl, s, ev);
+        e = run_fwd(pl, s, ev, true);
         if (e == hipSuccess) e = hipEventSynchronize(ev[3]);
         for (int k = 0; k < 3 && e == hipSuccess; ++k) {
             float ms = 0.f;

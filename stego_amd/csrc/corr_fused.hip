@@ -381,11 +381,17 @@ __device__ __forceinline__ unsigned lds_address(const void* p)
     return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p);
 }
 
+// The ring's barrier.  It is also a SCHEDULING fence: the software pipeline of the gather team (commit the stage gathered
+// two barriers ago, then re-issue its registers) only exists if the compiler keeps each stage's work between its two
+// barriers.  Without the fence it hoisted the blend of the NEXT stage above the barrier, which needs that stage's gathers:
+// an s_waitcnt vmcnt(0) per stage, i.e. no prefetch distance at all (1.2 -> 2.0 us per stage).
 __device__ __forceinline__ void ring_barrier()
 {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 // one feature stage in format H: a.b ~= ah.bh + ah.bl + al.bh over 32 channels (2 k-steps of 16)
 __device__ __forceinline__ void mma_stage_h(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
@@ -823,6 +829,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             TL(n, 1);
             commit_feat(ga, n + 2, false);
             TL(n, 2);
+            __builtin_amdgcn_sched_barrier(0);
             issue_feat(ga, n + 4 - NKC);
             TL(n, 3);
             TL(n + 1, 0);
@@ -830,6 +837,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             TL(n + 1, 1);
             commit_feat(gb, n + 3, false);
             TL(n + 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
             issue_feat(gb, n + 5 - NKC);
             TL(n + 1, 3);
         }
@@ -896,7 +904,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     __syncthreads();                             // E1: Tfd and the four partial sums are complete
     if (tid == 0) {
         const float sfd = (red[0] + red[1]) + (red[2] + red[3]);
-        prm.stats[(size_t)tile * 4 + 0] = sfd;
+        __hip_atomic_store(prm.stats + (size_t)tile * 4 + 0, sfd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (rendezvous)                          // one aligned 8-byte write-through store: {tag, value}
             __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1001,51 +1009,68 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         clamp_part += __shfl_xor(clamp_part, m, 64);
     }
     if (lane == 0) { red[16 + wave8 * 2] = loss_part; red[16 + wave8 * 2 + 1] = clamp_part; }
+    const bool gave_up = omv[1] == 0.f;
+    if (gave_up) __threadfence();                // (rare) whoever repairs this tile must see its cd / loss: release my stores
     __syncthreads();
+    // ---- my sums, write-through; then one ticket: the LAST workgroup of the launch finishes the job (below)
+    float* fin = red + 48;                       // [0] 1 = I am the last workgroup
     if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
         for (int w = 0; w < FUSED_WAVES; ++w) { s1 += red[16 + w * 2]; s2 += red[16 + w * 2 + 1]; }
         float* st = prm.stats + (size_t)tile * 4;
-        st[1] = s1; st[2] = s2; st[3] = omv[1];
+        __hip_atomic_store(st + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + 3, omv[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the write-through stores have landed
+        const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin[0] = t == (unsigned)(n_tiles - 1) ? 1.f : 0.f;
     }
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
-}
+    __syncthreads();
+    if (fin[0] == 0.f) return;
 
-// The three scalars and the saved means, from the per-tile sums in image order (modules.py:331,393,395):
-//   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2).
-// Blocks 1.. : one per negative tile; a tile whose rendezvous gave up (stats[3] == 0) is repaired here:
-//   loss = lp - old_mean * clamp(cd)   (the same fma the tile kernel uses).  Normally every block but 0 returns at once.
-__global__ void __launch_bounds__(NTHREADS) corr_fused_scalars_kernel(const FusedParams prm)
-{
-    const int B = prm.B, P2 = prm.P * prm.P;
+    // ================================================================= the last workgroup of the launch
+    // The three scalars and the saved means from the per-tile sums in image order (modules.py:331,393,395):
+    //   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
+    // tiles whose rendezvous gave up (stats[3] == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
+    // same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
+    float* sst = Tfd;                            // [n_tiles][4] staged copy of the stats (the ring is dead)
+    float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set
+    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
+        sst[i] = __hip_atomic_load(prm.stats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     const float inv_cnt = 1.f / ((float)B * (float)P2);
-    if (blockIdx.x == 0) {
-        if ((int)threadIdx.x < prm.n_sets) {
-            const int p = threadIdx.x;
-            float fs = 0.f, ls = 0.f, cs = 0.f;
-            for (int b = 0; b < B; ++b) {
-                const float* st = prm.stats + ((size_t)p * B + b) * 4;
-                fs += st[0]; ls += st[1]; cs += st[2];
-            }
-            const float om = prm.pointwise ? fs * inv_cnt : 0.f;
-            if (prm.saved_mean) prm.saved_mean[p] = om;
-            if (p < 2) prm.loss_means[p] = (ls - om * cs) * inv_cnt;
+    if (tid < prm.n_sets) {
+        float fsum = 0.f, lsum = 0.f, csum = 0.f;
+        for (int bb = 0; bb < B; ++bb) {
+            const float* st = sst + ((size_t)tid * B + bb) * 4;
+            fsum += st[0]; lsum += st[1]; csum += st[2];
         }
-        return;
+        const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
+        som[tid] = fsum * inv_cnt;
+        if (prm.saved_mean) prm.saved_mean[tid] = omp;
+        if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
     }
-    const int tile = 2 * B + (int)blockIdx.x - 1;            // negative tiles only carry a loss tensor
-    if (!prm.pointwise || prm.stats[(size_t)tile * 4 + 3] != 0.f) return;
-    const int p = tile / B;
-    float fs = 0.f;
-    for (int b = 0; b < B; ++b) fs += prm.stats[((size_t)p * B + b) * 4];
-    const float om = fs * inv_cnt;
-    const float cmin = prm.cmin, cmax = prm.cmax;
-    float* loss = prm.neg_loss + (size_t)(tile - 2 * B) * P2;
-    const float* cd = prm.neg_cd + (size_t)(tile - 2 * B) * P2;
-    for (int e = threadIdx.x; e < P2; e += NTHREADS) {
-        const float cl = fminf(fmaxf(cd[e], cmin), cmax);
-        loss[e] = __builtin_fmaf(-om, cl, loss[e]);
+    __syncthreads();
+    if (prm.pointwise) {
+        for (int t = 2 * B; t < n_tiles; ++t) {
+            if (sst[t * 4 + 3] != 0.f) continue;                   // (workgroup-uniform)
+            const float omp = som[t / B];
+            float* lossr = prm.neg_loss + (size_t)(t - 2 * B) * P2;
+            const float* cdr = prm.neg_cd + (size_t)(t - 2 * B) * P2;
+            for (int e = tid; e < P2; e += FUSED_THREADS) {
+                const float cdv = __hip_atomic_load(cdr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float lpv = __hip_atomic_load(lossr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float cl = fminf(fmaxf(cdv, cmin), cmax);
+                lossr[e] = __builtin_fmaf(-omp, cl, lpv);
+            }
+        }
     }
+    for (int i = tid; i < B; i += FUSED_THREADS)
+        __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < n_tiles; i += FUSED_THREADS)
+        __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch
@@ -1069,8 +1094,14 @@ bool fused_supported(const FusedParams& prm, int precision)
     return true;
 }
 
-hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sync_bytes, hipStream_t stream,
-                             hipEvent_t* ev /* null or [4]: before the memset, before / after the tile kernel, end */)
+// Zeroes the hand-off words of a workspace (once per workspace; every launch leaves them zero again).
+hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStream_t stream)
+{
+    return hipMemsetAsync(prm.anchor_cnt, 0, sync_bytes, stream);
+}
+
+hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sync_bytes, bool prepared, hipStream_t stream,
+                             hipEvent_t* ev /* null or [4]: before the memset, before / after the kernel, end */)
 {
     FusedParams prm = prm_in;
     const int n_tiles = prm.n_sets * prm.B;
@@ -1079,9 +1110,9 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     if (prm.n_owner < 1) prm.n_owner = 1;
     prm.timeout_ticks = (prm.debug & 64) ? 100 : 20000;           // 200 us of the 100 MHz clock
     const int lds = RING_LDS_BYTES;
+    hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipError_t e = hipMemsetAsync(prm.anchor_cnt, 0, sync_bytes, stream);      // counters + granules of this call
-    if (e != hipSuccess) return e;
+    if (!prepared && (e = prepare_corr_fused(prm, sync_bytes, stream)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], stream);
     const dim3 grid(n_tiles), block(FUSED_THREADS);
 #define STEGO_FUSED_LAUNCH(PR, N, NK)                                                                  \
@@ -1101,9 +1132,7 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
 #undef STEGO_FUSED_NK
 #undef STEGO_FUSED_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(corr_fused_scalars_kernel, dim3(1 + prm.n_neg * prm.B), dim3(NTHREADS), 0, stream, prm);
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (ev) { (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
     return hipGetLastError();
 }
 
