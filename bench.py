@@ -65,6 +65,16 @@ def algorithmic_flops_fwd(B, C, K, S, n_neg):
     return 2 * (2 + n_neg) * B * S ** 4 * (C + K)
 
 
+def algorithmic_bytes_bwd(B, K, H, W, S, n_neg):
+    """Backward of the code side (the feature side is no_grad, modules.py:326): reads saved_w and cd of every pair-set, the
+    sampled-code context of every set and the three upstream gradients (two scalars + one broadcast tensor: stride 0);
+    writes d_code and d_code_pos.  Every distinct tensor once, fp32."""
+    P = 2 + n_neg
+    LDK = (K + 7) // 8 * 8
+    nset = 2 + n_neg                       # anchor set is shared: (1 + 1 + n_neg) sampled sets of 128 x LDK rows
+    return 4 * (2 * P * B * S ** 4 + nset * B * 128 * LDK + 2 * B * K * H * W)
+
+
 def head_grad_numel(C, K, n_classes=27):
     """Trainable parameters whose gradients DDP all-reduces:
     cluster1 (C*K+K), cluster2 (C*C+C + C*K+K), linear_probe (K*n+n), cluster_probe (n*K)."""
@@ -102,6 +112,59 @@ def make_inputs(B, C, H, W, K, S, n_neg, seed, dev, layout="cl"):
         maps = [t.contiguous() for t in maps]                      # NCHW-contiguous: the generic (scalar gather) paths
     return dict(feats=maps[0], feats_pos=maps[1], code=maps[2], code_pos=maps[3],
                 coords1=coords1, coords2=coords2, perms=perms)
+
+
+def product_path(sets, cfg, args, kernel_step_s):
+    """Times the op as a training step calls it (train_segmentation.py:163-181): ContrastiveCorrelationLoss.forward with its own
+    RNG draws (coords1, coords2, one randperm per negative), the weighted sum and .backward() into the code maps -
+    eagerly, and replayed from a HIP graph (the draws are captured with the generator's graph-safe offsets)."""
+    from stego_amd.modules import ContrastiveCorrelationLoss
+    dev = sets[0]["feats"].device
+    loss_fn = ContrastiveCorrelationLoss(cfg)
+    codes = [(d["code"].detach().clone().requires_grad_(True), d["code_pos"].detach().clone().requires_grad_(True)) for d in sets]
+
+    def step(i):
+        d = sets[i]
+        c, cp = codes[i]
+        c.grad = None
+        cp.grad = None
+        (pil, _, pel, _, nl, _) = loss_fn(d["feats"], d["feats_pos"], None, None, c, cp)
+        (cfg.pos_intra_weight * pil + cfg.pos_inter_weight * pel + cfg.neg_inter_weight * nl.mean()).backward()
+
+    n = len(sets)
+    for i in range(n):
+        step(i)
+    torch.cuda.synchronize()
+    steps = max(40, args.steps // 2)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k % n)
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / steps
+    out = {"eager_ms_per_step": eager * 1e3, "eager_over_kernel_step": eager / kernel_step_s, "steps": steps,
+           "what": "ContrastiveCorrelationLoss(cfg)(feats, feats_pos, None, None, code, code_pos) incl. RNG draws; "
+                   "0.67 intra + 0.25 inter + 0.63 neg.mean(); .backward() into code / code_pos"}
+    try:
+        graphs = []
+        for i in range(n):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(i)
+            graphs.append(g)
+        torch.cuda.synchronize()
+        for k in range(8):
+            graphs[k % n].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            graphs[k % n].replay()
+        torch.cuda.synchronize()
+        gt = (time.perf_counter() - t0) / steps
+        out.update(graph_ms_per_step=gt * 1e3, graph_over_kernel_step=gt / kernel_step_s)
+    except Exception as e:      # noqa: BLE001
+        out.update(graph_ms_per_step=None, graph_error="%s: %s" % (type(e).__name__, str(e)[:200]))
+        torch.cuda.synchronize()
+    return out
 
 
 def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
@@ -208,7 +271,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(precision, steps, warmup):
+    def timed_run(precision, steps, warmup, fwd_only=args.fwd_only, collective=True):
         """W untimed + K timed steps of the whole job in one precision mode; returns (seconds, launch mode, desc)."""
         prec = capi.PREC_F32 if precision == "f32" else capi.PREC_F16X3
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
@@ -217,7 +280,7 @@ def main():
 
         def step_compute(i):
             d = sets[i]
-            need_grad = not args.fwd_only
+            need_grad = not fwd_only
             out = capi.corr_fwd(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
                                 as_channels_last(d["code"]), as_channels_last(d["code_pos"]), d["coords1"], d["coords2"],
                                 d["perms"], need_grad)
@@ -256,7 +319,7 @@ def main():
                 graphs[i].replay()
             else:
                 step_compute(i)
-            if dist is not None:
+            if dist is not None and collective:
                 # gradients of the segmentation head only (backbone frozen): one flat bucket per step.  async_op: RCCL's
                 # stream first waits for this step's kernels, then the all-reduce runs while the next step computes - in
                 # training it overlaps the next step's backbone forward the same way; every all-reduce is complete
@@ -293,8 +356,21 @@ def main():
         alt = {"precision": other, "value": world * B * steps_alt / dt_alt, "unit": "image-pairs/s",
                "ms_per_step": dt_alt / steps_alt * 1e3, "steps": steps_alt}
 
+    # ---- the forward alone (same graphs without the backward): the backward's share is the difference
+    split = None
+    if not args.fwd_only and not args.no_alt:
+        steps_f = max(20, args.steps // 4)
+        dt_f, _, _ = timed_run(args.precision, steps_f, max(4, args.warmup // 4), fwd_only=True, collective=False)
+        split = {"forward_ms": dt_f / steps_f * 1e3, "backward_ms": dt / args.steps * 1e3 - dt_f / steps_f * 1e3, "steps": steps_f}
+
+    # ---- the product path: ContrastiveCorrelationLoss(cfg)(...) + .backward() exactly as a training step calls it
+    # (train_segmentation.py:163-181): RNG draws, autograd.Function, weighted sum, backward - eager and graph-replayed
+    product = None
+    if rank == 0 and not args.no_alt:
+        product = product_path(sets, cfg, args, dt / args.steps)
+
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
-    roof = roof_mfma = None
+    roof = roof_mfma = roof_bwd = None
     fin_us = None
     if rank == 0:
         ms_samp = ms_main = ms_fin = 0.0
@@ -315,7 +391,6 @@ def main():
         ms_samp /= rounds
         ms_main /= rounds
         ms_fin /= rounds
-        fin_us = ms_fin * 1e3
         ab = algorithmic_bytes_fwd(B, C, H, W, K, S, n_neg)
         fl = algorithmic_flops_fwd(B, C, K, S, n_neg)
         traffic = None
@@ -325,28 +400,46 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_%s_B%d" % (args.workload, args.precision, B))
             except Exception:       # noqa: BLE001
                 traffic = None
-        # dominant kernel = the larger of the two forward stages; both are reported
-        kernels = {"sample_norm_kernel": ms_samp * 1e3, "corr_tile_kernel": ms_main * 1e3,
-                   "corr_finalize_kernel": ms_fin * 1e3}
-        # algorithmic bytes per stage (each distinct tensor once): the sampler reads feats (anchors), both code maps,
-        # coords and perms; the tile kernel reads feats_pos (and re-reads feats for the negatives: counted once, above)
-        # and writes every output
-        ab_in = 4 * (B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B
-        ab_out = ab - ab_in
-        dom = "sample_norm_kernel" if ms_samp >= ms_main else "corr_tile_kernel"
-        t_fwd = (ms_samp + ms_main + ms_fin) * 1e-3
-        ach = ab / t_fwd
-        roof = dict(bound="hbm", kernel="forward = sample_norm_kernel + corr_tile_kernel + corr_finalize_kernel",
-                    dominant_kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=ach / HBM_PEAK, traffic=traffic, algorithmic_bytes=ab, us_per_launch=kernels,
-                    per_kernel={"sample_norm_kernel": dict(algorithmic_bytes=ab_in, achieved_GBps=ab_in / (ms_samp * 1e-3) / 1e9,
-                                                           frac=ab_in / (ms_samp * 1e-3) / HBM_PEAK),
-                                "corr_tile_kernel": dict(algorithmic_bytes=ab_out, achieved_GBps=ab_out / (ms_main * 1e-3) / 1e9,
-                                                         frac=ab_out / (ms_main * 1e-3) / HBM_PEAK)})
+        d0 = sets[0]
+        fused = capi.corr_fwd_launches(desc, d0["feats"], d0["feats_pos"], d0["code"], d0["code_pos"]) == 1
         peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_F16_PEAK / 3.0
-        roof_mfma = dict(bound="mfma", kernel="corr_tile_kernel", achieved=fl / (ms_main * 1e-3) / 1e12,
-                         peak=peak / 1e12, unit="TFLOP/s", frac=fl / (ms_main * 1e-3) / peak, algorithmic_flops=fl,
-                         note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
+        if fused:
+            # ONE launch does the whole forward (every distinct tensor of SURVEY.md 8(d) once): its duration prices all
+            # algorithmic bytes.  ms_samp / ms_fin are the empty event intervals in front of / behind it.
+            t_fwd = ms_main * 1e-3
+            ach = ab / t_fwd
+            roof = dict(bound="hbm", kernel="corr_fused_kernel (the whole forward, one launch)", dominant_kernel="corr_fused_kernel",
+                        achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
+                        algorithmic_bytes=ab, us_per_launch={"corr_fused_kernel": ms_main * 1e3},
+                        timing="HIP events on the launch stream around single launches, input sets rotated")
+            roof_mfma = dict(bound="mfma", kernel="corr_fused_kernel", achieved=fl / t_fwd / 1e12, peak=peak / 1e12,
+                             unit="TFLOP/s", frac=fl / t_fwd / peak, algorithmic_flops=fl,
+                             note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
+        else:
+            fin_us = ms_fin * 1e3
+            kernels = {"sample_norm_kernel": ms_samp * 1e3, "corr_tile_kernel": ms_main * 1e3,
+                       "corr_finalize_kernel": ms_fin * 1e3}
+            ab_in = 4 * (B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B
+            ab_out = ab - ab_in
+            dom = "sample_norm_kernel" if ms_samp >= ms_main else "corr_tile_kernel"
+            t_fwd = (ms_samp + ms_main + ms_fin) * 1e-3
+            ach = ab / t_fwd
+            roof = dict(bound="hbm", kernel="forward = sample_norm_kernel + corr_tile_kernel + corr_finalize_kernel",
+                        dominant_kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=ach / HBM_PEAK, traffic=traffic, algorithmic_bytes=ab, us_per_launch=kernels,
+                        per_kernel={"sample_norm_kernel": dict(algorithmic_bytes=ab_in, achieved_GBps=ab_in / (ms_samp * 1e-3) / 1e9,
+                                                               frac=ab_in / (ms_samp * 1e-3) / HBM_PEAK),
+                                    "corr_tile_kernel": dict(algorithmic_bytes=ab_out, achieved_GBps=ab_out / (ms_main * 1e-3) / 1e9,
+                                                             frac=ab_out / (ms_main * 1e-3) / HBM_PEAK)})
+            roof_mfma = dict(bound="mfma", kernel="corr_tile_kernel", achieved=fl / (ms_main * 1e-3) / 1e12,
+                             peak=peak / 1e12, unit="TFLOP/s", frac=fl / (ms_main * 1e-3) / peak, algorithmic_flops=fl,
+                             note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
+        if split is not None:
+            abb = algorithmic_bytes_bwd(B, K, H, W, S, n_neg)
+            tb = split["backward_ms"] * 1e-3
+            roof_bwd = dict(bound="hbm", kernel="backward = corr_bwd_tile_kernel + corr_unsample_row_kernel (graph time minus the forward's)",
+                            achieved=abb / tb / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=abb / tb / HBM_PEAK,
+                            algorithmic_bytes=abb, us=tb * 1e6)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -367,7 +460,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
                        "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
-            "roofline": roof, "roofline_mfma": roof_mfma, "finalize_kernel_us": fin_us, "other_precision": alt,
+            "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
+            "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,
         }
     # RCCL (NCCL_DEBUG=VERSION on the bench boxes) writes its banner through C stdio, which would otherwise be flushed at

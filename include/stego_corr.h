@@ -147,6 +147,16 @@ int stego_corr_fwd(const StegoCorrDesc* desc,
                    float* saved_w, float* saved_mean, void* saved_ctx,
                    void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
+/* The RNG draws of ContrastiveCorrelationLoss.forward as the generator emits them -> what the loss consumes, one launch:
+ *   coords1/2 = u1/2 * 2 - 1                          (torch.rand(...) * 2 - 1, modules.py:366-367; bit-identical)
+ *   perms[n]  = super_perm fix-up of raw_perms[n]     (perm[perm == arange] += 1; perm % B, modules.py:307-311, :383)
+ * u1, u2: n_coord floats each; raw_perms: n_neg (<= 16) HOST-array of device pointers to int64 [B]; perms: int64 [n_neg, B]. */
+int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const int64_t* const* raw_perms, int32_t n_neg,
+                       int32_t B, float* coords1, float* coords2, int64_t* perms, stego_stream_t stream);
+
+/* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize; < 0: -error code. */
+int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
+                            const StegoMap* code, const StegoMap* code_pos);
 int stego_corr_workspace_prepare(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes, stego_stream_t stream);
 int stego_corr_fwd_prepared(const StegoCorrDesc* desc,
                    const StegoMap* feats, const StegoMap* feats_pos,

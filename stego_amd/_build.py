@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstego_corr.so")
-SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "vit_forward.hip", "host_util.hip", "c_api.hip"]
+SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "vit_forward.hip", "host_util.hip", "draws.hip", "c_api.hip"]
 HEADERS = ["corr_common.h", "corr_tile.h", "host_util.h", os.path.join("..", "..", "include", "stego_corr.h"), os.path.join("..", "..", "include", "stego_vit.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]

@@ -60,6 +60,8 @@ SIGNATURES = {
     "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_fwd_prepared": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
+    "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
+    "stego_finish_draws": (c_int32, [_P, _P, ctypes.c_int64, POINTER(ctypes.c_void_p), c_int32, c_int32, _P, _P, _P, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
                                + [c_int32, POINTER(c_float)]),
     "stego_corr_bwd_workspace_bytes": (c_size_t, [_D]),
@@ -215,6 +217,27 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
                                   _ptr(saved_w), _ptr(saved_mean), _ptr(saved_ctx), _ptr(ws), ws.numel(), _stream()))
     saved = (saved_w, saved_mean, saved_ctx) if need_grad else None
     return loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved
+
+
+def finish_draws(u1, u2, raw_perms, B):
+    """(coords1, coords2, perms) from torch.rand x2 and the n_neg torch.randperm results, one launch (stego_finish_draws)."""
+    lib = load()
+    dev = u1.device
+    n_neg = len(raw_perms)
+    c1 = torch.empty_like(u1)
+    c2 = torch.empty_like(u2)
+    perms = torch.empty(n_neg, B, dtype=torch.int64, device=dev)
+    arr = (ctypes.c_void_p * max(n_neg, 1))(*[r.data_ptr() for r in raw_perms])
+    with torch.cuda.device(dev):
+        _check(lib.stego_finish_draws(_ptr(u1), _ptr(u2), u1.numel(), arr, n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+    return c1, c2, perms
+
+
+def corr_fwd_launches(desc, feats, feats_pos, code, code_pos):
+    """Kernel launches stego_corr_fwd_prepared needs for these maps: 1 = the fused forward, 3 = sample / tile / finalize."""
+    lib = load()
+    mf, mfp, mc, mcp = _map(feats), _map(feats_pos), _map(code), _map(code_pos)
+    return int(lib.stego_corr_fwd_launches(byref(desc), byref(mf), byref(mfp), byref(mc), byref(mcp)))
 
 
 def corr_fwd_profile(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad, iters):

@@ -14,6 +14,8 @@ hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 bool fused_supported(const FusedParams& prm, int precision);
 hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, bool prepared, hipStream_t stream, hipEvent_t* ev);
 hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStream_t stream);
+hipError_t launch_finish_draws(const float* u1, const float* u2, long long n_coord, const long long* const* raw, int n_neg,
+                               int B, float* c1, float* c2, long long* perms, hipStream_t stream);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
@@ -320,6 +322,36 @@ int stego_corr_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap
                       workspace_bytes, &pl);
     if (rc) return rc;
     return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr));
+}
+
+int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const int64_t* const* raw_perms, int32_t n_neg,
+                       int32_t B, float* coords1, float* coords2, int64_t* perms, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_coord < 0 || n_neg < 0 || n_neg > 16 || B < 1) return STEGO_ERR_SHAPE;
+    if (n_coord > 0 && (!u1 || !u2 || !coords1 || !coords2)) return STEGO_ERR_NULL;
+    if (n_neg > 0 && (!raw_perms || !perms)) return STEGO_ERR_NULL;
+    for (int i = 0; i < n_neg; ++i)
+        if (!raw_perms[i]) return STEGO_ERR_NULL;
+    return hip_rc(launch_finish_draws(u1, u2, n_coord, reinterpret_cast<const long long* const*>(raw_perms), n_neg, B, coords1,
+                                      coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+}
+
+int stego_corr_fwd_launches(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code,
+                            const StegoMap* code_pos)
+{
+    int rc = check_desc(d, false);
+    if (rc) return -rc;
+    if (!feats || !feats_pos || !code || !code_pos) return -STEGO_ERR_NULL;
+    const Geometry g = geometry(d, false);
+    FusedParams fp{};
+    if ((rc = to_mapv(feats, d->C, d->H, d->W, &fp.feats)) || (rc = to_mapv(feats_pos, d->C, d->H, d->W, &fp.feats_pos)) ||
+        (rc = to_mapv(code, d->K, d->H, d->W, &fp.code)) || (rc = to_mapv(code_pos, d->K, d->H, d->W, &fp.code_pos)))
+        return -rc;
+    fp.B = d->B; fp.C = d->C; fp.K = d->K; fp.H = d->H; fp.W = d->W; fp.S = d->S; fp.P = d->S * d->S;
+    const bool fused = knob(KNOB_FWD_VARIANT) != 1 && g.fs_bytes < ((size_t)1 << 31) && g.cs_bytes < ((size_t)1 << 31) &&
+                       fused_supported(fp, d->precision);
+    return fused ? 1 : 3;
 }
 
 int stego_corr_workspace_prepare(const StegoCorrDesc* d, void* workspace, size_t workspace_bytes, stego_stream_t stream)

@@ -108,6 +108,7 @@ class _CorrLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
         need_grad = bool(code.requires_grad or code_pos.requires_grad)
+        ctx.set_materialize_grads(False)       # an output nobody differentiated costs no zero-fill and no loads in the backward
         (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved) = _backend.corr_fwd(
             desc, as_channels_last(feats.detach()), as_channels_last(feats_pos.detach()),
             as_channels_last(code.detach()), as_channels_last(code_pos.detach()), coords1, coords2, perms, need_grad)
@@ -136,6 +137,7 @@ class _HelperFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f1, f2, c1, c2, desc):
         need_grad = bool(c1.requires_grad or c2.requires_grad)
+        ctx.set_materialize_grads(False)
         loss, cd, saved = _backend.helper_fwd(desc, f1.detach(), f2.detach(), c1.detach(), c2.detach(), need_grad)
         ctx.desc = desc
         if need_grad:
@@ -209,9 +211,24 @@ class ContrastiveCorrelationLoss(nn.Module):
                 orig_salience: torch.Tensor, orig_salience_pos: torch.Tensor,
                 orig_code: torch.Tensor, orig_code_pos: torch.Tensor,
                 ):
-        coords1, coords2 = self.draw_coords(orig_feats, orig_salience, orig_salience_pos)
         B = orig_feats.shape[0]
-        # :382-383 - one randperm per negative from the device generator (the reference's draws), one batched fix-up
-        raw = [torch.randperm(B, device=orig_feats.device, dtype=torch.long) for _ in range(self.cfg.neg_samples)]
-        perms = _unfix(torch.stack(raw)) if raw else None
+        dev = orig_feats.device
+        cfg = self.cfg
+        if dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "finish_draws"):
+            # The reference's draws in the reference's order on the device generator (:366, :367, :383): torch.rand x2, then
+            # one torch.randperm per negative; "* 2 - 1" and the super_perm fix-up run in ONE kernel (stego_finish_draws)
+            # instead of nine.  (Forking the ~30 tiny draw kernels onto side streams while a HIP graph is captured was
+            # measured SLOWER: 352 vs 268 us per replay - cross-branch edges cost more than the kernels they overlap.)
+            shape = [B, cfg.feature_samples, cfg.feature_samples, 2]
+            n = cfg.neg_samples
+            out = [torch.rand(shape, device=dev), torch.rand(shape, device=dev)]
+            out += [torch.randperm(B, device=dev, dtype=torch.long) for _ in range(n)]
+            coords1, coords2, perms = _backend.finish_draws(out[0], out[1], out[2:], B)
+            if n == 0:
+                perms = None
+        else:
+            coords1, coords2 = self.draw_coords(orig_feats, orig_salience, orig_salience_pos)
+            # :382-383 - one randperm per negative from the device generator (the reference's draws), one batched fix-up
+            raw = [torch.randperm(B, device=dev, dtype=torch.long) for _ in range(cfg.neg_samples)]
+            perms = _unfix(torch.stack(raw)) if raw else None
         return self.forward_explicit(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
