@@ -230,7 +230,11 @@ def main():
                          "v_mfma_f32 (runs at the VALU rate on gfx950)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other precision mode")
     ap.add_argument("--sets", type=int, default=4, help="input sets rotated (4 x 91 MB > 256 MB Infinity Cache)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="eager launches through the C ABI, HIP-graph replays, or (auto) whichever a short trial of both finds faster")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="steps captured per HIP graph (0 = one graph holding one step of every rotated input set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the per-step all-reduce even with one rank (exercises the N > 1 path)")
@@ -271,8 +275,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(precision, steps, warmup, fwd_only=args.fwd_only, collective=True):
+    def timed_run(precision, steps, warmup, fwd_only=args.fwd_only, collective=True, use_graph=True):
         """W untimed + K timed steps of the whole job in one precision mode; returns (seconds, launch mode, desc)."""
+        collective_on = collective
         prec = capi.PREC_F32 if precision == "f32" else capi.PREC_F16X3
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
                               prec)
@@ -297,15 +302,28 @@ def main():
         torch.cuda.synchronize()
         graphs = None
         launch = "eager"
-        if not args.no_graph:
+        if use_graph:
             try:
+                # One replay runs `spg` consecutive steps (rotating through the input sets): a hipGraphLaunch costs ~18 us on
+                # top of its kernels whatever it holds (measured: one 58 us kernel per graph = 76 us per replay), which a
+                # real training step amortises over its backbone forward; K steps are always exactly K steps of work.
+                spg = args.steps_per_graph or args.sets
                 graphs = []
-                for i in range(args.sets):
+                for g0 in range(0, args.sets * spg, spg):
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr, capture_error_mode="thread_local"):     # RCCL's watchdog thread must not break a capture
-                        step_compute(i)
+                        for j in range(spg):
+                            step_compute((g0 + j) % args.sets)
                     graphs.append(gr)
-                launch = "hipgraph"
+                    if spg % args.sets == 0:
+                        break                       # every replay covers whole rotations: one graph is enough
+                single = []
+                for i in range(args.sets):          # single-step graphs for the remainder of K
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                        step_compute(i)
+                    single.append(gr)
+                launch = "hipgraph (%d steps per replay)" % spg
             except Exception as e:      # noqa: BLE001 - fall back to eager launches, say so in the output
                 graphs = None
                 launch = "eager (graph capture failed: %s)" % type(e).__name__
@@ -316,28 +334,45 @@ def main():
         def step(k):
             i = k % args.sets
             if graphs is not None:
-                graphs[i].replay()
+                single[i].replay()
             else:
                 step_compute(i)
-            if dist is not None and collective:
+            do_collective()
+
+        def do_collective():
+            if dist is not None and collective_on:
                 # gradients of the segmentation head only (backbone frozen): one flat bucket per step.  async_op: RCCL's
                 # stream first waits for this step's kernels, then the all-reduce runs while the next step computes - in
                 # training it overlaps the next step's backbone forward the same way; every all-reduce is complete
                 # before the clock stops (drain()).
                 pending[0] = dist.all_reduce(grad_buf, async_op=True)
 
+        def run(n):
+            """exactly n steps: whole multi-step replays first, single-step graphs for the rest"""
+            k = 0
+            if graphs is not None:
+                spg = args.steps_per_graph or args.sets
+                r = 0
+                while n - k >= spg:
+                    graphs[r % len(graphs)].replay()
+                    r += 1
+                    for _ in range(spg):
+                        do_collective()
+                    k += spg
+            while k < n:
+                step(k)
+                k += 1
+
         def drain():
             if pending[0] is not None:
                 pending[0].wait()
                 pending[0] = None
 
-        for k in range(warmup):
-            step(k)
+        run(warmup)
         drain()
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
-            step(k)
+        run(steps)
         drain()
         barrier()
         dt = time.perf_counter() - t0
@@ -347,12 +382,24 @@ def main():
             dt = float(t.item())
         return dt, launch, desc
 
-    dt, launch, desc = timed_run(args.precision, args.steps, args.warmup)
+    # ---- launch mode: the C ABI is asynchronous either way.  With three kernels per step, eager launches keep the queue full
+    # (measured 121.7 us/step); a HIP graph replay adds ~5 us per replay on this stack (129.3 with one step per replay, 124.0 with
+    # eight).  auto = a short trial of both, the faster one runs the K timed steps (all ranks agree through a MAX-reduce).
+    mode = "eager" if args.no_graph else args.launch
+    trial = None
+    if mode == "auto":
+        trial = {}
+        for m in ("eager", "graph"):
+            dt_m, _, _ = timed_run(args.precision, 48, 16, use_graph=(m == "graph"))
+            trial[m] = dt_m / 48 * 1e3
+        mode = "graph" if trial["graph"] < trial["eager"] else "eager"
+    dt, launch, desc = timed_run(args.precision, args.steps, args.warmup, use_graph=(mode == "graph"))
+    use_graph = mode == "graph"
     alt = None
     if not args.no_alt:                     # the other arithmetic mode, shorter, for the record (all ranks take part)
         other = "f32" if args.precision == "f16x3" else "f16x3"
         steps_alt = max(20, args.steps // 4)
-        dt_alt, _, _ = timed_run(other, steps_alt, max(4, args.warmup // 4))
+        dt_alt, _, _ = timed_run(other, steps_alt, max(4, args.warmup // 4), use_graph=use_graph)
         alt = {"precision": other, "value": world * B * steps_alt / dt_alt, "unit": "image-pairs/s",
                "ms_per_step": dt_alt / steps_alt * 1e3, "steps": steps_alt}
 
@@ -360,7 +407,7 @@ def main():
     split = None
     if not args.fwd_only and not args.no_alt:
         steps_f = max(20, args.steps // 4)
-        dt_f, _, _ = timed_run(args.precision, steps_f, max(4, args.warmup // 4), fwd_only=True, collective=False)
+        dt_f, _, _ = timed_run(args.precision, steps_f, max(4, args.warmup // 4), fwd_only=True, collective=False, use_graph=use_graph)
         split = {"forward_ms": dt_f / steps_f * 1e3, "backward_ms": dt / args.steps * 1e3 - dt_f / steps_f * 1e3, "steps": steps_f}
 
     # ---- the product path: ContrastiveCorrelationLoss(cfg)(...) + .backward() exactly as a training step calls it
@@ -458,6 +505,7 @@ def main():
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,
                                                              "forward only" if args.fwd_only else "forward+backward"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
+                       "launch_trial_ms_per_step": trial,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
                        "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
