@@ -239,6 +239,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the per-step all-reduce even with one rank (exercises the N > 1 path)")
     ap.add_argument("--fwd-only", action="store_true", help="time the forward alone (reported in config)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="CI only: run the multi-rank protocol of this file (rendezvous, per-step gradient all-reduce through "
+                         "FlatGradReducer, barriers, MAX-over-ranks timing, rank-0 JSON) on CPU with gloo and NO kernels; "
+                         "the record says so and carries no throughput claim")
     ap.add_argument("--layout", default="cl", choices=["cl", "nchw"],
                     help="cl = channels-last strided views as DinoFeaturizer emits (default); nchw = contiguous NCHW")
     args = ap.parse_args()
@@ -246,44 +250,72 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run_cpu
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or args.force_collective:
         import torch.distributed as dist
         if args.force_collective and "RANK" not in os.environ:      # single-process self-test of the N > 1 code path
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-        dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
-    from stego_amd import capi
     cfg = Cfg()
     cfg.corr_precision = args.precision
     C, H, W, K = WORKLOADS[args.workload]
     B, S, n_neg = args.batch, cfg.feature_samples, cfg.neg_samples
-    sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
-    # upstream gradients exactly as train_segmentation.py:169-181 produces them
-    g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
-    g_inter = torch.tensor(cfg.pos_inter_weight, device=dev)
-    g_neg = torch.full((1,), cfg.neg_inter_weight / (n_neg * B * S ** 4), device=dev).expand(n_neg * B, S, S, S, S)
-    grad_buf = torch.zeros(head_grad_numel(C, K), device=dev)     # flat head-gradient bucket (DDP)
-    from stego_amd.modules import as_channels_last      # the host-side layout policy of the op (no-op for cl views)
+    # the DDP exchange of the training loop: the trainer's own FlatGradReducer over a bucket of the head's size
+    # (stego_amd/ddp.py; LitUnsupervisedSegmenter.manual_backward calls exactly this)
+    from stego_amd.ddp import FlatGradReducer
+    head = torch.nn.Parameter(torch.zeros(head_grad_numel(C, K), device=dev))
+    reducer = FlatGradReducer([head])
+    grad_buf = reducer.flat
+    if dry:
+        capi = None
+        sets = [None] * args.sets
+        args.no_alt = True
+        args.no_cpu_baseline = True
+        args.launch = "eager"
+    else:
+        from stego_amd import capi
+        sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
+        # upstream gradients exactly as train_segmentation.py:169-181 produces them
+        g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
+        g_inter = torch.tensor(cfg.pos_inter_weight, device=dev)
+        g_neg = torch.full((1,), cfg.neg_inter_weight / (n_neg * B * S ** 4), device=dev).expand(n_neg * B, S, S, S, S)
+        from stego_amd.modules import as_channels_last      # the host-side layout policy of the op (no-op for cl views)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     def timed_run(precision, steps, warmup, fwd_only=args.fwd_only, collective=True, use_graph=True):
         """W untimed + K timed steps of the whole job in one precision mode; returns (seconds, launch mode, desc)."""
         collective_on = collective
-        prec = capi.PREC_F32 if precision == "f32" else capi.PREC_F16X3
-        desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
-                              prec)
         keep = [None] * args.sets
+        if dry:
+            desc = None
+            counter = [0]
 
-        def step_compute(i):
+            def step_compute(i):                    # no kernels: each step leaves "its gradient" rank + 1 in the bucket
+                counter[0] += 1
+                grad_buf.fill_(float(rank + 1))
+        else:
+            prec = capi.PREC_F32 if precision == "f32" else capi.PREC_F16X3
+            desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
+                                  prec)
+
+        def step_compute_gpu(i):
             d = sets[i]
             need_grad = not fwd_only
             out = capi.corr_fwd(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
@@ -297,12 +329,15 @@ def main():
             else:
                 keep[i] = (out,)
 
+        if not dry:
+            step_compute = step_compute_gpu
         for i in range(args.sets):          # eager warm-up (also sets kernel attributes before any capture)
             step_compute(i)
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         graphs = None
         launch = "eager"
-        if use_graph:
+        if use_graph and not dry:
             try:
                 # One replay runs `spg` consecutive steps (rotating through the input sets): a hipGraphLaunch costs ~18 us on
                 # top of its kernels whatever it holds (measured: one 58 us kernel per graph = 76 us per replay), which a
@@ -345,7 +380,7 @@ def main():
                 # stream first waits for this step's kernels, then the all-reduce runs while the next step computes - in
                 # training it overlaps the next step's backbone forward the same way; every all-reduce is complete
                 # before the clock stops (drain()).
-                pending[0] = dist.all_reduce(grad_buf, async_op=True)
+                pending[0] = reducer.allreduce_mean(async_op=True)
 
         def run(n):
             """exactly n steps: whole multi-step replays first, single-step graphs for the rest"""
@@ -380,6 +415,8 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        if dry:
+            launch = "dry run on CPU: no kernels (%d no-op steps per rank)" % counter[0]
         return dt, launch, desc
 
     # ---- launch mode: the C ABI is asynchronous either way.  With three kernels per step, eager launches keep the queue full
@@ -405,7 +442,7 @@ def main():
 
     # ---- the forward alone (same graphs without the backward): the backward's share is the difference
     split = None
-    if not args.fwd_only and not args.no_alt:
+    if not args.fwd_only and not args.no_alt and not dry:
         steps_f = max(20, args.steps // 4)
         dt_f, _, _ = timed_run(args.precision, steps_f, max(4, args.warmup // 4), fwd_only=True, collective=False, use_graph=use_graph)
         split = {"forward_ms": dt_f / steps_f * 1e3, "backward_ms": dt / args.steps * 1e3 - dt_f / steps_f * 1e3, "steps": steps_f}
@@ -413,13 +450,13 @@ def main():
     # ---- the product path: ContrastiveCorrelationLoss(cfg)(...) + .backward() exactly as a training step calls it
     # (train_segmentation.py:163-181): RNG draws, autograd.Function, weighted sum, backward - eager and graph-replayed
     product = None
-    if rank == 0 and not args.no_alt:
+    if rank == 0 and not args.no_alt and not dry:
         product = product_path(sets, cfg, args, dt / args.steps)
 
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
     roof = roof_mfma = roof_bwd = None
     fin_us = None
-    if rank == 0:
+    if rank == 0 and not dry:
         ms_samp = ms_main = ms_fin = 0.0
         rounds = 5
         for r in range(rounds + 1):
@@ -492,6 +529,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(B, C, H, W, K, S, n_neg, cfg)
 
+    check = None
+    if dry:
+        # after the last step's averaged all-reduce every rank holds mean(rank + 1) = (world + 1) / 2
+        check = {"grad_mean_after_allreduce": float(grad_buf[0]), "expected": (world + 1) / 2.0,
+                 "bucket_numel": int(grad_buf.numel())}
     if rank == 0:
         value = world * B * args.steps / dt
         rec = {
@@ -500,7 +542,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3 (f32 inputs/outputs/accumulate; feature products as fp16 hi+lo splits, "
                                                                    "22-bit, on the matrix cores; code correlation and backward exact f32)",
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "none (dry run of the multi-rank protocol on CPU: no kernels ran, value is not a measurement)",
             "config": {"workload": "%s: B=%d/GPU, C=%d, %dx%d map, K=%d, S=%d, %d negatives, self+KNN+random "
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,
                                                              "forward only" if args.fwd_only else "forward+backward"),
@@ -512,6 +554,10 @@ def main():
             "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,
         }
+        if dry:
+            rec["dry_run"] = True
+            rec["value"] = None
+            rec["collective_check"] = check
     # RCCL (NCCL_DEBUG=VERSION on the bench boxes) writes its banner through C stdio, which would otherwise be flushed at
     # exit, after the result: every rank pushes it out before the last barrier, rank 0 prints the record after it, so
     # the JSON line is the last line of the job's stdout

@@ -82,13 +82,25 @@ class FlatGradReducer:
                 p.grad = view
             off += n
 
-    def allreduce_mean(self):
-        """One all-reduce (RCCL over xGMI with backend 'nccl'); no-op for a single process."""
+    def allreduce_mean(self, async_op=False):
+        """One all-reduce of the whole bucket, averaged over the ranks; no-op (returns None) for a single process.
+
+        RCCL (backend 'nccl'): ``ReduceOp.AVG`` - the 1/world is folded into the collective, no extra kernel - launched
+        asynchronously on RCCL's stream.  With ``async_op=True`` the work handle is returned: ``handle.wait()`` is a
+        stream dependency (the host does not block), so the caller can enqueue whatever does not need the gradients
+        (logging reductions, the next batch's copies) before it waits.  gloo (CPU tests) has no AVG: SUM + divide,
+        synchronous."""
         if not is_distributed():
-            return
-        world = dist.get_world_size(self.group)
+            return None
+        if dist.get_backend(self.group) == "nccl":
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            if async_op:
+                return work
+            work.wait()
+            return None
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(world)
+        self.flat.div_(dist.get_world_size(self.group))
+        return None
 
     def broadcast_params(self, src=0):
         """Startup synchronisation of the trainable parameters (DDP does the same at construction)."""

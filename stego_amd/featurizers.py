@@ -41,6 +41,11 @@ class TokenCache:
         self.complete = False
         self.misses = 0
 
+    def clear(self):
+        """Forget everything (the backbone's weights changed)."""
+        self.filled.zero_()
+        self.complete = False
+
     def fetch(self, index, img, compute):
         """tokens fp32 [B, ntok, D] for dataset indices `index` (long [B]); `compute(img_subset)` runs the backbone for
         the rows not cached yet.  The miss test is a host sync, paid only until the table is full."""
@@ -105,7 +110,12 @@ class DinoFeaturizer(nn.Module):
         self._native = None           # vit_native.NativeViT, built on first use on a HIP device
         self.backbone_path = None     # "native" | "torch": which path the last forward took
         # new weights (also when loaded through a parent module's load_state_dict) -> re-pack the backbone on next use
-        self.register_load_state_dict_post_hook(lambda module, _incompatible: module._native and module._native.invalidate())
+        def _new_weights(module, _incompatible):
+            if module._native:
+                module._native.invalidate()
+            if module.token_cache is not None:
+                module.token_cache.clear()          # tokens of the OLD backbone
+        self.register_load_state_dict_post_hook(_new_weights)
 
         weights = getattr(cfg, "pretrained_weights", None)
         if weights is not None:

@@ -147,10 +147,17 @@ class LitUnsupervisedSegmenter(nn.Module):
         return self._reducer
 
     def manual_backward(self, loss):
+        """loss.backward() + the DDP gradient exchange (Lightning's manual_backward under accelerator='ddp',
+        train_segmentation.py:227): ONE asynchronous averaged all-reduce of the flat bucket; wait_gradients() joins it."""
         loss.backward()
         if self._reducer is not None:
             self._reducer.reattach()
-            self._reducer.allreduce_mean()
+            self._grad_work = self._reducer.allreduce_mean(async_op=True)
+
+    def wait_gradients(self):
+        work, self._grad_work = getattr(self, "_grad_work", None), None
+        if work is not None:
+            work.wait()                 # stream dependency on RCCL's stream; the host keeps enqueueing
 
     def training_step(self, batch, batch_idx):
         net_optim, linear_probe_optim, cluster_probe_optim = self.optimizers()
@@ -227,6 +234,7 @@ class LitUnsupervisedSegmenter(nn.Module):
         self.log('loss/total', loss, **log_args)
 
         self.manual_backward(loss)
+        self.wait_gradients()
         net_optim.step()
         cluster_probe_optim.step()
         linear_probe_optim.step()
@@ -276,12 +284,17 @@ class SyntheticContrastiveDataset(torch.utils.data.Dataset):
     def __len__(self):
         return self.n
 
+    n_cache_items = property(lambda self: 2 * self.n)          # anchors [0, n) + their positives [n, 2n)
+    deterministic_items = True                                 # the same index always yields the same pixels
+
     def __getitem__(self, ind):
         g = torch.Generator().manual_seed(self.seed * 100003 + ind)
         img = torch.randn(3, self.res, self.res, generator=g)
         img_pos = img + 0.3 * torch.randn(3, self.res, self.res, generator=g)
         label = torch.randint(0, self.n_classes, (self.res, self.res), generator=g)
-        return dict(ind=ind, img=img, label=label, img_pos=img_pos, ind_pos=ind, label_pos=label,
+        # the positive is a different image: it gets its own index (n + ind), as a real KNN positive has (data.py:547-549),
+        # so that anything keyed by index (TokenCache) never confuses it with the anchor
+        return dict(ind=ind, img=img, label=label, img_pos=img_pos, ind_pos=self.n + ind, label_pos=label,
                     mask=torch.ones(1, self.res, self.res), mask_pos=torch.ones(1, self.res, self.res))
 
 
@@ -299,7 +312,19 @@ class Trainer:
         if self.world > 1:
             model.setup_distributed()
         if getattr(model.cfg, "cache_backbone_tokens", False) and hasattr(model.net, "enable_token_cache"):
-            model.net.enable_token_cache(len(loader.dataset), (model.cfg.res, model.cfg.res), self.device)
+            # The cache is keyed by dataset index: valid only if an index always yields the same pixels (fixed crops; the
+            # reference's random-crop loaders, data.py loader_crop_type "random", re-crop every epoch) and if ind_pos
+            # addresses the positive's own pixels.
+            ds = loader.dataset
+            crop = getattr(model.cfg, "loader_crop_type", "center")
+            if not getattr(ds, "deterministic_items", crop != "random"):
+                raise ValueError("cfg.cache_backbone_tokens needs a dataset whose items are fixed per index "
+                                 "(loader_crop_type=%r re-crops every epoch)" % crop)
+            n_items = int(getattr(ds, "n_cache_items", len(ds)))
+            model.net.enable_token_cache(n_items, (model.cfg.res, model.cfg.res), self.device)
+        if len(loader) == 0:
+            raise ValueError("empty loader (dataset of %d items, batch size %s, drop_last): nothing to train on"
+                             % (len(loader.dataset), getattr(loader, "batch_size", "?")))
         step = 0
         history = []
         while step < self.max_steps:

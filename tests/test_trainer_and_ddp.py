@@ -254,3 +254,70 @@ def test_token_cache_serves_the_frozen_backbone_from_memory():
     assert calls == [8, 5, 3]
     assert torch.allclose(f3, f_direct, rtol=2e-3, atol=2e-3) and torch.allclose(f1, f_direct[:5], rtol=2e-3, atol=2e-3)
     assert f3.stride(1) == 1                                # still the channels-last view the loss kernels want
+
+
+def test_token_cache_positive_has_its_own_rows_and_is_dropped_with_the_weights():
+    """Trainer-level: with cfg.cache_backbone_tokens the positive's cached features equal its uncached features (it must not
+    be served the anchor's row), random-crop loaders are refused, and loading new weights empties the cache."""
+    from stego_amd.train_segmentation import SyntheticContrastiveDataset, Trainer
+    cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "batch_size=4", "dim=12",
+                                 "feature_samples=3", "neg_samples=1", "cache_backbone_tokens=True", "max_steps=3", "dropout=False"])
+    torch.manual_seed(3)
+    m = LitUnsupervisedSegmenter(5, cfg).cpu()
+    ds = SyntheticContrastiveDataset(8, 32, 5, seed=1)
+    item = ds[3]
+    assert item["ind_pos"] == 8 + 3 and ds.n_cache_items == 16
+    loader = torch.utils.data.DataLoader(ds, 4, shuffle=False, drop_last=True)
+    tr = Trainer(3, device=torch.device("cpu"))
+    M._backend = oracle_backend                 # the loss itself has no CPU path: the oracle-backed double stands in
+    try:
+        tr.fit(m, loader)
+    finally:
+        from stego_amd import capi
+        M._backend = capi
+    cache = m.net.token_cache
+    assert cache is not None and cache.tokens.shape[0] == 16
+    m.net.eval()
+    batch = next(iter(loader))
+    with torch.no_grad():
+        cached_pos, _ = m.net(batch["img_pos"], cache_index=batch["ind_pos"])
+        direct_pos, _ = m.net(batch["img_pos"])
+        direct_anchor, _ = m.net(batch["img"])
+    assert torch.allclose(cached_pos, direct_pos, rtol=2e-3, atol=2e-3)
+    assert not torch.allclose(cached_pos, direct_anchor, rtol=2e-3, atol=2e-3)
+    # new weights -> stale tokens are dropped
+    assert bool(cache.filled.any())
+    m.net.load_state_dict(m.net.state_dict())
+    assert not bool(cache.filled.any()) and not cache.complete
+
+    class Recrop(SyntheticContrastiveDataset):
+        deterministic_items = False
+    with pytest.raises(ValueError, match="fixed per index"):
+        Trainer(1, device=torch.device("cpu")).fit(LitUnsupervisedSegmenter(5, cfg).cpu(),
+                                                    torch.utils.data.DataLoader(Recrop(8, 32, 5), 4, drop_last=True))
+    with pytest.raises(ValueError, match="empty loader"):
+        Trainer(1, device=torch.device("cpu")).fit(LitUnsupervisedSegmenter(5, cfg).cpu(),
+                                                    torch.utils.data.DataLoader(SyntheticContrastiveDataset(2, 32, 5), 4, drop_last=True))
+
+
+def test_bench_multi_rank_protocol_two_processes_gloo():
+    """bench.py's own N > 1 path under torch.distributed.run (the way the driver launches it): rendezvous on 127.0.0.1, the
+    per-step gradient exchange through the trainer's FlatGradReducer, barriers, MAX-over-ranks timing, ONE JSON line from
+    rank 0 as the last line of stdout.  --dry-run-cpu replaces the kernels by no-ops (no GPU in CI); the record says so."""
+    import json, subprocess, sys, socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dry-run-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = [ln for ln in out.stdout.strip().splitlines() if ln.strip()][-1]
+    rec = json.loads(last)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["warmup"] == 2 and rec["dry_run"] is True and rec["value"] is None
+    assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 64 and rec["config"]["parallelism"] == "dp2"
+    chk = rec["collective_check"]
+    assert chk["grad_mean_after_allreduce"] == chk["expected"] == 1.5
+    assert chk["bucket_numel"] == 384 * 70 + 70 + 384 * 384 + 384 + 384 * 70 + 70 + 70 * 27 + 27 + 27 * 70
+    assert rec["config"]["collective"].startswith("all_reduce(")
