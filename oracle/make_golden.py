@@ -217,6 +217,72 @@ def vit_case():
     print("vit_tiny2", tuple(feat[0].shape), "max softmax prob: mean %.3f" % attn[0].max(-1)[0].mean().item())
 
 
+LOSS_CURVE = dict(B=4, C=384, H=10, W=10, K=16, S=5, n_neg=2, steps=20, lr=5e-4, seed_data=71, seed_head=72, seed_step0=7300,
+                  w_intra=0.67, w_inter=0.25, w_neg=0.63)
+
+
+def loss_curve_inputs(p=LOSS_CURVE):
+    """Fixed 'backbone features' of the loop (frozen backbone: train_segmentation.py:160-170 only ever sees its output) and the
+    segmentation head of DinoFeaturizer (modules.py:33-47 make_clusterer / make_nonlinear_clusterer, applied at :108-116 with
+    dropout off), both regenerated from seeds on the CPU generator - shared by the generator below and by the GPU replay test."""
+    g = torch.Generator().manual_seed(p["seed_data"])
+    B, C, H, W, K = p["B"], p["C"], p["H"], p["W"], p["K"]
+    proto = torch.randn(6, C, generator=g)
+    z = torch.randn(B, H // 2 + 1, W // 2 + 1, 6, generator=g).repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :H, :W]
+    feats = (z @ proto + 0.3 * torch.randn(B, H, W, C, generator=g)).permute(0, 3, 1, 2).contiguous()
+    feats_pos = (feats + 0.5 * torch.randn(B, C, H, W, generator=g)).contiguous()
+    torch.manual_seed(p["seed_head"])
+    cluster1 = torch.nn.Sequential(torch.nn.Conv2d(C, K, (1, 1)))                                       # modules.py:33-36
+    cluster2 = torch.nn.Sequential(torch.nn.Conv2d(C, C, (1, 1)), torch.nn.ReLU(), torch.nn.Conv2d(C, K, (1, 1)))   # :38-47
+    return feats, feats_pos, cluster1, cluster2
+
+
+def loss_curve_case(M):
+    """train_segmentation.py:112-245 in miniature: the UNMODIFIED reference ContrastiveCorrelationLoss.forward (modules.py:349-398,
+    its own RNG draws) inside a 20-step Adam loop (lr 5e-4, :391) on the segmentation head, loss composed as :176-181.
+    Every step is seeded (torch.manual_seed(seed_step0 + t)) right before the loss call; the draws the reference then makes
+    (coords1 :366, coords2 :367, super_perm x n_neg :383) are reproduced from the same seed and stored, so that a replay
+    can feed them through forward_explicit.  Stored: the draws, the three loss terms + total per step, the final head."""
+    p = LOSS_CURVE
+    feats, feats_pos, cluster1, cluster2 = loss_curve_inputs(p)
+    cfg = Cfg(feature_samples=p["S"], neg_samples=p["n_neg"])
+    loss_fn = M.ContrastiveCorrelationLoss(cfg)
+    opt = torch.optim.Adam(list(cluster1.parameters()) + list(cluster2.parameters()), lr=p["lr"])
+    shape = [p["B"], p["S"], p["S"], 2]
+    curve, c1s, c2s, perms = [], [], [], []
+    for t in range(p["steps"]):
+        torch.manual_seed(p["seed_step0"] + t)
+        c1 = torch.rand(shape) * 2 - 1
+        c2 = torch.rand(shape) * 2 - 1
+        pr = torch.stack([M.super_perm(p["B"], feats.device) for _ in range(p["n_neg"])])
+        c1s.append(c1); c2s.append(c2); perms.append(pr)
+        opt.zero_grad()
+        code = cluster1(feats) + cluster2(feats)                       # modules.py:108-116 (dropout off)
+        code_pos = cluster1(feats_pos) + cluster2(feats_pos)
+        torch.manual_seed(p["seed_step0"] + t)                         # the reference draws the same values inside forward()
+        (pil, _, pel, _, nl, _) = loss_fn(feats, feats_pos, None, None, code, code_pos)
+        pil, pel, nl = pil.mean(), pel.mean(), nl.mean()
+        loss = p["w_inter"] * pel + p["w_intra"] * pil + p["w_neg"] * nl
+        loss.backward()
+        opt.step()
+        curve.append([float(pil), float(pel), float(nl), float(loss)])
+    # the draws reproduced outside must be the ones forward() used: recompose step 0 from the reference's own helper()
+    torch.manual_seed(p["seed_head"])
+    _, _, k1, k2 = loss_curve_inputs(p)
+    with torch.no_grad():
+        code0 = k1(feats) + k2(feats); code0p = k1(feats_pos) + k2(feats_pos)
+        chk = ref_forward_explicit(M, cfg, feats, feats_pos, code0, code0p, c1s[0], c2s[0], list(perms[0]))
+    assert abs(float(chk[0]) - curve[0][0]) < 1e-6 and abs(float(chk[4].mean()) - curve[0][2]) < 1e-6, "draw order mismatch"
+    np.savez_compressed(os.path.join(OUT, "loss_curve.npz"), curve=np.array(curve, dtype=np.float64),
+                        coords1=torch.stack(c1s).numpy(), coords2=torch.stack(c2s).numpy(), perms=torch.stack(perms).numpy(),
+                        final_cluster1_w=cluster1[0].weight.detach().numpy().reshape(p["K"], p["C"]),
+                        final_cluster1_b=cluster1[0].bias.detach().numpy(),
+                        final_cluster2_out_w=cluster2[2].weight.detach().numpy().reshape(p["K"], p["C"]),
+                        final_cluster2_hidden_w_sum=np.array([float(cluster2[0].weight.detach().double().sum()),
+                                                              float(cluster2[0].weight.detach().double().abs().sum())]))
+    print("loss_curve", curve[0], "->", curve[-1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -225,6 +291,7 @@ def main():
     seeded_e2e_case(M)
     knn_case()
     vit_case()
+    loss_curve_case(M)
     # small full-tensor cases (inputs stored); H != W catches x/y swaps, odd K/C catch padding bugs
     run_case(M, "small_default", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=1)
     run_case(M, "small_nopointwise", B=3, C=20, H=6, W=7, K=6, S=4, n_neg=2, seed=2, cfg_kw=dict(pointwise=False))

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the reference's golden vectors and
 the fp64 oracle.  Tolerance (north_star): 1e-3 relative in fp32, written out in
 conftest.assert_close (rtol=1e-3, atol = 1e-4 * mean|expected|).  Needs the MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -524,3 +526,41 @@ def test_fused_forward_stress_rotating_inputs_against_three_launch_path(precisio
             assert worst < 2e-6, (rep, worst)
     finally:
         capi.debug_set("STEGO_FWD_VARIANT", 0)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_loss_curve_of_20_training_steps_overlaps_the_reference(precision):
+    """north_star: 'loss-curve overlap within 1e-3 of upstream'.  tests/golden/loss_curve.npz holds the UNMODIFIED reference
+    ContrastiveCorrelationLoss (modules.py:349-398) inside a 20-step Adam loop on the segmentation head
+    (train_segmentation.py:163-181,391; oracle/make_golden.py:loss_curve_case) together with the RNG draws it made.  The same
+    loop on the HIP path (fused forward + backward through the C ABI, torch Adam on the device) must log the same losses at
+    every step and end with the same head."""
+    from oracle.make_golden import LOSS_CURVE as p, loss_curve_inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_curve.npz"))
+    feats, feats_pos, cluster1, cluster2 = loss_curve_inputs(p)
+    feats, feats_pos = feats.to(DEV), feats_pos.to(DEV)
+    cluster1, cluster2 = cluster1.to(DEV), cluster2.to(DEV)
+    cfg = O.CorrCfg(feature_samples=p["S"], neg_samples=p["n_neg"])
+    cfg.corr_precision = precision
+    loss_fn = M.ContrastiveCorrelationLoss(cfg)
+    opt = torch.optim.Adam(list(cluster1.parameters()) + list(cluster2.parameters()), lr=p["lr"])
+    curve = []
+    for t in range(p["steps"]):
+        opt.zero_grad()
+        code = cluster1(feats) + cluster2(feats)
+        code_pos = cluster1(feats_pos) + cluster2(feats_pos)
+        out = loss_fn.forward_explicit(feats, feats_pos, code, code_pos, _dev(g["coords1"][t]), _dev(g["coords2"][t]), _dev(g["perms"][t]))
+        pil, pel, nl = out[0].mean(), out[2].mean(), out[4].mean()
+        loss = p["w_inter"] * pel + p["w_intra"] * pil + p["w_neg"] * nl
+        loss.backward()
+        opt.step()
+        curve.append([float(pil.detach()), float(pel.detach()), float(nl.detach()), float(loss.detach())])
+    curve = np.array(curve)
+    ref = g["curve"]
+    err = np.abs(curve - ref)
+    assert err.max() < 1e-4, (int(err.argmax()) // 4, err.max())                  # each logged term, absolute (terms are O(0.1))
+    assert (err[:, 3] / np.abs(ref[:, 3])).max() < 1e-3                           # the total loss, relative: the north_star bar
+    w1 = cluster1[0].weight.detach().reshape(p["K"], p["C"]).cpu().numpy()
+    w2 = cluster2[2].weight.detach().reshape(p["K"], p["C"]).cpu().numpy()
+    for got, want in ((w1, g["final_cluster1_w"]), (w2, g["final_cluster2_out_w"])):
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-3
