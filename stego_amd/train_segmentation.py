@@ -51,6 +51,10 @@ def load_config(path=None, overrides=()):
     return types.SimpleNamespace(**d)
 
 
+MAX_CODE_DIM = 72                # include/stego_corr.h "Limits of this build"
+MAX_FEATURE_SAMPLES = 11
+
+
 class LitUnsupervisedSegmenter(nn.Module):
     def __init__(self, n_classes, cfg):
         super().__init__()
@@ -75,6 +79,15 @@ class LitUnsupervisedSegmenter(nn.Module):
         self.linear_probe_loss_fn = nn.CrossEntropyLoss()
         self.crf_loss_fn = ContrastiveCRFLoss(cfg.crf_samples, cfg.alpha, cfg.beta, cfg.gamma, cfg.w1, cfg.w2, cfg.shift)
         self.contrastive_corr_loss_fn = ContrastiveCorrelationLoss(cfg)
+        # limits of this build of libstego_corr (include/stego_corr.h): fail here, with the cfg keys named, not with
+        # STEGO_ERR_UNSUPPORTED inside the first training_step
+        if cfg.correspondence_weight > 0:
+            if dim > MAX_CODE_DIM:
+                raise ValueError("cfg.dim=%d: this build of the correspondence-loss kernels supports code dimensions up to %d "
+                                 "(train_config.yml:39 ships 70); see include/stego_corr.h" % (dim, MAX_CODE_DIM))
+            if cfg.feature_samples > MAX_FEATURE_SAMPLES:
+                raise ValueError("cfg.feature_samples=%d: this build supports up to %d (S*S <= 128 sample points per image; "
+                                 "train_config.yml:51 ships 11)" % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
         for p in self.contrastive_corr_loss_fn.parameters():
             p.requires_grad = False
         self.automatic_optimization = False

@@ -78,8 +78,8 @@ def test_native_matches_reference_golden():
     got = vit_native.NativeViT(model).forward_tokens(img.cuda()).cpu()
     assert got.shape == feat.shape
     err = _rel(got, feat)
-    assert err < 3e-3, err                                # fp16 operands (11-bit mantissa), fp32 everything else
-    assert float((got - feat).abs().max()) < 4e-2
+    assert err < 1e-3, err                                # the north_star bar (measured 7.5e-4): fp16 operands, fp32 everything else
+    assert float((got - feat).abs().max()) < 4e-2        # elementwise bound (absolute; |feat| is O(1..10)): why the path is opt-in
 
 
 @pytest.mark.gpu
