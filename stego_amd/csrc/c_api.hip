@@ -97,7 +97,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
-    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8, 256) + 256;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
+    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8 * 4, 256) + 256;   // + 3 more granules per tile: sum lp, sum clamp, applied;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
     g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.csf_bytes + g.ctx_bytes;
     g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
     return g;

@@ -133,7 +133,7 @@ struct FusedParams {
     float* loss_means;                         // [2]
     float* stats;                              // [n_sets*B][4]: sum fd, sum lp, sum clamp, 1 = old_mean applied in-kernel
     unsigned* anchor_cnt;                      // [B] points published per anchor           } zeroed before the launch
-    unsigned long long* gran;                  // [n_sets*B] {tag = 1, sum fd} granules     }  (the last workgroup of a
+    unsigned long long* gran;                  // [4][n_sets*B] {tag = 1, value} granules   }  (the last workgroup of a
     unsigned* done_cnt;                        // workgroups that finished                  }   launch zeroes them again)
     unsigned char* fs;                         // anchor feature operand stages [B][NCH2][16 KB] (ring format H, or F in f32 mode)
     unsigned char* csf;                        // anchor code operand stages    [B][NKC][16 KB]  (ring format F)

@@ -904,10 +904,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     __syncthreads();                             // E1: Tfd and the four partial sums are complete
     if (tid == 0) {
         const float sfd = (red[0] + red[1]) + (red[2] + red[3]);
-        __hip_atomic_store(prm.stats + (size_t)tile * 4 + 0, sfd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (rendezvous)                          // one aligned 8-byte write-through store: {tag, value}
-            __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        // one aligned 8-byte write-through store: {tag, value} (read by the tiles of my pair-set and by the last workgroup)
+        __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     float* omv = red + 8;                        // [0] old_mean, [1] applied
     if (mfma_team) {
@@ -1012,16 +1011,18 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     const bool gave_up = omv[1] == 0.f;
     if (gave_up) __threadfence();                // (rare) whoever repairs this tile must see its cd / loss: release my stores
     __syncthreads();
-    // ---- my sums, write-through; then one ticket: the LAST workgroup of the launch finishes the job (below)
+    // ---- my sums as {tag, value} granules, then one ticket, WITHOUT waiting for the stores in between (a store-ack round
+    // trip per workgroup at the very end of the launch): the LAST workgroup of the launch finishes the job below and polls
+    // the granules it needs - by then they have been in flight for at least an atomic's round trip.
     float* fin = red + 48;                       // [0] 1 = I am the last workgroup
+    unsigned long long* gst = prm.gran + n_tiles;                  // [n_tiles][3]: sum lp, sum clamp, old_mean applied
     if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
         for (int w = 0; w < FUSED_WAVES; ++w) { s1 += red[16 + w * 2]; s2 += red[16 + w * 2 + 1]; }
-        float* st = prm.stats + (size_t)tile * 4;
-        __hip_atomic_store(st + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(st + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(st + 3, omv[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the write-through stores have landed
+        unsigned long long* g3 = gst + (size_t)tile * 3;
+        __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, omv[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fin[0] = t == (unsigned)(n_tiles - 1) ? 1.f : 0.f;
     }
@@ -1032,12 +1033,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     // ================================================================= the last workgroup of the launch
     // The three scalars and the saved means from the per-tile sums in image order (modules.py:331,393,395):
     //   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
-    // tiles whose rendezvous gave up (stats[3] == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
+    // tiles whose rendezvous gave up (applied == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
     // same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
-    float* sst = Tfd;                            // [n_tiles][4] staged copy of the stats (the ring is dead)
+    float* sst = Tfd;                            // [n_tiles][4] staged copy of the sums (the ring is dead)
     float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set
-    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
-        sst[i] = __hip_atomic_load(prm.stats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS) {
+            const int t = i >> 2, k = i & 3;
+            const unsigned long long* src = k == 0 ? prm.gran + t : gst + (size_t)t * 3 + (k - 1);
+            unsigned long long x;
+            for (;;) {
+                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((x >> 32) == 1ull) break;
+                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sst[i] = __builtin_bit_cast(float, (unsigned)x);
+        }
+    }
     __syncthreads();
     const float inv_cnt = 1.f / ((float)B * (float)P2);
     if (tid < prm.n_sets) {
@@ -1052,7 +1066,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
     }
     __syncthreads();
-    if (prm.pointwise) {
+    // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
+    bool mine = false;
+    for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;
+    if (prm.pointwise && __syncthreads_or(mine)) {
         for (int t = 2 * B; t < n_tiles; ++t) {
             if (sst[t * 4 + 3] != 0.f) continue;                   // (workgroup-uniform)
             const float omp = som[t / B];
@@ -1068,7 +1085,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     }
     for (int i = tid; i < B; i += FUSED_THREADS)
         __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < n_tiles; i += FUSED_THREADS)
+    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
         __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -130,7 +130,7 @@ def test_featurizer_uses_native_backbone_and_feeds_the_loss_layout():
 
     class C:
         dino_patch_size = 8; dino_feat_type = "feat"; model_type = "vit_small"; projection_type = "nonlinear"
-        dropout = False; pretrained_weights = None
+        dropout = False; pretrained_weights = None; native_backbone = True        # opt-in (default: the fp32 torch backbone)
     torch.manual_seed(7)
     fz = featurizers.DinoFeaturizer(70, C()).cuda().eval()
     img = torch.randn(2, 3, 224, 224, device="cuda")
