@@ -77,7 +77,10 @@ typedef struct StegoCorrDesc {
 } StegoCorrDesc;
 
 /* Limits of this build: S*S <= 128 (S <= 11), K <= 72 (cfg.dim; the reference ships 70), every per-image
- * element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED. */
+ * element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED.
+ * Determinism: every kernel sums in a fixed order (bitwise repeatable results), with ONE exception: the backward of maps
+ * wider than 64 pixels (no BASELINE config) takes a band fallback whose fp32 summation order follows arrival order; repeated
+ * runs agree to <= 1e-6 of the largest gradient (tests/test_parity_gpu.py). */
 
 int stego_abi_version(void);
 const char* stego_error_string(int code);

@@ -438,6 +438,7 @@ int stego_corr_bwd(const StegoCorrDesc* d, const int64_t* perms, const float* sa
     prm.d_code = d_code; prm.d_code_pos = d_code_pos;
     prm.B = d->B; prm.K = d->K; prm.H = d->H; prm.W = d->W; prm.S = d->S; prm.P = d->S * d->S;
     prm.n_neg = d->n_neg; prm.n_sets = 2 + d->n_neg; prm.mode = 0;
+    prm.precision = d->precision;
     prm.debug = knob(KNOB_DEBUG_BWD);
     prm.cmin = d->zero_clamp ? 0.0f : -9999.0f;
     prm.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();

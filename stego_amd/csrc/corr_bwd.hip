@@ -236,6 +236,288 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ------------------------------------------------------------------------------- tile kernel, split-fp16 GEMMs
+// The same backward with the two code GEMMs on the fp16 matrix cores (precision F16X3, the training case: scalar / broadcast
+// upstream gradients; the fp32 MFMA of the kernel above runs at the VALU rate on gfx950: 2 x 4.3 us per tile).  Every fp32
+// operand is split into fp16 hi + lo and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32
+// accumulation, as in the forward.  MFMA operands must be k-contiguous per lane:
+//   CT [side][hi|lo][channel][point]   the normalised sampled codes of both sides, TRANSPOSED on the way into LDS
+//   Gh/Gl [row][col]                   G, row-major, times one power of two per tile
+//   dAn^T = Bn^T . G^T    A operand = rows of CT(B), B operand = rows of G (k = column: 8-byte reads)
+//   dBn^T = An^T . G      A operand = rows of CT(A) (k = anchor point), B operand = COLUMNS of G, gathered as 4 x 2 bytes
+//                         per lane and step (a transposed copy of G does not fit next to CT: 157 KB are in use)
+// Scale: with scalar upstreams |g| = |gl| |w + old_mean| < 4 |gl| (w = a cosine - a row mean - a shift), so 2^-ceil(log2(4 |gl|))
+// keeps every entry below 1; fp16 hi + lo then resolve 2^-25 of that bound absolutely - fp32 accuracy relative to the
+// largest entries, which is what a 128-term sum needs.  Dense upstreams (tests, unusual callers) take the fp32 kernel.
+constexpr int HB_LDR = 136;                           // halves per row of an operand image (272 B: conflict-free 8-byte reads)
+constexpr int SMH_NRM = 0;                            // float nrm[2][128]
+constexpr int SMH_CT = 1024;
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// normalize-backward of the B side's gradient held TRANSPOSED in MFMA 16x16 C/D layout and store to DT:
+// d[mc][np][reg] <-> channel 16 mc + 4 (lane >> 4) + reg, point 16 (NP wave + np) + (lane & 15).
+constexpr int HW_WAVES = 8;                           // waves of the split kernel (two per SIMD: the phases are latency chains)
+constexpr int HW_THREADS = 64 * HW_WAVES;
+constexpr int HW_NP = TP / (16 * HW_WAVES);           // 16-point tiles per wave
+template <int NT>
+__device__ __forceinline__ void normalize_bwd_store_t(f32x4 (&d)[NT][HW_NP], const float* __restrict__ Cn, int ldk,
+                                                      const float* __restrict__ nrm, float* __restrict__ dt_out,
+                                                      int K, int KQ, int lane, int wave)
+{
+    const int cl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int np = 0; np < HW_NP; ++np) {
+        const int pt = 16 * (HW_NP * wave + np) + cl;
+        f32x4 cn[NT];
+        float dot = 0.f;
+#pragma unroll
+        for (int mc = 0; mc < NT; ++mc) {
+            const int ch0 = 16 * mc + 4 * kq;
+            cn[mc] = *reinterpret_cast<const f32x4*>(Cn + (size_t)pt * ldk + ch0);     // columns >= K hold padding / neighbours
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (ch0 + reg >= K) cn[mc][reg] = 0.f;
+                dot += cn[mc][reg] * (ch0 + reg < K ? d[mc][np][reg] : 0.f);
+            }
+        }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        const float nr = nrm[pt];
+        const bool big = nr > 1e-10f;
+        const float inv = 1.f / fmaxf(nr, 1e-10f);
+#pragma unroll
+        for (int mc = 0; mc < NT; ++mc) {
+            const int ch0 = 16 * mc + 4 * kq;
+            if (ch0 < KQ) {                           // KQ is a multiple of 8: a 4-channel group is inside or outside
+                f32x4 v;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float dn = d[mc][np][reg];
+                    v[reg] = big ? (dn - cn[mc][reg] * dot) * inv : dn * inv;
+                    if (ch0 + reg >= K) v[reg] = 0.f;
+                }
+                *reinterpret_cast<f32x4*>(dt_out + (size_t)pt * ldk + ch0) = v;
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CTR = 16 * NT;                      // channel rows per operand image
+    float* nrm = reinterpret_cast<float*>(smem + SMH_NRM);
+    half_t* CT = reinterpret_cast<half_t*>(smem + SMH_CT);                       // [side][hi|lo][CTR][HB_LDR]
+    half_t* Gh = CT + 4 * CTR * HB_LDR;
+    half_t* Gl = Gh + TP * HB_LDR;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int B = prm.B, P = prm.P, K = prm.K, ldk = prm.LDK;
+    const int tile = blockIdx.x;
+    const int b = tile % B, p = tile / B;
+    const bool sameAB = p == 0;
+    const int sA = b;
+    const int sB = p == 0 ? b : p * B + b;
+    const float* csA = prm.cs + (size_t)sA * TP * ldk;
+    const float* csB = prm.cs + (size_t)sB * TP * ldk;
+
+    // debug bit 8: phase stamps (100 MHz global clock), 4 per tile, second half of the workspace tail
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)blockIdx.x * 4;
+    const bool stamp_on = (prm.debug & 8) && tid == 0 && blockIdx.x < 1024;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
+    // ---- upstream of this tile: one scalar (launcher: no dense upstream takes this kernel)
+    const int P2 = P * P;
+    const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
+    float gl = 0.f;
+    if (p >= 2) { if (prm.g_neg_loss) gl = prm.g_neg_loss[0]; }
+    else {
+        const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
+        if (gs) gl = gs[0] * (1.f / ((float)B * (float)P2));
+    }
+    const float om = prm.saved_mean[p];
+    float sc_tile = 1.f, inv_tile = 1.f;              // 2^-e with 2^e >= 4 |gl|
+    if (gl != 0.f) {
+        const int e = __builtin_amdgcn_frexp_expf(4.f * fabsf(gl));
+        sc_tile = __builtin_ldexpf(1.f, -e);
+        inv_tile = __builtin_ldexpf(1.f, e);
+    }
+    const float gls = gl * sc_tile;
+
+    // ---- every global load of the tile's operands goes out first (one round trip: a wave has 512 registers here):
+    // the saved w of my 32 rows of G, and my share of both code images
+    constexpr int RB = TP / HW_WAVES;                 // rows of G per wave
+    constexpr int c4n = CTR / 4;                      // 4-channel groups per row (reads past ldk stay inside the next row / the slack)
+    constexpr int NIT = ((TP / 2) * c4n + HW_THREADS - 1) / HW_THREADS;
+    float wv[RB][2];
+    f32x4 r0[2][NIT], r1[2][NIT];
+    {
+        const int c0 = min(2 * lane, P - 1), c1 = min(2 * lane + 1, P - 1);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int r = (prm.debug & 4) ? 0 : min(wave + HW_WAVES * j, P - 1);       // (ablation 4: one row)
+            wv[j][0] = wp[r * P + c0];
+            wv[j][1] = wp[r * P + c1];
+        }
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const float* src = (side == 0 || sameAB) ? csA : csB;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = (prm.debug & 16) ? 0 : min(tid + it * HW_THREADS, (TP / 2) * c4n - 1);    // (ablation 16: one element)
+                const int pp = i / c4n, c4 = i - pp * c4n;
+                r0[side][it] = *reinterpret_cast<const f32x4*>(src + (size_t)(2 * pp) * ldk + 4 * c4);
+                r1[side][it] = *reinterpret_cast<const f32x4*>(src + (size_t)(2 * pp + 1) * ldk + 4 * c4);
+            }
+        }
+    }
+    if (tid < 2 * TP) nrm[tid] = prm.nrm[(size_t)(tid < TP ? sA : sB) * TP + (tid & (TP - 1))];
+    // ---- G (rows r = wave + HW_WAVES j, columns 2 lane, 2 lane + 1) -> fp16 hi / lo, row-major
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int r = wave + HW_WAVES * j;
+        float x[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // the forward left the clamp pass-mask 1[cmin <= cd <= cmax] in the mantissa LSB of w
+            const unsigned wb = __builtin_bit_cast(unsigned, wv[j][h]);
+            const float w = __builtin_bit_cast(float, wb & ~1u);
+            const float g = (wb & 1u) ? -(w + om) * gls : 0.f;
+            x[h] = (r < P && 2 * lane + h < P) ? g : 0.f;
+        }
+        unsigned hi, lo;
+        split_f16_pair(x[0], x[1], hi, lo);
+        *reinterpret_cast<unsigned*>(Gh + r * HB_LDR + 2 * lane) = hi;
+        *reinterpret_cast<unsigned*>(Gl + r * HB_LDR + 2 * lane) = lo;
+    }
+    // ---- the code operands: [point][channel] fp32 rows -> [channel][point] fp16 hi / lo images (two points per store)
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (side == 1 && sameAB) break;
+        half_t* dh = CT + (size_t)(2 * side) * CTR * HB_LDR;
+        half_t* dl = dh + CTR * HB_LDR;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * HW_THREADS;
+            if (i < (TP / 2) * c4n) {
+                const int pp = i / c4n, c4 = i - pp * c4n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = 4 * c4 + e;
+                    unsigned h, l;
+                    split_f16_pair(ch < K ? r0[side][it][e] : 0.f, ch < K ? r1[side][it][e] : 0.f, h, l);
+                    *reinterpret_cast<unsigned*>(dh + ch * HB_LDR + 2 * pp) = h;
+                    *reinterpret_cast<unsigned*>(dl + ch * HB_LDR + 2 * pp) = l;
+                }
+            }
+        }
+    }
+    __syncthreads();                                  // CT, G
+    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
+
+    // lane map of v_mfma_f32_16x16x16_f16: A[i = lane & 15][k = 4 (lane >> 4) + 0..3], B[k = 4 (lane >> 4) + 0..3][j = lane & 15]
+    const int cl = lane & 15, kq = lane >> 4;
+    half_t* ATh = CT;                                 // side 0 = anchors
+    half_t* ATl = CT + CTR * HB_LDR;
+    half_t* BTh = sameAB ? ATh : CT + 2 * CTR * HB_LDR;
+    half_t* BTl = sameAB ? ATl : CT + 3 * CTR * HB_LDR;
+    float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
+    const bool skip = (prm.debug & 1) || gl == 0.f;   // (no upstream: G = 0, the gradients are zero)
+
+    // ---- dAn^T = Bn^T . G^T: channel rows of CT(B) (A operand) against the ROWS 32 wave + 16 np + j of G (B operand:
+    // B[k][j] = G[j][k], k-contiguous in a row-major G).  Result channel-major like dBn^T below.
+    f32x4 dAt[NT][HW_NP];
+#pragma unroll
+    for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+        for (int np = 0; np < HW_NP; ++np) dAt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!skip) {
+        const int ra = cl * HB_LDR + 4 * kq;
+        const int rg = (16 * HW_NP * wave + cl) * HB_LDR + 4 * kq;
+#pragma unroll 2
+        for (int kk = 0; kk < TP; kk += 16) {
+            f16x4 ah[NT], al[NT], bh[HW_NP], bl[HW_NP];
+#pragma unroll
+            for (int mc = 0; mc < NT; ++mc) {
+                ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + kk);
+                al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + kk);
+            }
+#pragma unroll
+            for (int np = 0; np < HW_NP; ++np) {
+                bh[np] = *reinterpret_cast<const f16x4*>(Gh + rg + 16 * np * HB_LDR + kk);
+                bl[np] = *reinterpret_cast<const f16x4*>(Gl + rg + 16 * np * HB_LDR + kk);
+            }
+            // the three terms outermost: consecutive MFMAs never wait for each other's accumulator
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+                    for (int np = 0; np < HW_NP; ++np)
+                        dAt[mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np],
+                                                                            dAt[mc][np], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+            for (int np = 0; np < HW_NP; ++np) dAt[mc][np] *= inv_tile;
+    }
+    if (!sameAB) normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
+
+    // ---- dBn^T = An^T . G: channel rows of CT(A) against the columns 32 wave + 16 np + j of G (k = anchor point)
+    f32x4 dBt[NT][HW_NP];
+#pragma unroll
+    for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+        for (int np = 0; np < HW_NP; ++np) dBt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!skip) {
+        const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
+        const int gb = 4 * kq * HB_LDR + 16 * HW_NP * wave + cl;      // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl
+#pragma unroll 2
+        for (int kk = 0; kk < TP; kk += 16) {
+            f16x4 ah[NT], al[NT], bh[HW_NP], bl[HW_NP];
+#pragma unroll
+            for (int mc = 0; mc < NT; ++mc) {
+                ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + kk);
+                al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + kk);
+            }
+#pragma unroll
+            for (int np = 0; np < HW_NP; ++np)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bh[np][e] = Gh[gb + (kk + e) * HB_LDR + 16 * np];
+                    bl[np][e] = Gl[gb + (kk + e) * HB_LDR + 16 * np];
+                }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+                    for (int np = 0; np < HW_NP; ++np)
+                        dBt[mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np],
+                                                                            dBt[mc][np], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+            for (int np = 0; np < HW_NP; ++np) dBt[mc][np] *= inv_tile;
+    }
+    if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
+    if (sameAB) {
+        // c1 is c2: both adjoints hit the same samples (same register layout: just add)
+#pragma unroll
+        for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+            for (int np = 0; np < HW_NP; ++np) dAt[mc][np] += dBt[mc][np];
+        normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
+    } else {
+        normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
+    }
+    if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
+}
+
 // ------------------------------------------------------------------------------- unsample
 // grid = n_dest(2) * B * n_bands ; block = 512 (8 waves); a band has RT <= 8 pixel rows and WAVE r OWNS ROW r.
 // LDS: float acc[RT][W][K] | contribution table | per-row worklists | counters.
@@ -669,14 +951,23 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
     // ---- tile kernel
     {
         const int cside = TP * prm.LDK * 4;
-        const int lds = SMB_AN + 2 * cside + TP * LDG * 4;
         const int nt = (prm.KQ + 15) / 16;
+        // split-fp16 GEMMs: the training case (scalar / broadcast upstreams on the losses, none on the cd tensors)
+        const bool split = prm.precision == PREC_F16X3 && prm.mode == 0 && !(prm.debug & 64) &&   // (debug 64: fp32 MFMA kernel)
+                           !prm.g_intra_cd && !prm.g_inter_cd && !prm.g_neg_cd && (!prm.g_neg_loss || prm.g_neg_loss_stride == 0);
+        const int lds = split ? SMH_CT + (4 * 16 * nt + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;
         const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
 #define STEGO_BWD_CASE(N)                                                                                         \
     case N: {                                                                                                     \
-        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>), lds);        \
-        if (ea != hipSuccess) return ea;                                                                          \
-        hipLaunchKernelGGL((corr_bwd_tile_kernel<N>), grid, block, lds, stream, prm);                             \
+        if (split) {                                                                                              \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N>), lds);  \
+            if (ea != hipSuccess) return ea;                                                                      \
+            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N>), grid, dim3(HW_THREADS), lds, stream, prm);            \
+        } else {                                                                                                  \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>), lds);    \
+            if (ea != hipSuccess) return ea;                                                                      \
+            hipLaunchKernelGGL((corr_bwd_tile_kernel<N>), grid, block, lds, stream, prm);                         \
+        }                                                                                                         \
         break;                                                                                                    \
     }
         switch (nt) {

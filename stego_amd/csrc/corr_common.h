@@ -114,7 +114,8 @@ struct BwdParams {
     int g_neg_loss_stride;                     // 1 dense, 0 broadcast scalar
     int B, K, H, W, S, P, n_neg, n_sets;
     int mode;
-    int debug;                                 // 1 skip MFMA, 2 skip scatter, 4 skip G fill
+    int precision;                             // PREC_*: F16X3 = the tile kernel's GEMMs as split-fp16 products (mode 0)
+    int debug;                                 // 1 skip MFMA, 2 skip scatter, 4 skip G fill, 64 fp32-MFMA tile kernel
     float cmin, cmax;
 };
 

@@ -9,14 +9,14 @@ cfg = bench.Cfg()
 C, H, W, K = bench.WORKLOADS["vits8_224"]
 B, S, n_neg = 32, 11, 5
 d = bench.make_inputs(B, C, H, W, K, S, n_neg, 1000, dev)
-desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F32)
+desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F32 if os.environ.get("PREC") == "f32" else capi.PREC_F16X3)
 lib = capi.load()
 out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
 lm, icd, ecd, nl, ncd, saved = out
 sw, sm, sctx = saved
 g_intra = torch.tensor(0.67, device=dev); g_inter = torch.tensor(0.25, device=dev)
 g_neg = torch.full((1,), 0.63 / (n_neg * B * S ** 4), device=dev)
-os.environ["STEGO_DEBUG_BWD"] = sys.argv[1] if len(sys.argv) > 1 else "8"
+capi.debug_set("STEGO_DEBUG_BWD", int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 nws = lib.stego_corr_bwd_workspace_bytes(byref(desc))
 ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
 dc = torch.empty(B, H, W, K, device=dev); dcp = torch.empty(B, H, W, K, device=dev)
