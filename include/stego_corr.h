@@ -76,8 +76,10 @@ typedef struct StegoCorrDesc {
     int32_t precision;         /* STEGO_PREC_*                                                 */
 } StegoCorrDesc;
 
-/* Limits of this build: S*S <= 128 (S <= 11), K <= 72 (cfg.dim; the reference ships 70), every per-image
- * element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED.
+/* Limits of this build: S*S <= 128 (S <= 11); K (cfg.dim; the reference ships 70) <= 128 on the fused path (K even,
+ * channels-last maps with C = 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
+ * helper()); every per-image element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
+ * GEMMs are split-fp16 products in both precision modes (their fp32 operand images no longer fit LDS).
  * Determinism: every kernel sums in a fixed order (bitwise repeatable results), with ONE exception: the backward of maps
  * wider than 64 pixels (no BASELINE config) takes a band fallback whose fp32 summation order follows arrival order; repeated
  * runs agree to <= 1e-6 of the largest gradient (tests/test_parity_gpu.py). */

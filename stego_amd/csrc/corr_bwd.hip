@@ -237,21 +237,22 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
 }
 
 // ------------------------------------------------------------------------------- tile kernel, split-fp16 GEMMs
-// The same backward with the two code GEMMs on the fp16 matrix cores (precision F16X3, the training case: scalar / broadcast
-// upstream gradients; the fp32 MFMA of the kernel above runs at the VALU rate on gfx950: 2 x 4.3 us per tile).  Every fp32
-// operand is split into fp16 hi + lo and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32
-// accumulation, as in the forward.  MFMA operands must be k-contiguous per lane:
+// The same backward with the two code GEMMs on the fp16 matrix cores (forward() semantics: precision F16X3, and any mode once
+// K > 80; the fp32 MFMA of the kernel above runs at the VALU rate on gfx950: 2 x 4.3 us per tile).  Every fp32 operand is
+// split into fp16 hi + lo and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32 accumulation, as in
+// the forward.  MFMA operands must be k-contiguous per lane:
 //   CT [side][hi|lo][channel][point]   the normalised sampled codes of both sides, TRANSPOSED on the way into LDS
 //   Gh/Gl [row][col]                   G, row-major, times one power of two per tile
 //   dAn^T = Bn^T . G^T    A operand = rows of CT(B), B operand = rows of G (k = column: 8-byte reads)
 //   dBn^T = An^T . G      A operand = rows of CT(A) (k = anchor point), B operand = COLUMNS of G, gathered as 4 x 2 bytes
 //                         per lane and step (a transposed copy of G does not fit next to CT: 157 KB are in use)
-// Scale: with scalar upstreams |g| = |gl| |w + old_mean| < 4 |gl| (w = a cosine - a row mean - a shift), so 2^-ceil(log2(4 |gl|))
-// keeps every entry below 1; fp16 hi + lo then resolve 2^-25 of that bound absolutely - fp32 accuracy relative to the
-// largest entries, which is what a 128-term sum needs.  Dense upstreams (tests, unusual callers) take the fp32 kernel.
+// Scale: G's entries are ~1e-7 (upstream 1 / (B P^2)).  The tile's largest |g| (exact: every lane holds its 32 entries in
+// registers, one wave reduction + 8 partials through LDS) picks one power of two that brings it into [0.5, 1); fp16 hi + lo
+// then resolve 2^-25 of that absolutely - fp32 accuracy relative to the largest entries, which is what a 128-term sum needs.
+// Channel tiles beyond 5 (K > 80) are processed in two groups that share the G image.
 constexpr int HB_LDR = 136;                           // halves per row of an operand image (272 B: conflict-free 8-byte reads)
-constexpr int SMH_NRM = 0;                            // float nrm[2][128]
-constexpr int SMH_CT = 1024;
+constexpr int SMH_NRM = 0;                            // float nrm[2][128], red[8]
+constexpr int SMH_CT = 1280;
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -307,8 +308,12 @@ template <int NT>
 __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int CTR = 16 * NT;                      // channel rows per operand image
+    // channel tiles are processed in groups whose operand images fit LDS next to G: all of them up to K = 80, two groups beyond
+    constexpr int NTG = NT <= 5 ? NT : (NT + 1) / 2;
+    constexpr int NG = (NT + NTG - 1) / NTG;
+    constexpr int CTR = 16 * NTG;                     // channel rows per operand image
     float* nrm = reinterpret_cast<float*>(smem + SMH_NRM);
+    float* red = nrm + 2 * TP;                        // [HW_WAVES] partial maxima of |g|
     half_t* CT = reinterpret_cast<half_t*>(smem + SMH_CT);                       // [side][hi|lo][CTR][HB_LDR]
     half_t* Gh = CT + 4 * CTR * HB_LDR;
     half_t* Gl = Gh + TP * HB_LDR;
@@ -328,42 +333,40 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)blockIdx.x * 4;
     const bool stamp_on = (prm.debug & 8) && tid == 0 && blockIdx.x < 1024;
     if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
-    // ---- upstream of this tile: one scalar (launcher: no dense upstream takes this kernel)
-    const int P2 = P * P;
-    const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
-    float gl = 0.f;
-    if (p >= 2) { if (prm.g_neg_loss) gl = prm.g_neg_loss[0]; }
-    else {
-        const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
-        if (gs) gl = gs[0] * (1.f / ((float)B * (float)P2));
-    }
-    const float om = prm.saved_mean[p];
-    float sc_tile = 1.f, inv_tile = 1.f;              // 2^-e with 2^e >= 4 |gl|
-    if (gl != 0.f) {
-        const int e = __builtin_amdgcn_frexp_expf(4.f * fabsf(gl));
-        sc_tile = __builtin_ldexpf(1.f, -e);
-        inv_tile = __builtin_ldexpf(1.f, e);
-    }
-    const float gls = gl * sc_tile;
 
-    // ---- every global load of the tile's operands goes out first (one round trip: a wave has 512 registers here):
-    // the saved w of my 32 rows of G, and my share of both code images
-    constexpr int RB = TP / HW_WAVES;                 // rows of G per wave
-    constexpr int c4n = CTR / 4;                      // 4-channel groups per row (reads past ldk stay inside the next row / the slack)
-    constexpr int NIT = ((TP / 2) * c4n + HW_THREADS - 1) / HW_THREADS;
-    float wv[RB][2];
-    f32x4 r0[2][NIT], r1[2][NIT];
-    {
-        const int c0 = min(2 * lane, P - 1), c1 = min(2 * lane + 1, P - 1);
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int r = (prm.debug & 4) ? 0 : min(wave + HW_WAVES * j, P - 1);       // (ablation 4: one row)
-            wv[j][0] = wp[r * P + c0];
-            wv[j][1] = wp[r * P + c1];
+    // ---- upstreams folded into (pointer, index multiplier, scale) triples: absent / broadcast gradients need no branches
+    //      g = -(w + old_mean) * gl * 1[cmin <= cd <= cmax] + gc
+    const int P2 = P * P;
+    const size_t t0 = p < 2 ? (size_t)b * P2 : ((size_t)(p - 2) * B + b) * P2;
+    const float* wp = prm.saved_w + ((size_t)p * B + b) * P2;
+    const float* glp = wp;                            // dummy when there is no upstream (scale 0)
+    bool has_gl = false;
+    float gl_b = 0.f;                                 // broadcast / scalar upstream of the loss
+    if (p >= 2) {
+        if (prm.g_neg_loss) {
+            if (prm.g_neg_loss_stride != 0) { glp = prm.g_neg_loss + t0; has_gl = true; }
+            else gl_b = prm.g_neg_loss[0];
         }
+    } else {
+        const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
+        if (gs) gl_b = gs[0] * (1.f / ((float)B * (float)P2));
+    }
+    const float* gcd = p == 0 ? prm.g_intra_cd : (p == 1 ? prm.g_inter_cd : prm.g_neg_cd);
+    const bool has_gc = gcd != nullptr;
+    const float* gcp = has_gc ? gcd + t0 : wp;
+    const float om = prm.saved_mean[p];
+
+    // ---- every global load of the first operands goes out first (one round trip: a wave has 512 registers here): the saved
+    // w (and dense upstreams) of my 16 rows of G, and my share of the first group's code rows of both sides
+    constexpr int RB = TP / HW_WAVES;                 // rows of G per wave
+    constexpr int c4n = CTR / 4;                      // 4-channel groups per row of a group (reads past ldk stay inside the slack)
+    constexpr int NIT = ((TP / 2) * c4n + HW_THREADS - 1) / HW_THREADS;
+    float wv[RB][2], glv[RB][2], gcv[RB][2];
+    f32x4 r0[2][NIT], r1[2][NIT];
+    auto load_codes = [&](int grp) {
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            const float* src = (side == 0 || sameAB) ? csA : csB;
+            const float* src = ((side == 0 || sameAB) ? csA : csB) + grp * CTR;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int i = (prm.debug & 16) ? 0 : min(tid + it * HW_THREADS, (TP / 2) * c4n - 1);    // (ablation 16: one element)
@@ -372,50 +375,98 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
                 r1[side][it] = *reinterpret_cast<const f32x4*>(src + (size_t)(2 * pp + 1) * ldk + 4 * c4);
             }
         }
+    };
+    // [point][channel] fp32 rows -> [channel][point] fp16 hi / lo images (two points per store)
+    auto convert_codes = [&](int grp) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            if (side == 1 && sameAB) break;
+            half_t* dh = CT + (size_t)(2 * side) * CTR * HB_LDR;
+            half_t* dl = dh + CTR * HB_LDR;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * HW_THREADS;
+                if (i < (TP / 2) * c4n) {
+                    const int pp = i / c4n, c4 = i - pp * c4n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ch = 4 * c4 + e;
+                        const bool in = grp * CTR + ch < K;
+                        unsigned h, l;
+                        split_f16_pair(in ? r0[side][it][e] : 0.f, in ? r1[side][it][e] : 0.f, h, l);
+                        *reinterpret_cast<unsigned*>(dh + ch * HB_LDR + 2 * pp) = h;
+                        *reinterpret_cast<unsigned*>(dl + ch * HB_LDR + 2 * pp) = l;
+                    }
+                }
+            }
+        }
+    };
+    {
+        const int c0 = min(2 * lane, P - 1), c1 = min(2 * lane + 1, P - 1);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int r = (prm.debug & 4) ? 0 : min(wave + HW_WAVES * j, P - 1);       // (ablation 4: one row)
+            wv[j][0] = wp[r * P + c0];
+            wv[j][1] = wp[r * P + c1];
+        }
+        if (has_gl) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = min(wave + HW_WAVES * j, P - 1);
+                glv[j][0] = glp[r * P + c0];
+                glv[j][1] = glp[r * P + c1];
+            }
+        }
+        if (has_gc) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = min(wave + HW_WAVES * j, P - 1);
+                gcv[j][0] = gcp[r * P + c0];
+                gcv[j][1] = gcp[r * P + c1];
+            }
+        }
+        load_codes(0);
     }
     if (tid < 2 * TP) nrm[tid] = prm.nrm[(size_t)(tid < TP ? sA : sB) * TP + (tid & (TP - 1))];
-    // ---- G (rows r = wave + HW_WAVES j, columns 2 lane, 2 lane + 1) -> fp16 hi / lo, row-major
+    // ---- G (rows r = wave + HW_WAVES j, columns 2 lane, 2 lane + 1) in registers; its largest entry picks the tile's scale
+    float gmax = 0.f;
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int r = wave + HW_WAVES * j;
-        float x[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // the forward left the clamp pass-mask 1[cmin <= cd <= cmax] in the mantissa LSB of w
             const unsigned wb = __builtin_bit_cast(unsigned, wv[j][h]);
             const float w = __builtin_bit_cast(float, wb & ~1u);
-            const float g = (wb & 1u) ? -(w + om) * gls : 0.f;
-            x[h] = (r < P && 2 * lane + h < P) ? g : 0.f;
+            float g = (wb & 1u) ? -(w + om) * (has_gl ? glv[j][h] : gl_b) : 0.f;
+            if (has_gc) g += gcv[j][h];
+            g = (r < P && 2 * lane + h < P) ? g : 0.f;
+            wv[j][h] = g;
+            gmax = fmaxf(gmax, fabsf(g));
         }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
+    if (lane == 0) red[wave] = gmax;
+    __syncthreads();
+    float tmax = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < HW_WAVES; ++w2) tmax = fmaxf(tmax, red[w2]);
+    // one power of two per tile brings the largest |g| into [0.5, 1): fp16 hi + lo then resolve 2^-25 of it absolutely
+    float sc_tile = 1.f, inv_tile = 1.f;
+    if (tmax > 0.f && tmax < 3.0e38f) {
+        const int e = __builtin_amdgcn_frexp_expf(tmax);
+        sc_tile = __builtin_ldexpf(1.f, -e);
+        inv_tile = __builtin_ldexpf(1.f, e);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int r = wave + HW_WAVES * j;
         unsigned hi, lo;
-        split_f16_pair(x[0], x[1], hi, lo);
+        split_f16_pair(wv[j][0] * sc_tile, wv[j][1] * sc_tile, hi, lo);
         *reinterpret_cast<unsigned*>(Gh + r * HB_LDR + 2 * lane) = hi;
         *reinterpret_cast<unsigned*>(Gl + r * HB_LDR + 2 * lane) = lo;
     }
-    // ---- the code operands: [point][channel] fp32 rows -> [channel][point] fp16 hi / lo images (two points per store)
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        if (side == 1 && sameAB) break;
-        half_t* dh = CT + (size_t)(2 * side) * CTR * HB_LDR;
-        half_t* dl = dh + CTR * HB_LDR;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * HW_THREADS;
-            if (i < (TP / 2) * c4n) {
-                const int pp = i / c4n, c4 = i - pp * c4n;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ch = 4 * c4 + e;
-                    unsigned h, l;
-                    split_f16_pair(ch < K ? r0[side][it][e] : 0.f, ch < K ? r1[side][it][e] : 0.f, h, l);
-                    *reinterpret_cast<unsigned*>(dh + ch * HB_LDR + 2 * pp) = h;
-                    *reinterpret_cast<unsigned*>(dl + ch * HB_LDR + 2 * pp) = l;
-                }
-            }
-        }
-    }
-    __syncthreads();                                  // CT, G
-    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
 
     // lane map of v_mfma_f32_16x16x16_f16: A[i = lane & 15][k = 4 (lane >> 4) + 0..3], B[k = 4 (lane >> 4) + 0..3][j = lane & 15]
     const int cl = lane & 15, kq = lane >> 4;
@@ -424,87 +475,91 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     half_t* BTh = sameAB ? ATh : CT + 2 * CTR * HB_LDR;
     half_t* BTl = sameAB ? ATl : CT + 3 * CTR * HB_LDR;
     float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
-    const bool skip = (prm.debug & 1) || gl == 0.f;   // (no upstream: G = 0, the gradients are zero)
+    const bool skip = (prm.debug & 1) || tmax == 0.f; // (no upstream: G = 0, the gradients are zero)
 
-    // ---- dAn^T = Bn^T . G^T: channel rows of CT(B) (A operand) against the ROWS 32 wave + 16 np + j of G (B operand:
-    // B[k][j] = G[j][k], k-contiguous in a row-major G).  Result channel-major like dBn^T below.
-    f32x4 dAt[NT][HW_NP];
+    f32x4 dAt[NT][HW_NP], dBt[NT][HW_NP];
 #pragma unroll
     for (int mc = 0; mc < NT; ++mc)
 #pragma unroll
-        for (int np = 0; np < HW_NP; ++np) dAt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!skip) {
-        const int ra = cl * HB_LDR + 4 * kq;
-        const int rg = (16 * HW_NP * wave + cl) * HB_LDR + 4 * kq;
-#pragma unroll 2
-        for (int kk = 0; kk < TP; kk += 16) {
-            f16x4 ah[NT], al[NT], bh[HW_NP], bl[HW_NP];
+        for (int np = 0; np < HW_NP; ++np) { dAt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f}; dBt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
 #pragma unroll
-            for (int mc = 0; mc < NT; ++mc) {
-                ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + kk);
-                al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + kk);
-            }
-#pragma unroll
-            for (int np = 0; np < HW_NP; ++np) {
-                bh[np] = *reinterpret_cast<const f16x4*>(Gh + rg + 16 * np * HB_LDR + kk);
-                bl[np] = *reinterpret_cast<const f16x4*>(Gl + rg + 16 * np * HB_LDR + kk);
-            }
-            // the three terms outermost: consecutive MFMAs never wait for each other's accumulator
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int mc = 0; mc < NT; ++mc)
-#pragma unroll
-                    for (int np = 0; np < HW_NP; ++np)
-                        dAt[mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np],
-                                                                            dAt[mc][np], 0, 0, 0);
+    for (int grp = 0; grp < NG; ++grp) {
+        if (grp > 0) {
+            __syncthreads();                          // everyone is done with the previous group's images
+            load_codes(grp);
         }
-#pragma unroll
-        for (int mc = 0; mc < NT; ++mc)
-#pragma unroll
-            for (int np = 0; np < HW_NP; ++np) dAt[mc][np] *= inv_tile;
-    }
-    if (!sameAB) normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
-
-    // ---- dBn^T = An^T . G: channel rows of CT(A) against the columns 32 wave + 16 np + j of G (k = anchor point)
-    f32x4 dBt[NT][HW_NP];
-#pragma unroll
-    for (int mc = 0; mc < NT; ++mc)
-#pragma unroll
-        for (int np = 0; np < HW_NP; ++np) dBt[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!skip) {
-        const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
-        const int gb = 4 * kq * HB_LDR + 16 * HW_NP * wave + cl;      // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl
+        convert_codes(grp);
+        __syncthreads();                              // CT of this group (and, the first time, G) complete
+        if (stamp_on && grp == 0) ts[1] = __builtin_amdgcn_s_memrealtime();
+        if (skip) continue;
+        // ---- dAn^T = Bn^T . G^T: channel rows of CT(B) (A operand) against the ROWS 16 (HW_NP wave + np) + j of G (B operand:
+        // B[k][j] = G[j][k], k-contiguous in a row-major G)
+        {
+            const int ra = cl * HB_LDR + 4 * kq;
+            const int rg = (16 * HW_NP * wave + cl) * HB_LDR + 4 * kq;
 #pragma unroll 2
-        for (int kk = 0; kk < TP; kk += 16) {
-            f16x4 ah[NT], al[NT], bh[HW_NP], bl[HW_NP];
+            for (int kk = 0; kk < TP; kk += 16) {
+                f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
-            for (int mc = 0; mc < NT; ++mc) {
-                ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + kk);
-                al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + kk);
-            }
-#pragma unroll
-            for (int np = 0; np < HW_NP; ++np)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bh[np][e] = Gh[gb + (kk + e) * HB_LDR + 16 * np];
-                    bl[np][e] = Gl[gb + (kk + e) * HB_LDR + 16 * np];
+                for (int mc = 0; mc < NTG; ++mc) {
+                    ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + kk);
+                    al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + kk);
                 }
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+                for (int np = 0; np < HW_NP; ++np) {
+                    bh[np] = *reinterpret_cast<const f16x4*>(Gh + rg + 16 * np * HB_LDR + kk);
+                    bl[np] = *reinterpret_cast<const f16x4*>(Gl + rg + 16 * np * HB_LDR + kk);
+                }
+                // the three terms outermost: consecutive MFMAs never wait for each other's accumulator
 #pragma unroll
-                for (int mc = 0; mc < NT; ++mc)
+                for (int term = 0; term < 3; ++term)
 #pragma unroll
-                    for (int np = 0; np < HW_NP; ++np)
-                        dBt[mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np],
-                                                                            dBt[mc][np], 0, 0, 0);
+                    for (int mc = 0; mc < NTG; ++mc)
+#pragma unroll
+                        for (int np = 0; np < HW_NP; ++np)
+                            if (grp * NTG + mc < NT)
+                                dAt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                                    term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dAt[grp * NTG + mc][np], 0, 0, 0);
+            }
         }
+        // ---- dBn^T = An^T . G: channel rows of CT(A) against the COLUMNS 16 (HW_NP wave + np) + j of G (k = anchor point),
+        // gathered as 4 x 2 bytes per lane and step
+        {
+            const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
+            const int gb = 4 * kq * HB_LDR + 16 * HW_NP * wave + cl;      // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl
+#pragma unroll 2
+            for (int kk = 0; kk < TP; kk += 16) {
+                f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
-        for (int mc = 0; mc < NT; ++mc)
+                for (int mc = 0; mc < NTG; ++mc) {
+                    ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + kk);
+                    al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + kk);
+                }
 #pragma unroll
-            for (int np = 0; np < HW_NP; ++np) dBt[mc][np] *= inv_tile;
+                for (int np = 0; np < HW_NP; ++np)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bh[np][e] = Gh[gb + (kk + e) * HB_LDR + 16 * np];
+                        bl[np][e] = Gl[gb + (kk + e) * HB_LDR + 16 * np];
+                    }
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int mc = 0; mc < NTG; ++mc)
+#pragma unroll
+                        for (int np = 0; np < HW_NP; ++np)
+                            if (grp * NTG + mc < NT)
+                                dBt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                                    term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dBt[grp * NTG + mc][np], 0, 0, 0);
+            }
+        }
     }
     if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+        for (int np = 0; np < HW_NP; ++np) { dAt[mc][np] *= inv_tile; dBt[mc][np] *= inv_tile; }
     if (sameAB) {
         // c1 is c2: both adjoints hit the same samples (same register layout: just add)
 #pragma unroll
@@ -513,6 +568,7 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
             for (int np = 0; np < HW_NP; ++np) dAt[mc][np] += dBt[mc][np];
         normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
     } else {
+        normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
         normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
     }
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
@@ -701,17 +757,18 @@ constexpr int UR_WAVES = 3;
 constexpr int UR_GROUP = 6;          // items scanned per step; a point hits a row at most once -> <= 6*128 entries
 constexpr int UR_CAP = UR_GROUP * TP;
 constexpr int UR_ITEMCAP = 96;       // a pass looks at 256 candidates; only heavy rows have > 1, split over 3 waves
-constexpr int UR_NT = 5;             // 16-channel tiles (K <= 72)
-constexpr int UR_EG = 9;             // groups of 4 entries per drain step (54 loads in flight per lane; 10 spills)
+// UR_NT (template): 16-channel tiles, 5 for K <= 80, 8 for K <= 128.  UR_EG: groups of 4 entries per drain step
+// (NT = 5: 9 groups = 54 loads in flight per lane; NT = 8: 5 groups = 45)
 
 __device__ __forceinline__ int lane_prefix(unsigned long long mask)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int MT>        // 16-pixel tiles per row: W <= 16 * MT
-__global__ void __launch_bounds__(UR_WAVES * 64, MT <= 2 ? 4 : 2) corr_unsample_row_kernel(const BwdParams prm)
+template <int MT, int UR_NT>        // 16-pixel tiles per row: W <= 16 * MT; 16-channel tiles: K <= 16 * UR_NT
+__global__ void __launch_bounds__(UR_WAVES * 64, (MT <= 2 && UR_NT <= 5) ? 4 : 2) corr_unsample_row_kernel(const BwdParams prm)
 {
+    constexpr int UR_EG = UR_NT <= 5 ? 9 : 5;
     constexpr int RED_BYTES = UR_WAVES * UR_NT * 64 * (int)sizeof(f32x4);          // reduction buffer, aliases the worklists
     constexpr int WL_BYTES = UR_WAVES * MT * UR_CAP * 4;      // one worklist per 16-pixel tile
     __shared__ __attribute__((aligned(16))) unsigned char wl_raw[RED_BYTES > WL_BYTES ? RED_BYTES : WL_BYTES];
@@ -952,10 +1009,11 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
     {
         const int cside = TP * prm.LDK * 4;
         const int nt = (prm.KQ + 15) / 16;
-        // split-fp16 GEMMs: the training case (scalar / broadcast upstreams on the losses, none on the cd tensors)
-        const bool split = prm.precision == PREC_F16X3 && prm.mode == 0 && !(prm.debug & 64) &&   // (debug 64: fp32 MFMA kernel)
-                           !prm.g_intra_cd && !prm.g_inter_cd && !prm.g_neg_cd && (!prm.g_neg_loss || prm.g_neg_loss_stride == 0);
-        const int lds = split ? SMH_CT + (4 * 16 * nt + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;
+        // forward() semantics: split-fp16 GEMMs in F16X3 mode, and - whatever the mode - for code dimensions above 80, whose
+        // fp32 operand images no longer fit LDS (the split kernel walks the channel tiles in two groups)
+        const bool split = prm.mode == 0 && !(prm.debug & 64) && (prm.precision == PREC_F16X3 || nt > 5);   // (debug 64: fp32 MFMA kernel)
+        const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
+        const int lds = split ? SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;
         const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
 #define STEGO_BWD_CASE(N)                                                                                         \
     case N: {                                                                                                     \
@@ -970,6 +1028,23 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         }                                                                                                         \
         break;                                                                                                    \
     }
+        if (nt > 5 && !split) return hipErrorInvalidValue;       // (helper() is limited to K <= 72 by check_desc)
+        if (nt > 5) {
+#define STEGO_BWD_WIDE(N)                                                                                         \
+    case N: {                                                                                                     \
+        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N>), lds);      \
+        if (ea != hipSuccess) return ea;                                                                          \
+        hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N>), grid, dim3(HW_THREADS), lds, stream, prm);                \
+        break;                                                                                                    \
+    }
+            switch (nt) {
+                STEGO_BWD_WIDE(6)
+                STEGO_BWD_WIDE(7)
+                default:
+                STEGO_BWD_WIDE(8)
+            }
+#undef STEGO_BWD_WIDE
+        } else
         switch (nt) {
             STEGO_BWD_CASE(1)
             STEGO_BWD_CASE(2)
@@ -986,8 +1061,14 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
     if (prm.W <= 64 && (size_t)prm.n_sets * prm.B * 2 * TP * prm.LDK < ((size_t)1 << 31) && !(prm.debug & 32)) {
         const int n_heavy = prm.mode == 1 ? 0 : prm.B * prm.H;
         const dim3 grid(n_heavy + (2 * prm.B * prm.H - n_heavy + UR_WAVES - 1) / UR_WAVES), block(UR_WAVES * 64);
-        if (prm.W <= 32) hipLaunchKernelGGL((corr_unsample_row_kernel<2>), grid, block, 0, stream, prm);
-        else hipLaunchKernelGGL((corr_unsample_row_kernel<4>), grid, block, 0, stream, prm);
+        const bool wide_k = prm.KQ > 80;
+        if (prm.W <= 32) {
+            if (wide_k) hipLaunchKernelGGL((corr_unsample_row_kernel<2, 8>), grid, block, 0, stream, prm);
+            else hipLaunchKernelGGL((corr_unsample_row_kernel<2, 5>), grid, block, 0, stream, prm);
+        } else {
+            if (wide_k) hipLaunchKernelGGL((corr_unsample_row_kernel<4, 8>), grid, block, 0, stream, prm);
+            else hipLaunchKernelGGL((corr_unsample_row_kernel<4, 5>), grid, block, 0, stream, prm);
+        }
         return hipGetLastError();
     }
     // ---- unsample kernel: bands of RT <= 8 rows (one per wave) with RT*W*K floats <= ~96 KB of LDS

@@ -153,10 +153,11 @@ __device__ int assign_tile(const FusedParams& prm, int me, int lane, const int (
 
 // ------------------------------------------------------------------------------------------ phase 1: anchor sets
 // Lane hl of a half-wave owns, of ONE sample point: feature channels 128 j + 4 hl .. + 3 (j < NJ) and code channels
-// 2 hl, 2 hl + 1 and 64 + hl.
+// 2 hl, 2 hl + 1, 64 + hl and 96 + hl (K <= 128).
 struct CodeTaps {
     f32x2 a[4];
     float b[4];
+    float c[4];
 };
 
 // index of point q = (h, w) in a coords image: it samples coords[w][h] (sample() permutes the grid, modules.py:288)
@@ -220,6 +221,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
     f32x4 t[G][NJ][4];
     CodeTaps ct[G];
     const int c1 = 64 + hl < prm.K ? 64 + hl : 0;
+    const int c2 = 96 + hl < prm.K ? 96 + hl : 0;
     const int c0 = 2 * hl < prm.K ? 2 * hl : 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -241,6 +243,8 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         ct[g].a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
         if (prm.K > 64) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
         else { ct[g].b[0] = ct[g].b[1] = ct[g].b[2] = ct[g].b[3] = 0.f; }
+        if (prm.K > 96) { ct[g].c[0] = cimg[oc.x + c2]; ct[g].c[1] = cimg[oc.y + c2]; ct[g].c[2] = cimg[oc.z + c2]; ct[g].c[3] = cimg[oc.w + c2]; }
+        else { ct[g].c[0] = ct[g].c[1] = ct[g].c[2] = ct[g].c[3] = 0.f; }
     }
     if (tsd) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -290,14 +294,17 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         f32x2 r0 = wg.x * ct[g].a[0] + wg.y * ct[g].a[1] + wg.z * ct[g].a[2] + wg.w * ct[g].a[3];
         float r1 = wg.x * ct[g].b[0] + wg.y * ct[g].b[1] + wg.z * ct[g].b[2] + wg.w * ct[g].b[3];
         if (2 * hl >= prm.K) r0 = f32x2{0.f, 0.f};
+        float r2 = wg.x * ct[g].c[0] + wg.y * ct[g].c[1] + wg.z * ct[g].c[2] + wg.w * ct[g].c[3];
         if (64 + hl >= prm.K) r1 = 0.f;
-        float cs2 = r0[0] * r0[0] + r0[1] * r0[1] + r1 * r1;
+        if (96 + hl >= prm.K) r2 = 0.f;
+        float cs2 = r0[0] * r0[0] + r0[1] * r0[1] + r1 * r1 + r2 * r2;
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) cs2 += __shfl_xor(cs2, m, 64);
         const float nr = valid ? sqrtf(cs2) : 0.f;
         const float cinv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
         r0 = r0 * cinv;
         r1 = r1 * cinv;
+        r2 = r2 * cinv;
         const int kall = prm.NKC * prm.kper;
         if (2 * hl < kall) {
             const int k = 2 * hl, sc = k / prm.kper, col = k - sc * prm.kper;
@@ -309,6 +316,11 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         }
         if (2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(lds_cx + lr * crow + 8 * hl) = r0;
         if (64 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (64 + hl)) = r1;
+        if (96 + hl < kall) {
+            const int k = 96 + hl, sc = k / prm.kper, col = k - sc * prm.kper;
+            *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r2;
+        }
+        if (96 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (96 + hl)) = r2;
         if (act[g] && hl == 0) prm.nrm[(size_t)ba[g] * TP + qq] = nr;
     }
 }
@@ -1103,7 +1115,7 @@ bool fused_supported(const FusedParams& prm, int precision)
     };
     if (!(prm.C == 384 || prm.C == 768)) return false;                         // NJ instantiations below
     if (!cl4(prm.feats) || !cl4(prm.feats_pos) || !cl2(prm.code) || !cl2(prm.code_pos)) return false;
-    if (prm.K % 2 != 0 || prm.K > 72) return false;
+    if (prm.K % 2 != 0 || prm.K > 128) return false;                            // four code K-chunks of <= 32 channels
     if (prm.H > 256 || prm.W > 256) return false;                             // packed tap coordinates (8 bits each)
     if ((long long)(prm.H - 1) * prm.code.sh + (long long)(prm.W - 1) * prm.code.sw + prm.K >= (1ll << 29)) return false;
     if ((long long)(prm.H - 1) * prm.code_pos.sh + (long long)(prm.W - 1) * prm.code_pos.sw + prm.K >= (1ll << 29)) return false;
@@ -1142,7 +1154,8 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     do {                                                                                               \
         if (prm.NKC == 1) STEGO_FUSED_LAUNCH(PR, N, 1);                                                \
         else if (prm.NKC == 2) STEGO_FUSED_LAUNCH(PR, N, 2);                                           \
-        else STEGO_FUSED_LAUNCH(PR, N, 3);                                                             \
+        else if (prm.NKC == 3) STEGO_FUSED_LAUNCH(PR, N, 3);                                           \
+        else STEGO_FUSED_LAUNCH(PR, N, 4);                                                             \
     } while (0)
     if (precision == PREC_F32) { if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3); else STEGO_FUSED_NK(PREC_F32, 6); }
     else { if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3); else STEGO_FUSED_NK(PREC_F16X3, 6); }

@@ -51,7 +51,7 @@ def load_config(path=None, overrides=()):
     return types.SimpleNamespace(**d)
 
 
-MAX_CODE_DIM = 72                # include/stego_corr.h "Limits of this build"
+MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: even, channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
 
 

@@ -586,3 +586,47 @@ def test_backward_wide_map_fallback_is_order_nondeterministic_but_bounded():
         assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
         assert float(np.abs(r["d_code"] - runs[0]["d_code"]).max()) <= 1e-6 * scale
         assert float(np.abs(r["d_code_pos"] - runs[0]["d_code_pos"]).max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("K", [96, 100, 128])
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_code_dimensions_above_72_forward_and_backward_against_fp64_oracle(K, precision):
+    """cfg.dim beyond the 70 the reference ships (train_config.yml:39; its ViT-B models use ~100): the fused forward walks four
+    code K-chunks, the backward tile kernel two groups of channel tiles, the unsample kernel 8 channel tiles.  Channels-last
+    ViT-width maps (what DinoFeaturizer emits); other layouts / widths keep the K <= 72 limit and say so."""
+    B, C, H, W, S, n_neg = 3, 384, 9, 10, 7, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=40 + K)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    la = 5e-4
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=la, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=la, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=la, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=la, what="neg_cd")
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) < 1e-3 * max(abs(float(ref.pos_intra_loss)), 1e-3)
+    numel = B * S ** 4
+    g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+    # a general (dense) upstream on every output goes through the same kernels
+    rng = np.random.default_rng(K)
+    ups = [rng.standard_normal(np.shape(o)).astype(np.float32) for o in r["out"]]
+
+    def upstream(out):
+        return sum((o * _dev(u)).sum() for o, u in zip(out, ups))
+    r2 = _run(inputs, d["perms"], cfg, layout="cl", precision=precision, upstream=upstream)
+    dc2, dcp2 = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=float(ups[0]), g_intra_cd=ups[1], g_inter=float(ups[2]),
+                                     g_inter_cd=ups[3], g_neg_loss=ups[4], g_neg_cd=ups[5])
+    assert_close(r2["d_code"], dc2, rtol=1e-3, atol_frac=1e-3, what="d_code (dense upstream)")
+    assert_close(r2["d_code_pos"], dcp2, rtol=1e-3, atol_frac=1e-3, what="d_code_pos (dense upstream)")
+
+
+def test_code_dimensions_above_72_need_the_fused_layout():
+    cfg = O.CorrCfg(feature_samples=3, neg_samples=1)
+    f = torch.randn(2, 16, 8, 8, device=DEV)                # not a ViT width: three-launch path, K <= 72 only
+    c = torch.randn(2, 96, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)

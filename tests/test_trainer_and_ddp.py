@@ -324,7 +324,7 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
 
 
 def test_unsupported_code_dim_and_sample_count_fail_at_construction_with_the_cfg_key_named():
-    for ov, key in ((["dim=96"], "cfg.dim=96"), (["feature_samples=12"], "cfg.feature_samples=12")):
+    for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=12"], "cfg.feature_samples=12")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.raises(ValueError, match=key):
             LitUnsupervisedSegmenter(5, cfg)
