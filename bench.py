@@ -463,7 +463,10 @@ def main():
             a = b = c = 0.0
             for i in range(args.sets):
                 d = sets[i]
-                k0, k1, k2 = capi.corr_fwd_profile(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"],
+                # the same host-side layout policy as the timed loop (a no-op for channels-last views): the kernels profiled
+                # are the kernels the timed steps ran
+                k0, k1, k2 = capi.corr_fwd_profile(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
+                                                   as_channels_last(d["code"]), as_channels_last(d["code_pos"]),
                                                    d["coords1"], d["coords2"], d["perms"], not args.fwd_only, 1)
                 a += k0
                 b += k1
@@ -485,7 +488,8 @@ def main():
             except Exception:       # noqa: BLE001
                 traffic = None
         d0 = sets[0]
-        fused = capi.corr_fwd_launches(desc, d0["feats"], d0["feats_pos"], d0["code"], d0["code_pos"]) == 1
+        fused = capi.corr_fwd_launches(desc, as_channels_last(d0["feats"]), as_channels_last(d0["feats_pos"]),
+                                       as_channels_last(d0["code"]), as_channels_last(d0["code_pos"])) == 1
         peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_F16_PEAK / 3.0
         if fused:
             # ONE launch does the whole forward (every distinct tensor of SURVEY.md 8(d) once): its duration prices all

@@ -24,8 +24,8 @@ def main():
     out = {"workload": wl, "fwd": [], "bwd": []}
 
     def fwd_time(prec, variant, debug):
-        os.environ["STEGO_FWD_VARIANT"] = str(variant)
-        os.environ["STEGO_DEBUG"] = str(debug)
+        capi.debug_set("STEGO_FWD_VARIANT", int(variant))
+        capi.debug_set("STEGO_DEBUG", int(debug))
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
         ts = tm = tf = 0.0
         n = 0
@@ -53,8 +53,8 @@ def main():
                     rec = dict(prec=pname, variant=variant, ablation=dname, error=str(e))
                 out["fwd"].append(rec)
                 print(rec, flush=True)
-    os.environ["STEGO_DEBUG"] = "0"
-    os.environ["STEGO_FWD_VARIANT"] = "1"
+    capi.debug_set("STEGO_DEBUG", 0)
+    capi.debug_set("STEGO_FWD_VARIANT", 1)
 
     # backward
     desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F32)
@@ -66,7 +66,7 @@ def main():
         fw.append(capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"],
                                 d["perms"], True))
     for debug, dname in ((0, "full"), (1, "no-mfma"), (2, "no-scatter"), (4, "no-gfill-loads"), (7, "gather+norm only")):
-        os.environ["STEGO_DEBUG_BWD"] = str(debug)
+        capi.debug_set("STEGO_DEBUG_BWD", int(debug))
         ts = []
         for r in range(4):
             for d, o in zip(sets, fw):
@@ -82,7 +82,7 @@ def main():
         rec = dict(ablation=dname, bwd_call_us=round(sum(ts) / len(ts), 2), note="2 memsets + kernel")
         out["bwd"].append(rec)
         print(rec, flush=True)
-    os.environ["STEGO_DEBUG_BWD"] = "0"
+    capi.debug_set("STEGO_DEBUG_BWD", 0)
     print(json.dumps(out))
 
 

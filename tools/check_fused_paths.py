@@ -3,7 +3,7 @@
 paths (debug 32 = repair kernel applies old_mean, 64 = every tile samples its anchor itself), kernel times."""
 import os, sys, json
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from stego_amd import capi

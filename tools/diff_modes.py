@@ -11,7 +11,7 @@ dev = "cuda:0"
 def cl(t): return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
 res = {}; cds = {}
 for prec in ("f32", "f16x3", "f16x3"):
-    os.environ["STEGO_DEBUG"] = os.environ.get("DBG", "0") if prec == "f16x3" else "0"
+    capi.debug_set("STEGO_DEBUG", int(os.environ.get("DBG", "0") if prec == "f16x3" else "0"))
     c = copy.copy(cfg); c.corr_precision = prec
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items()}
     out = M.ContrastiveCorrelationLoss(c).forward_explicit(cl(t["feats"]), cl(t["feats_pos"]), cl(t["code"]), cl(t["code_pos"]),

@@ -2,7 +2,7 @@
 """Race forensics: for a bad column q of a bad tile, find which 32-channel stage of the B operand was wrong and what it was replaced by."""
 import os, sys, json
 import torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from stego_amd import capi

@@ -18,7 +18,7 @@ lib = capi.load()
 nt = (2 + n_neg) * B
 for prec in (capi.PREC_F32, capi.PREC_BF16X3):
     for dbg in [int(x) for x in (sys.argv[1:] or ["256"])]:
-        os.environ["STEGO_DEBUG"] = str(dbg)
+        capi.debug_set("STEGO_DEBUG", int(dbg))
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
         f32 = dict(dtype=torch.float32, device=dev)
         outs = [torch.empty(2, **f32), torch.empty(B, S**4, **f32), torch.empty(B, S**4, **f32),
@@ -42,4 +42,4 @@ for prec in (capi.PREC_F32, capi.PREC_BF16X3):
         print("prec=%d debug=%d" % (prec, dbg))
         for k, n in enumerate(names):
             print("   %-13s p0/p50/p100 %.2f %.2f %.2f us" % ((n,) + tuple(np.percentile(rel[:, k], [0, 50, 100]))))
-        os.environ["STEGO_DEBUG"] = "0"
+        capi.debug_set("STEGO_DEBUG", 0)
