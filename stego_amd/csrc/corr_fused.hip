@@ -1000,9 +1000,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             }
             const int e0 = f0 - a;
             if (vec_ok && ok[0] && ok[3]) {
-                *reinterpret_cast<f32x4*>(cd_out + e0) = cd4;
-                if (loss_out) *reinterpret_cast<f32x4*>(loss_out + e0) = lo4;
-                if (w_out) *reinterpret_cast<f32x4*>(w_out + e0) = w4;
+                // streaming stores: nobody in this launch reads the outputs again, and lines that never become dirty in the
+                // L2s do not have to be written back when the kernel ends
+                __builtin_nontemporal_store(cd4, reinterpret_cast<f32x4*>(cd_out + e0));
+                if (loss_out) __builtin_nontemporal_store(lo4, reinterpret_cast<f32x4*>(loss_out + e0));
+                if (w_out) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(w_out + e0));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)

@@ -630,3 +630,45 @@ def test_code_dimensions_above_72_need_the_fused_layout():
     c = torch.randn(2, 96, 8, 8, device=DEV)
     with pytest.raises(RuntimeError, match="unsupported"):
         M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+
+
+def test_unprepared_entry_point_accepts_any_workspace_and_prepared_one_stays_clean():
+    """stego_corr_fwd() zeroes the in-launch hand-off words itself: a workspace full of 0xFF bytes gives the same outputs as the
+    prepared path (stego_corr_workspace_prepare once + stego_corr_fwd_prepared), bit for bit; and every launch leaves the words
+    zero again, so the prepared workspace serves call after call."""
+    import ctypes
+    import bench
+    dev = torch.device(DEV)
+    C, H, W, K = bench.WORKLOADS["vits8_224"]
+    B, S, n_neg = 8, 11, 5
+    cfg = bench.Cfg()
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 77, dev)
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+    lib = capi.load()
+    by = ctypes.byref
+    assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
+    nws = lib.stego_corr_workspace_bytes(by(desc))
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def outs():
+        return [torch.empty(2, **f32), torch.empty(B, S ** 4, **f32), torch.empty(B, S ** 4, **f32), torch.empty(n_neg * B, S ** 4, **f32),
+                torch.empty(n_neg * B, S ** 4, **f32), torch.empty(7 * B, S ** 4, **f32), torch.empty(7, **f32),
+                torch.empty(lib.stego_corr_saved_ctx_bytes(by(desc)), dtype=torch.uint8, device=dev)]
+    maps = [capi._map(d[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(fn, ws, o):
+        rc = fn(by(desc), *[by(m) for m in maps], d["coords1"].data_ptr(), d["coords2"].data_ptr(), d["perms"].data_ptr(),
+                *[t.data_ptr() for t in o], ws.data_ptr(), ws.numel(), stream)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    dirty = torch.full((nws,), 255, dtype=torch.uint8, device=dev)
+    o1 = outs()
+    call(lib.stego_corr_fwd, dirty, o1)
+    clean = torch.full((nws,), 255, dtype=torch.uint8, device=dev)
+    assert lib.stego_corr_workspace_prepare(by(desc), clean.data_ptr(), clean.numel(), stream) == 0
+    for rep in range(3):                                   # the same prepared workspace, call after call
+        o2 = outs()
+        call(lib.stego_corr_fwd_prepared, clean, o2)
+        for a, b in zip(o1[:7], o2[:7]):
+            assert torch.equal(a, b)
