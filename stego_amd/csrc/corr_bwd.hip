@@ -246,9 +246,9 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
 //   dAn^T = Bn^T . G^T    A operand = rows of CT(B), B operand = rows of G (k = column: 8-byte reads)
 //   dBn^T = An^T . G      A operand = rows of CT(A) (k = anchor point), B operand = COLUMNS of G, gathered as 4 x 2 bytes
 //                         per lane and step (a transposed copy of G does not fit next to CT: 157 KB are in use)
-// Scale: G's entries are ~1e-7 (upstream 1 / (B P^2)).  The tile's largest |g| (exact: every lane holds its 32 entries in
-// registers, one wave reduction + 8 partials through LDS) picks one power of two that brings it into [0.5, 1); fp16 hi + lo
-// then resolve 2^-25 of that absolutely - fp32 accuracy relative to the largest entries, which is what a 128-term sum needs.
+// Scale: G's entries are ~1e-7 (upstream 1 / (B P^2)).  One power of two per tile brings the largest |g| (scalar upstreams: the
+// bound 4 |gl|; tensor upstreams, DENSE: the exact maximum, one wave reduction + 8 partials through LDS) into [0.5, 1); fp16
+// hi + lo then resolve 2^-25 of that absolutely - fp32 accuracy relative to the largest entries, which is what a 128-term sum needs.
 // Channel tiles beyond 5 (K > 80) are processed in two groups that share the G image.
 constexpr int HB_LDR = 136;                           // halves per row of an operand image (272 B: conflict-free 8-byte reads)
 constexpr int SMH_NRM = 0;                            // float nrm[2][128], red[8]
@@ -304,7 +304,7 @@ __device__ __forceinline__ void normalize_bwd_store_t(f32x4 (&d)[NT][HW_NP], con
     }
 }
 
-template <int NT>
+template <int NT, bool DENSE>      // DENSE: some upstream gradient is a tensor (not the training case)
 __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -344,14 +344,14 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     float gl_b = 0.f;                                 // broadcast / scalar upstream of the loss
     if (p >= 2) {
         if (prm.g_neg_loss) {
-            if (prm.g_neg_loss_stride != 0) { glp = prm.g_neg_loss + t0; has_gl = true; }
+            if (DENSE && prm.g_neg_loss_stride != 0) { glp = prm.g_neg_loss + t0; has_gl = true; }
             else gl_b = prm.g_neg_loss[0];
         }
     } else {
         const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
         if (gs) gl_b = gs[0] * (1.f / ((float)B * (float)P2));
     }
-    const float* gcd = p == 0 ? prm.g_intra_cd : (p == 1 ? prm.g_inter_cd : prm.g_neg_cd);
+    const float* gcd = !DENSE ? nullptr : (p == 0 ? prm.g_intra_cd : (p == 1 ? prm.g_inter_cd : prm.g_neg_cd));
     const bool has_gc = gcd != nullptr;
     const float* gcp = has_gc ? gcd + t0 : wp;
     const float om = prm.saved_mean[p];
@@ -445,13 +445,21 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
             gmax = fmaxf(gmax, fabsf(g));
         }
     }
+    float tmax;
+    if constexpr (DENSE) {
+        // the exact largest |g| of the tile: one wave reduction + 8 partials through LDS
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
-    if (lane == 0) red[wave] = gmax;
-    __syncthreads();
-    float tmax = 0.f;
+        for (int m = 32; m >= 1; m >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
+        if (lane == 0) red[wave] = gmax;
+        __syncthreads();
+        tmax = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < HW_WAVES; ++w2) tmax = fmaxf(tmax, red[w2]);
+        for (int w2 = 0; w2 < HW_WAVES; ++w2) tmax = fmaxf(tmax, red[w2]);
+    } else {
+        // scalar upstream: |g| = |gl| |w + old_mean| < 4 |gl| (w = a cosine - a row mean - a shift): a bound is as good as the
+        // maximum here (it only has to keep |g| s below fp16's range and within a few bits of 1), and costs no barrier
+        tmax = 4.f * fabsf(gl_b);
+    }
     // one power of two per tile brings the largest |g| into [0.5, 1): fp16 hi + lo then resolve 2^-25 of it absolutely
     float sc_tile = 1.f, inv_tile = 1.f;
     if (tmax > 0.f && tmax < 3.0e38f) {
@@ -970,7 +978,7 @@ __global__ void __launch_bounds__(UR_WAVES * 64, (MT <= 2 && UR_NT <= 5) ? 4 : 2
 #pragma unroll
                 for (int nt = 0; nt < UR_NT; ++nt) {
                     const int ch = 16 * nt + l16;
-                    if (x < W && ch < K) out[(size_t)x * K + ch] = acc[mt][nt][reg];
+                    if (x < W && ch < K) __builtin_nontemporal_store(acc[mt][nt][reg], out + (size_t)x * K + ch);
                 }
             }
         return;
@@ -995,7 +1003,7 @@ __global__ void __launch_bounds__(UR_WAVES * 64, (MT <= 2 && UR_NT <= 5) ? 4 : 2
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int x = 16 * mt + 4 * k4 + reg;
-                    if (x < W && ch < K) out[(size_t)x * K + ch] = v[reg];
+                    if (x < W && ch < K) __builtin_nontemporal_store(v[reg], out + (size_t)x * K + ch);
                 }
             }
         }
@@ -1013,14 +1021,19 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         // fp32 operand images no longer fit LDS (the split kernel walks the channel tiles in two groups)
         const bool split = prm.mode == 0 && !(prm.debug & 64) && (prm.precision == PREC_F16X3 || nt > 5);   // (debug 64: fp32 MFMA kernel)
         const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
+        const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride != 0);
         const int lds = split ? SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;
         const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
 #define STEGO_BWD_CASE(N)                                                                                         \
     case N: {                                                                                                     \
-        if (split) {                                                                                              \
-            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N>), lds);  \
+        if (split && dense) {                                                                                     \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N, true>), lds);   \
             if (ea != hipSuccess) return ea;                                                                      \
-            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N>), grid, dim3(HW_THREADS), lds, stream, prm);            \
+            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N, true>), grid, dim3(HW_THREADS), lds, stream, prm);      \
+        } else if (split) {                                                                                       \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N, false>), lds);  \
+            if (ea != hipSuccess) return ea;                                                                      \
+            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N, false>), grid, dim3(HW_THREADS), lds, stream, prm);     \
         } else {                                                                                                  \
             hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_kernel<N>), lds);    \
             if (ea != hipSuccess) return ea;                                                                      \
@@ -1032,9 +1045,15 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         if (nt > 5) {
 #define STEGO_BWD_WIDE(N)                                                                                         \
     case N: {                                                                                                     \
-        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N>), lds);      \
-        if (ea != hipSuccess) return ea;                                                                          \
-        hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N>), grid, dim3(HW_THREADS), lds, stream, prm);                \
+        if (dense) {                                                                                              \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N, true>), lds);   \
+            if (ea != hipSuccess) return ea;                                                                      \
+            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N, true>), grid, dim3(HW_THREADS), lds, stream, prm);      \
+        } else {                                                                                                  \
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_h_kernel<N, false>), lds);  \
+            if (ea != hipSuccess) return ea;                                                                      \
+            hipLaunchKernelGGL((corr_bwd_tile_h_kernel<N, false>), grid, dim3(HW_THREADS), lds, stream, prm);     \
+        }                                                                                                         \
         break;                                                                                                    \
     }
             switch (nt) {
