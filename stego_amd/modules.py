@@ -34,12 +34,48 @@ def average_norm(t):
     return t / t.square().sum(1, keepdim=True).sqrt().mean()
 
 
+class _DenseCorrFunction(torch.autograd.Function):
+    """tensor_correlation with gradients, all three contractions on the native dense-correspondence kernel:
+        out[n,h,w,i,j] = sum_c a[n,c,h,w] b[n,c,i,j]
+        dA[n,c,h,w]    = sum_ij g[n,h,w,i,j] b[n,c,i,j]   = tensor_correlation(g seen as a map with channels (i,j), b^T)
+        dB[n,c,i,j]    = sum_hw g[n,h,w,i,j] a[n,c,h,w]   = tensor_correlation(g seen as a map with channels (h,w), a^T)
+    The adjoints are the same kernel on strided VIEWS (StegoMap carries element strides): nothing is transposed in memory."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        ctx.set_materialize_grads(False)
+        return capi.dense_corr(a.detach(), b.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        if g is None:
+            return None, None
+        a, b = a.detach(), b.detach()
+        N, C, H1, W1 = a.shape
+        H2, W2 = b.shape[2:]
+        g = g.contiguous().view(N, H1 * W1, H2 * W2)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            gq = g.permute(0, 2, 1).unflatten(2, (H1, W1))             # [N, (i,j), H1, W1]: "channels" = positions of b
+            bt = b.flatten(2).permute(0, 2, 1).unsqueeze(-1)           # [N, (i,j), C, 1]
+            da = capi.dense_corr(gq, bt).squeeze(-1).permute(0, 3, 1, 2)        # [N, H1, W1, C, 1] -> [N, C, H1, W1]
+        if ctx.needs_input_grad[1]:
+            gp = g.unflatten(2, (H2, W2))                              # [N, (h,w), H2, W2]: "channels" = positions of a
+            at = a.flatten(2).permute(0, 2, 1).unsqueeze(-1)           # [N, (h,w), C, 1]
+            db = capi.dense_corr(gp, at).squeeze(-1).permute(0, 3, 1, 2)        # [N, H2, W2, C, 1] -> [N, C, H2, W2]
+        return da, db
+
+
 def tensor_correlation(a, b):
-    """reference modules.py:283-284.  Inference-time calls on HIP tensors (the plotting / PR-curve scripts) run on the
-    native dense-correspondence kernel (stego_dense_corr); anything that needs autograd, or lives on the CPU, is the
-    reference's einsum (this helper is not on the training hot path: the fused loss has its own contraction)."""
-    if (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and
-            not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad))):
+    """reference modules.py:283-284.  float32 4-D maps on a HIP device run on the native dense-correspondence kernel
+    (stego_dense_corr), with gradients (both adjoints are the same kernel on strided views: _DenseCorrFunction); anything
+    else (CPU tensors - the reference's own path for tests / plotting - or other dtypes) is the reference's einsum.  This
+    helper is not on the training hot path: the fused loss has its own contraction."""
+    if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and b.dim() == 4:
+        if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+            return _DenseCorrFunction.apply(a, b)
         return capi.dense_corr(a, b)
     return torch.einsum("nchw,ncij->nhwij", a, b)
 

@@ -69,3 +69,27 @@ def test_dense_corr_raw_products_any_magnitude(scale):
     out = capi.dense_corr(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
     ref = _ref(a, b, False)
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 7, 9, 5, 6), (3, 384, 28, 28, 28, 28), (1, 70, 11, 11, 20, 20)])
+def test_tensor_correlation_gradients_run_on_the_native_kernel(shape):
+    """modules.tensor_correlation with autograd (reference modules.py:283-284: the einsum is differentiable there): both
+    adjoints are the dense-correspondence kernel on strided views; compared with autograd through the reference's einsum."""
+    import torch
+    from stego_amd import modules as M
+    N, C, H1, W1, H2, W2 = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(N, C, H1, W1, device="cuda", generator=g)
+    b = torch.randn(N, H2, W2, C, device="cuda", generator=g).permute(0, 3, 1, 2)       # a channels-last view, as DINO emits
+    up = torch.randn(N, H1, W1, H2, W2, device="cuda", generator=g)
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = M.tensor_correlation(a1, b1)
+    assert out.grad_fn is not None and "DenseCorr" in type(out.grad_fn).__name__
+    (out * up).sum().backward()
+    a2, b2 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.einsum("nchw,ncij->nhwij", a2, b2)
+    (ref * up.double()).sum().backward()
+    for got, want in ((out, ref), (a1.grad, a2.grad), (b1.grad, b2.grad)):
+        err = (got.double() - want).abs().max() / want.abs().max()
+        assert float(err) < 2e-6, float(err)
