@@ -61,9 +61,11 @@ class LitUnsupervisedSegmenter(nn.Module):
         self.cfg = cfg
         self.n_classes = n_classes
         dim = cfg.dim if cfg.continuous else n_classes
-        if cfg.arch == "feature-pyramid":
-            raise ValueError("arch 'feature-pyramid' needs a torchvision ResNet trunk: build FeaturePyramidNet("
-                             "granularity, cut_model, dim, continuous) yourself and assign it to .net")
+        if cfg.arch == "feature-pyramid":           # train_segmentation.py:65-67
+            from .trunks import load_model
+            data_dir = os.path.join(getattr(cfg, "output_root", "."), "data")
+            cut_model = load_model(cfg.model_type, data_dir, allow_random_init=getattr(cfg, "allow_random_trunk", False))
+            self.net = FeaturePyramidNet(cfg.granularity, cut_model, dim, cfg.continuous)
         elif cfg.arch == "dino":
             self.net = DinoFeaturizer(dim, cfg)
         else:

@@ -328,3 +328,21 @@ def test_unsupported_code_dim_and_sample_count_fail_at_construction_with_the_cfg
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.raises(ValueError, match=key):
             LitUnsupervisedSegmenter(5, cfg)
+
+
+def test_feature_pyramid_arch_builds_through_the_segmenter():
+    """cfg.arch == 'feature-pyramid' (train_segmentation.py:65-67): load_model's ResNet-50 trunk (torchvision-compatible
+    parameter names; random init when allowed, FileNotFoundError naming the checkpoint otherwise) cut by FeaturePyramidNet."""
+    from stego_amd import trunks
+    ov = ["arch=feature-pyramid", "model_type=resnet50", "granularity=2", "dim=16", "res=64", "allow_random_trunk=True"]
+    m = LitUnsupervisedSegmenter(5, load_config(overrides=ov)).cpu().eval()
+    with torch.no_grad():
+        feats, code = m.net(torch.randn(2, 3, 224, 224))
+    assert feats.shape == (2, 2048, 7, 7) and code.shape == (2, 16, 56, 56)
+    keys = trunks.ResNet50().state_dict().keys()
+    assert "layer3.5.conv3.weight" in keys and "layer1.0.downsample.1.running_var" in keys and "fc.bias" in keys
+    assert sum(p.numel() for p in trunks.ResNet50().parameters()) == 25557032          # torchvision's resnet50
+    with pytest.raises(FileNotFoundError, match="resnet50-0676ba61.pth"):
+        LitUnsupervisedSegmenter(5, load_config(overrides=ov[:-1]))
+    with pytest.raises(ValueError, match="No model"):
+        trunks.load_model("vgg11", ".")
