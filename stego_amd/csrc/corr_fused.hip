@@ -524,14 +524,47 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     // ---- phase 1 (all waves): my share of the anchor sets of my XCD, 2 points per wave and pass
     constexpr int G1 = 1;
     constexpr int P1ROWS = FUSED_WAVES * 2 * G1;
-    if (me < prm.n_owner && !(prm.debug & 64)) {     // (debug 64: nobody samples, every tile takes the give-up path)
+    // Which tile am I: the LAST wave works it out (ballots over perms, ~1.3 us) while the others sample - with ~18 anchor rows
+    // per workgroup and two rows per wave it has none of its own - and leaves it in LDS behind phase 1's barriers.
+    float* tile_slot = red + 56;
+    const bool p1_here = me < prm.n_owner && !(prm.debug & 64);
+    if (p1_here && wave8 == FUSED_WAVES - 1) {
+        const int t = assign_tile(prm, me, lane, pref0);
+        if (lane == 0) tile_slot[0] = __builtin_bit_cast(float, t);
+        // ... and the tap table of the tile's B points (two per lane) for the whole gather team: its coordinate round trip is
+        // off the team's critical path (the first four B stages, which the MFMA team waits for)
+        const int tb = t % B, tp = t / B;
+        if (tp != 0) {
+            const MapV mf = tp == 1 ? prm.feats_pos : prm.feats;
+            const int tsB = tp * B + tb;
+            f32x2 cxy[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                cxy[h] = *reinterpret_cast<const f32x2*>(prm.coords2 + (size_t)tb * P * 2 + coord_index(prm, lane + 64 * h));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = lane + 64 * h;
+                int4 yx;
+                float4 w;
+                point_taps(prm, cxy[h], q, yx, w);
+                tapof[q] = taps_to_offsets(yx, mf.sh, mf.sw);
+                tapoc[q] = yx;                                      // (y << 16 | x) of the four taps: code offsets are rebuilt from it
+                tapw[q] = w;
+                prm.tapyx[(size_t)tsB * TP + q] = yx;               // saved context of the backward
+                prm.tapw[(size_t)tsB * TP + q] = w;
+            }
+        }
+    }
+    if (p1_here) {     // (debug 64: nobody samples, every tile takes the give-up path)
         const int x = me & 7, r = me >> 3;
         const int nb = x < B ? (B - x + 7) >> 3 : 0;
         const int nslot = (prm.n_owner - x + 7) >> 3;
         const long long L = (long long)nb * TP;
         const int beg = (int)(L * r / nslot), end = (int)(L * (r + 1) / nslot);
+        if (beg >= end) __syncthreads();             // (no rows here: still publish the last wave's tile to the others)
         for (int blk0 = beg; blk0 < end; blk0 += P1ROWS) {
-            p1_sample_rows<NJ, PREC, G1>(prm, x, blk0, end, 2 * G1 * wave8, P1ROWS, lane, ring, stamp_on ? ts + 8 : nullptr);
+            if (blk0 + 2 * G1 * wave8 < end)         // (a wave without rows in this pass goes straight to the barrier)
+                p1_sample_rows<NJ, PREC, G1>(prm, x, blk0, end, 2 * G1 * wave8, P1ROWS, lane, ring, stamp_on ? ts + 8 : nullptr);
             __syncthreads();
             const int nrows = min(P1ROWS, end - blk0);
             // a run must stay inside one anchor: split the pass at an anchor boundary
@@ -547,8 +580,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     }
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
 
-    // ---- which tile am I (every wave for itself: no barrier before the teams part ways)
-    const int tile = assign_tile(prm, me, lane, pref0);
+    // ---- which tile am I
+    int tile;
+    if (p1_here) tile = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tile_slot[0]));
+    else tile = assign_tile(prm, me, lane, pref0);       // (every wave for itself: no barrier before the teams part ways)
     if (stamp_on) ts[6] = __builtin_amdgcn_s_memrealtime();
     const int b = tile % B, p = tile / B;
     const bool sameAB = p == 0;
@@ -659,7 +694,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         float ss[GI], bsc[GI], ssc[GI];
 #pragma unroll
         for (int j = 0; j < GI; ++j) { ss[j] = 0.f; bsc[j] = 0.f; ssc[j] = 0.f; }
-        if (lane < 8 * GI) {
+        if (!p1_here && lane < 8 * GI) {
+            // (only without phase 1 here: otherwise the last wave built the whole table before phase 1's barriers)
             // tap table of the B points: every wave computes the 8 GI entries it reads itself (no barrier needed)
             const int q = GP * (lane >> 3) + 8 * gwave + (lane & 7);
             const f32x2 cxy = *reinterpret_cast<const f32x2*>(coordsB + coord_index(prm, q));
