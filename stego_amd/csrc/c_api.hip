@@ -351,7 +351,7 @@ int stego_corr_fwd_launches(const StegoCorrDesc* d, const StegoMap* feats, const
     if ((rc = to_mapv(feats, d->C, d->H, d->W, &fp.feats)) || (rc = to_mapv(feats_pos, d->C, d->H, d->W, &fp.feats_pos)) ||
         (rc = to_mapv(code, d->K, d->H, d->W, &fp.code)) || (rc = to_mapv(code_pos, d->K, d->H, d->W, &fp.code_pos)))
         return -rc;
-    fp.B = d->B; fp.C = d->C; fp.K = d->K; fp.H = d->H; fp.W = d->W; fp.S = d->S; fp.P = d->S * d->S;
+    fp.B = d->B; fp.C = d->C; fp.K = d->K; fp.H = d->H; fp.W = d->W; fp.S = d->S; fp.P = d->S * d->S; fp.n_neg = d->n_neg;
     const bool fused = knob(KNOB_FWD_VARIANT) != 1 && g.fs_bytes < ((size_t)1 << 31) && g.cs_bytes < ((size_t)1 << 31) &&
                        fused_supported(fp, d->precision);
     return fused ? 1 : 3;

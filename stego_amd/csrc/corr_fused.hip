@@ -1152,6 +1152,10 @@ bool fused_supported(const FusedParams& prm, int precision)
         return m.sc == 1 && (m.sn % 2) == 0 && (m.sh % 2) == 0 && (m.sw % 2) == 0 && (reinterpret_cast<uintptr_t>(m.p) % 8) == 0;
     };
     if (!(prm.C == 384 || prm.C == 768)) return false;                         // NJ instantiations below
+    // One workgroup per tile, all of them co-resident (136 KB of LDS: one per CU): the in-launch hand-offs (anchors, old_mean)
+    // are between workgroups that run at the same time.  More tiles than CUs (B = 64 with 5 negatives: 448) would leave
+    // first-round workgroups spinning to their timeout for tiles that cannot start: those batches take the three-launch path.
+    if ((2 + prm.n_neg) * prm.B > device_cu_count()) return false;
     if (!cl4(prm.feats) || !cl4(prm.feats_pos) || !cl2(prm.code) || !cl2(prm.code_pos)) return false;
     if (prm.K % 2 != 0 || prm.K > 128) return false;                            // four code K-chunks of <= 32 channels
     if (prm.H > 256 || prm.W > 256) return false;                             // packed tap coordinates (8 bits each)

@@ -672,3 +672,52 @@ def test_unprepared_entry_point_accepts_any_workspace_and_prepared_one_stays_cle
         call(lib.stego_corr_fwd_prepared, clean, o2)
         for a, b in zip(o1[:7], o2[:7]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=1, C=384, H=4, W=4, K=4, S=1, n_neg=1),        # one sample point, one image (perm = [0])
+    dict(B=2, C=384, H=3, W=5, K=6, S=2, n_neg=0),        # no negatives: no rendezvous, two pair-sets only
+    dict(B=5, C=768, H=7, W=6, K=66, S=7, n_neg=2),       # ViT-B width, B not a multiple of 8 (uneven phase-1 shares)
+    dict(B=9, C=384, H=12, W=12, K=70, S=11, n_neg=3),    # 45 tiles on 45 workgroups, anchors of 9 images over 8 XCDs
+    dict(B=3, C=384, H=2, W=2, K=72, S=3, n_neg=1),       # 2x2 map: most taps clamp; K at the three-launch limit
+    dict(B=36, C=384, H=8, W=8, K=10, S=4, n_neg=5),      # 252 tiles: the largest batch that is still one workgroup per CU
+])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_fused_path_edge_shapes(shape, precision):
+    """The single-launch forward (channels-last ViT-width maps) at the corners of its domain, forward + backward vs the oracle."""
+    d = O.synth_inputs(seed=25, **shape)
+    cfg = O.CorrCfg(feature_samples=shape["S"], neg_samples=shape["n_neg"])
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    cl = {k: _channels_last(_dev(d[k])) for k in ("feats", "feats_pos", "code", "code_pos")}
+    desc = capi.make_desc(shape["B"], shape["C"], shape["K"], shape["H"], shape["W"], shape["S"], shape["n_neg"], cfg, (.18, .12, .46))
+    assert capi.corr_fwd_launches(desc, cl["feats"], cl["feats_pos"], cl["code"], cl["code_pos"]) == 1
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    la = 5e-4
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=la, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=la, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=la, what="neg_loss")
+    scale = max(abs(float(ref.pos_intra_loss)), abs(float(ref.pos_inter_loss)), 1e-3)
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) < 1e-3 * scale
+    assert abs(float(r["out"][2]) - float(ref.pos_inter_loss)) < 1e-3 * scale
+    numel = shape["B"] * shape["S"] ** 4
+    g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (shape["n_neg"] * numel)) if shape["n_neg"] else None
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_more_tiles_than_compute_units_take_the_three_launch_path():
+    """B = 40 with 5 negatives = 280 tiles > 256 CUs: the fused kernel's workgroups would not all be resident, so its in-launch
+    hand-offs would spin to their timeouts; such batches are routed to the three-launch forward (same results)."""
+    shape = dict(B=40, C=384, H=6, W=6, K=8, S=3, n_neg=5)
+    d = O.synth_inputs(seed=26, **shape)
+    cfg = O.CorrCfg(feature_samples=3, neg_samples=5)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    cl = {k: _channels_last(_dev(d[k])) for k in ("feats", "feats_pos", "code", "code_pos")}
+    desc = capi.make_desc(40, 384, 8, 6, 6, 3, 5, cfg, (.18, .12, .46))
+    assert capi.corr_fwd_launches(desc, cl["feats"], cl["feats_pos"], cl["code"], cl["code_pos"]) == 3
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3", grad=False)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=5e-4, what="neg_cd")
