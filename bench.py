@@ -337,6 +337,9 @@ def main():
             torch.cuda.synchronize()
         graphs = None
         launch = "eager"
+        # a torch.distributed call costs ~40 us of host time, which eager stepping at ~100 us/step cannot hide: in graph mode
+        # the all-reduce of every step is captured with the step (RCCL collectives are graph-capturable) and replays for free
+        coll_in_graph = use_graph and dist is not None and collective_on and not dry
         if use_graph and not dry:
             try:
                 # One replay runs `spg` consecutive steps (rotating through the input sets): a hipGraphLaunch costs ~18 us on
@@ -347,8 +350,17 @@ def main():
                 for g0 in range(0, args.sets * spg, spg):
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr, capture_error_mode="thread_local"):     # RCCL's watchdog thread must not break a capture
+                        prev = None
                         for j in range(spg):
                             step_compute((g0 + j) % args.sets)
+                            if coll_in_graph:
+                                # step j's all-reduce runs on RCCL's stream under step j + 1's kernels (as it runs under the next
+                                # backbone forward in training); the graph joins the last one before it ends
+                                if prev is not None:
+                                    prev.wait()
+                                prev = reducer.allreduce_mean(async_op=True, single_rank_ok=True)
+                        if prev is not None:
+                            prev.wait()
                     graphs.append(gr)
                     if spg % args.sets == 0:
                         break                       # every replay covers whole rotations: one graph is enough
@@ -357,8 +369,10 @@ def main():
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                         step_compute(i)
+                        if coll_in_graph:
+                            reducer.allreduce_mean(async_op=False, single_rank_ok=True)
                     single.append(gr)
-                launch = "hipgraph (%d steps per replay)" % spg
+                launch = "hipgraph (%d steps per replay%s)" % (spg, ", the gradient all-reduce captured in the graph" if coll_in_graph else "")
             except Exception as e:      # noqa: BLE001 - fall back to eager launches, say so in the output
                 graphs = None
                 launch = "eager (graph capture failed: %s)" % type(e).__name__
@@ -375,12 +389,12 @@ def main():
             do_collective()
 
         def do_collective():
-            if dist is not None and collective_on:
+            if dist is not None and collective_on and not (graphs is not None and coll_in_graph):
                 # gradients of the segmentation head only (backbone frozen): one flat bucket per step.  async_op: RCCL's
                 # stream first waits for this step's kernels, then the all-reduce runs while the next step computes - in
                 # training it overlaps the next step's backbone forward the same way; every all-reduce is complete
                 # before the clock stops (drain()).
-                pending[0] = reducer.allreduce_mean(async_op=True)
+                pending[0] = reducer.allreduce_mean(async_op=True, single_rank_ok=True)
 
         def run(n):
             """exactly n steps: whole multi-step replays first, single-step graphs for the rest"""
@@ -553,7 +567,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
                        "launch_trial_ms_per_step": trial,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
-                       "collective": ("all_reduce(%d f32 head grads)/step" % grad_buf.numel()) if world > 1 else None},
+                       "collective": ("all_reduce(%d f32 head grads)/step, FlatGradReducer.allreduce_mean(async)" % grad_buf.numel())
+                       if dist is not None else None},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
             "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,

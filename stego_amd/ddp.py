@@ -82,7 +82,7 @@ class FlatGradReducer:
                 p.grad = view
             off += n
 
-    def allreduce_mean(self, async_op=False):
+    def allreduce_mean(self, async_op=False, single_rank_ok=False):
         """One all-reduce of the whole bucket, averaged over the ranks; no-op (returns None) for a single process.
 
         RCCL (backend 'nccl'): ``ReduceOp.AVG`` - the 1/world is folded into the collective, no extra kernel - launched
@@ -90,8 +90,8 @@ class FlatGradReducer:
         stream dependency (the host does not block), so the caller can enqueue whatever does not need the gradients
         (logging reductions, the next batch's copies) before it waits.  gloo (CPU tests) has no AVG: SUM + divide,
         synchronous."""
-        if not is_distributed():
-            return None
+        if not is_distributed() and not (single_rank_ok and dist.is_available() and dist.is_initialized()):
+            return None                  # (single_rank_ok: run the collective on a group of one - bench.py --force-collective)
         if dist.get_backend(self.group) == "nccl":
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             if async_op:
