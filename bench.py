@@ -443,6 +443,10 @@ def main():
         for m in ("eager", "graph"):
             dt_m, _, _ = timed_run(args.precision, 48, 16, use_graph=(m == "graph"))
             trial[m] = dt_m / 48 * 1e3
+        if dist is not None:                # every rank takes the same decision: the slowest rank's trial times
+            tt = torch.tensor([trial["eager"], trial["graph"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial = {"eager": float(tt[0]), "graph": float(tt[1])}
         mode = "graph" if trial["graph"] < trial["eager"] else "eager"
     dt, launch, desc = timed_run(args.precision, args.steps, args.warmup, use_graph=(mode == "graph"))
     use_graph = mode == "graph"
