@@ -316,8 +316,14 @@ class SyntheticContrastiveDataset(torch.utils.data.Dataset):
 class Trainer:
     """Minimal stand-in for the Lightning Trainer the reference builds at train_segmentation.py:476-497."""
 
-    def __init__(self, max_steps, device=None, log_every=10):
+    def __init__(self, max_steps, device=None, log_every=10, val_loader=None, val_check_interval=None, checkpoint_path=None):
+        """val_loader / val_check_interval: every that many steps the model's validation_step runs over val_loader and
+        validation_epoch_end reports the metrics (train_segmentation.py:247-330, Trainer(val_check_interval=cfg.val_freq) :489);
+        checkpoint_path: rank 0 writes a Lightning-layout checkpoint there after every validation and at the end (the
+        ModelCheckpoint callback of :482-486)."""
         self.max_steps, self.log_every = max_steps, log_every
+        self.val_loader, self.val_check_interval, self.checkpoint_path = val_loader, val_check_interval, checkpoint_path
+        self.val_history = []
         self.rank, self.world, self.local_rank = ddp.init_from_env()
         self.device = device or (torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu"))
 
@@ -351,9 +357,27 @@ class Trainer:
                     print("step %5d  loss %.5f  " % (step, history[-1]) +
                           "  ".join("%s %.5f" % (k, float(v)) for k, v in model.logged.items() if k.startswith("loss/pos") or k.startswith("loss/neg")))
                 step += 1
+                if self.val_loader is not None and self.val_check_interval and step % self.val_check_interval == 0:
+                    self._validate(model)
                 if step >= self.max_steps:
                     break
+        if self.checkpoint_path and self.rank == 0:
+            model.save_checkpoint(self.checkpoint_path)
         return history
+
+    def _validate(self, model):
+        model.eval()
+        outs = []
+        with torch.no_grad():
+            for i, batch in enumerate(self.val_loader):
+                batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                outs.append(model.validation_step(batch, i))
+        metrics = model.validation_epoch_end(outs)
+        self.val_history.append(metrics)
+        model.train()
+        if self.checkpoint_path and self.rank == 0:
+            model.save_checkpoint(self.checkpoint_path)
+        return metrics
 
 
 def my_app(cfg):

@@ -69,8 +69,9 @@ class NativeViT:
             arr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
             nbytes = lib.stego_vit_weights_bytes(ctypes.byref(desc))
             blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            capi._check(lib.stego_vit_pack_weights(ctypes.byref(desc), arr, n, blob.data_ptr(), nbytes, capi._stream()))
-            torch.cuda.current_stream().synchronize()          # `params` may be temporaries: keep them alive until packed
+            with torch.cuda.device(dev):
+                capi._check(lib.stego_vit_pack_weights(ctypes.byref(desc), arr, n, blob.data_ptr(), nbytes, capi._stream()))
+                torch.cuda.current_stream().synchronize()      # `params` may be temporaries: keep them alive until packed
             self._packed[key] = blob
         return blob
 
@@ -85,13 +86,18 @@ class NativeViT:
         desc = self._desc(B, H, W)
         dev = img.device
         blob = self._weights(desc, dev)
-        wkey = (B, H, W, dev)
-        ws = self._ws.get(wkey)
-        if ws is None:
-            ws = torch.empty(lib.stego_vit_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
-            self._ws[wkey] = ws
+        # ONE workspace per device, sized for the largest request seen (a smaller batch fits in it): TokenCache partial-miss
+        # batches arrive with every B' from 1 to B and must not leave B large buffers behind
+        need = int(lib.stego_vit_workspace_bytes(ctypes.byref(desc)))
+        if need == 0:
+            raise RuntimeError("stego_vit: unsupported shape B=%d %dx%d for this backbone (see include/stego_vit.h)" % (B, H, W))
+        ws = self._ws.get(dev)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[dev] = ws
         ps = self.model.patch_embed.patch_size
         out = torch.empty(B, 1 + (H // ps) * (W // ps), self.model.embed_dim, dtype=torch.float32, device=dev)
-        capi._check(lib.stego_vit_forward(ctypes.byref(desc), blob.data_ptr(), img.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), capi._stream()))
+        with torch.cuda.device(dev):
+            capi._check(lib.stego_vit_forward(ctypes.byref(desc), blob.data_ptr(), img.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), capi._stream()))
         return out

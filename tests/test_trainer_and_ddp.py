@@ -346,3 +346,29 @@ def test_feature_pyramid_arch_builds_through_the_segmenter():
         LitUnsupervisedSegmenter(5, load_config(overrides=ov[:-1]))
     with pytest.raises(ValueError, match="No model"):
         trunks.load_model("vgg11", ".")
+
+
+def test_trainer_runs_validation_and_writes_a_loadable_checkpoint(tmp_path):
+    """Trainer.fit: validation every val_check_interval steps (train_segmentation.py:247-330, :489) and a Lightning-layout
+    checkpoint that LitUnsupervisedSegmenter.load_from_checkpoint reads back (the ModelCheckpoint callback of :482-486)."""
+    from stego_amd.train_segmentation import SyntheticContrastiveDataset, Trainer
+    cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "batch_size=4", "dim=12",
+                                 "feature_samples=3", "neg_samples=1", "max_steps=4", "dropout=False", "n_images=2"])
+    torch.manual_seed(4)
+    m = LitUnsupervisedSegmenter(5, cfg).cpu()
+    ds = SyntheticContrastiveDataset(8, 32, 5, seed=2)
+    loader = torch.utils.data.DataLoader(ds, 4, shuffle=False, drop_last=True)
+    ck = str(tmp_path / "last.ckpt")
+    tr = Trainer(4, device=torch.device("cpu"), val_loader=torch.utils.data.DataLoader(ds, 4), val_check_interval=2, checkpoint_path=ck)
+    M._backend = oracle_backend
+    try:
+        hist = tr.fit(m, loader)
+    finally:
+        from stego_amd import capi
+        M._backend = capi
+    assert len(hist) == 4 and len(tr.val_history) == 2
+    assert any(k.endswith("mIoU") or "Accuracy" in k for k in tr.val_history[-1]), tr.val_history[-1].keys()
+    assert os.path.exists(ck)
+    m2 = LitUnsupervisedSegmenter.load_from_checkpoint(ck)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
