@@ -721,3 +721,32 @@ def test_more_tiles_than_compute_units_take_the_three_launch_path():
     ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
     assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
     assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=5e-4, what="neg_cd")
+
+
+def test_split_fp16_backward_error_stays_in_the_fp32_class():
+    """F16X3 also runs the backward's two code GEMMs as split-fp16 products (corr_bwd_tile_h_kernel); F32 keeps
+    v_mfma_f32_16x16x4_f32.  Against the fp64 oracle the split gradients must be as good as the fp32 ones: same error class
+    (<= 2x + rounding floor), on smooth DINO-like inputs and on codes with a 2^12 dynamic range inside a point (tiny channels
+    fall into fp16-subnormal lo halves of the transposed operand images)."""
+    B, C, H, W, K, S, n_neg = 4, 384, 12, 12, 70, 11, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=505, dino_like=True)
+    rng = np.random.default_rng(505)
+    code = d["code"].copy()
+    code_pos = d["code_pos"].copy()
+    spread = np.exp2(rng.integers(-12, 1, size=(1, K, 1, 1))).astype(np.float32)
+    code[1] *= spread[0]
+    code_pos[2] *= spread[0]
+    code[3] *= np.float32(1e-5)
+    inputs = dict(feats=d["feats"], feats_pos=d["feats_pos"], code=code, code_pos=code_pos, coords1=d["coords1"], coords2=d["coords2"])
+    cfg = O.CorrCfg(neg_samples=n_neg)
+    numel = B * S ** 4
+    g_nl = np.full((n_neg * B,) + (S,) * 4, 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    err = {}
+    for precision in ("f32", "f16x3"):
+        r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
+        assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code %s" % precision)
+        assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos %s" % precision)
+        err[precision] = max(np.abs(r["d_code"] - dc).max() / np.abs(dc).max(), np.abs(r["d_code_pos"] - dcp).max() / np.abs(dcp).max())
+    assert err["f16x3"] <= 2.0 * err["f32"] + 1e-6, err
+    assert err["f16x3"] < 2e-5, err
