@@ -1,4 +1,4 @@
-// Fused forward of STEGO's ContrastiveCorrelationLoss for gfx950 (MI355X): ONE launch (+ a one-block scalar kernel).
+// Fused forward of STEGO's ContrastiveCorrelationLoss for gfx950 (MI355X): ONE launch, nothing before or after it.
 //
 // Reference path: src/modules.py:349-398 (forward), :325-347 (helper), :275-295 (norm / tensor_correlation / sample).
 //
@@ -12,17 +12,19 @@
 //   * tile -> workgroup placement by the XCD of the tile's B-side SOURCE image (block b runs on XCD b % 8, observed):
 //     all workgroups that gather from image j - the intra / inter tiles of anchor j and every negative tile (i, b) with
 //     perm_i[b] = j - sit on XCD j % 8, so every feature / code map is fetched into exactly one L2, once;
-//   * phase 1 (all 8 waves of every workgroup, first thing): the anchor sets are sampled + normalised ONCE, ~18 points per
+//   * phase 1 (all 12 waves of every workgroup, first thing): the anchor sets are sampled + normalised ONCE, ~18 points per
 //     workgroup by the same XCD affinity (anchor b is sampled on XCD b % 8, so the same fetch of image b serves its
 //     negatives), staged through LDS into ready-made operand stages and written with coalesced write-through (sc1)
 //     stores; one counter per anchor publishes them.  A tile waits for its anchor's counter (one polling wave, bounded
 //     spin; on timeout that wave recomputes the anchor itself - same values, so duplicate stores are benign) and then
 //     streams the anchor operand with sc1 LDS-DMA copies.  The compact operand (196 KB) is what crosses XCDs, never
-//     the raw taps of a second image (550 KB);
+//     the raw taps of a second image (550 KB).  The last wave (it has no rows: 12 waves x 2 rows > 18) meanwhile works out
+//     which tile this workgroup owns (ballots over perms) and builds the gather team's tap table;
 //   * the main loop is a RING of four 32-channel stages (A side: LDS-DMA issued three stages ahead from inline asm, so
-//     that neither the compiler nor a barrier drains it; B side: gathered two stages ahead in registers, committed one
-//     stage ahead) - with two 64-channel stages every barrier waited for a whole round trip (period = latency +
-//     transfer);
+//     that neither the compiler nor a barrier drains it; B side: gathered by a team of 8 waves two stages ahead into
+//     registers - tap offsets and weights register-resident - and committed one stage ahead); one raw s_barrier per
+//     stage, which is also a scheduling fence.  With two 64-channel stages every barrier waited for a whole round trip
+//     (period = latency + transfer);
 //   * the codes go through the same ring as K-chunks of exact-fp32 operands AHEAD of the features: their fp32 MFMAs
 //     (VALU rate) run while the ring fills with feature stages; the B-side codes are gathered by the gather team with
 //     the feature taps (same points), their norm becomes a column scale of cd, the backward's context is written on the way;
@@ -30,9 +32,10 @@
 //     negative loss tensor - is a rendezvous INSIDE the launch: every negative tile publishes its sum(fd) as one
 //     tagged 8-byte granule before it parks its tiles, and reads the B granules of its pair-set just before the
 //     output sweep (measured 1.2 us mean / 1.7 us worst after the last publisher, hidden behind the parking).  The spin
-//     is bounded: a tile that gives up writes the loss without the old_mean term and flags itself, and
-//     corr_fused_scalars_kernel (which computes the three scalars from the per-tile sums in a fixed order anyway)
-//     repairs flagged tiles.  Normally it repairs nothing.
+//     is bounded: a tile that gives up writes the loss without the old_mean term and flags itself;
+//   * every workgroup ends with a ticket; the LAST one computes the three scalars from the per-tile sums in a fixed
+//     order, repairs flagged tiles (normally none) and writes the hand-off words back to zero, so that a prepared
+//     workspace serves launch after launch without a memset (stego_corr_workspace_prepare / stego_corr_fwd_prepared).
 //
 // Arithmetic: PREC_F16X3 split-fp16 feature products (hi*hi + hi*lo + lo*hi, fp32 accumulate), exact fp32 code
 // products, fp32 epilogue.  No atomics on data, fixed summation orders: bitwise repeatable.
