@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STEGO_ABI_VERSION 1
+#define STEGO_ABI_VERSION 2   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128 */
 
 enum {
     STEGO_OK = 0,
