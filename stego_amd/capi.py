@@ -94,7 +94,7 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the .so is stale / symbol missing
         fn.restype = res
         fn.argtypes = args
-    if lib.stego_abi_version() != 1:
+    if lib.stego_abi_version() != 2:
         raise RuntimeError("stego_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib
