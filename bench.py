@@ -115,6 +115,24 @@ def make_inputs(B, C, H, W, K, S, n_neg, seed, dev, layout="cl"):
 
 
 def product_path(sets, cfg, args, kernel_step_s):
+    """Default (the reference's RNG draws call for call) plus the opt-in cfg.fast_draws variant (same distributions from one
+    kernel: not the reference's random stream)."""
+    import copy
+    out = _product_path(sets, cfg, args, kernel_step_s)
+    fast = copy.copy(cfg)
+    fast.fast_draws = True
+    out["fast_draws"] = _product_path(sets, fast, args, kernel_step_s)
+    out["fast_draws"]["what"] = "the same call with cfg.fast_draws=True (opt-in): draws of the reference's distributions from one Philox kernel"
+    # what stego_amd's own training step calls: ContrastiveCorrelationLoss.total() - the three means come out of the forward launch,
+    # one dot product combines them, the backward takes three device scalars
+    out["total_api"] = _product_path(sets, cfg, args, kernel_step_s, total=True)
+    out["total_api"]["what"] = "loss_fn.total(feats, feats_pos, None, None, code, code_pos, (0.67, 0.25, 0.63))[0].backward(), the reference's draws"
+    out["total_api_fast_draws"] = _product_path(sets, fast, args, kernel_step_s, total=True)
+    out["total_api_fast_draws"]["what"] = "the same with cfg.fast_draws=True"
+    return out
+
+
+def _product_path(sets, cfg, args, kernel_step_s, total=False):
     """Times the op as a training step calls it (train_segmentation.py:163-181): ContrastiveCorrelationLoss.forward with its own
     RNG draws (coords1, coords2, one randperm per negative), the weighted sum and .backward() into the code maps -
     eagerly, and replayed from a HIP graph (the draws are captured with the generator's graph-safe offsets)."""
@@ -128,6 +146,10 @@ def product_path(sets, cfg, args, kernel_step_s):
         c, cp = codes[i]
         c.grad = None
         cp.grad = None
+        if total:
+            loss_fn.total(d["feats"], d["feats_pos"], None, None, c, cp,
+                          (cfg.pos_intra_weight, cfg.pos_inter_weight, cfg.neg_inter_weight))[0].backward()
+            return
         (pil, _, pel, _, nl, _) = loss_fn(d["feats"], d["feats_pos"], None, None, c, cp)
         (cfg.pos_intra_weight * pil + cfg.pos_inter_weight * pel + cfg.neg_inter_weight * nl.mean()).backward()
 

@@ -134,7 +134,8 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
  *   coords1, coords2 : [B,S,S,2] contiguous, values in [-1,1] (x=width first)
  *   perms            : int64 [n_neg,B] contiguous, values in [0,B)  (may be NULL iff n_neg==0)
  * outputs (contiguous):
- *   loss_means       : [2] = { pos_intra_loss.mean(), pos_inter_loss.mean() }
+ *   loss_means       : [3] = { pos_intra_loss.mean(), pos_inter_loss.mean(), neg_inter_loss.mean() }   (ABI 2: three floats -
+ *                      the third is torch.cat(negative losses).mean(), what train_segmentation.py:176 computes; 0 when n_neg == 0)
  *   pos_intra_cd, pos_inter_cd : [B,S,S,S,S]
  *   neg_inter_loss, neg_inter_cd : [n_neg*B,S,S,S,S]   (torch.cat over negatives, :390-391)
  *   saved_w          : optional [(2+n_neg)*B, S^4]: (fd_centred - shift) per pair-set with the clamp pass-mask
@@ -159,6 +160,14 @@ int stego_corr_fwd(const StegoCorrDesc* desc,
  * u1, u2: n_coord floats each; raw_perms: n_neg (<= 16) HOST-array of device pointers to int64 [B]; perms: int64 [n_neg, B]. */
 int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const int64_t* const* raw_perms, int32_t n_neg,
                        int32_t B, float* coords1, float* coords2, int64_t* perms, stego_stream_t stream);
+
+/* OPT-IN alternative to the torch draws (cfg.fast_draws): the same DISTRIBUTIONS as modules.py:366-367, 382-385 - coords
+ * uniform on torch.rand's 2^-24 lattice, times 2 minus 1; one uniformly random permutation of [0, B) per negative followed by
+ * the super_perm fix-up - from one kernel with its own counter-based generator (Philox-4x32-10) keyed by the 64 random bits at
+ * `seed` (device memory; the caller draws them from the torch generator).  NOT the reference's random stream.
+ * coords1/2: n_coord floats each; perms: int64 [n_neg, B]. */
+int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2,
+                     int64_t* perms, stego_stream_t stream);
 
 /* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize; < 0: -error code. */
 int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
@@ -201,8 +210,9 @@ int stego_corr_fwd_profile(const StegoCorrDesc* desc,
  *
  *   g_intra, g_inter : device scalars, upstream of loss_means[0], loss_means[1] (NULL -> 0)
  *   g_neg_loss       : upstream of neg_inter_loss; g_neg_loss_stride = 1 -> dense
- *                      [n_neg*B,S^4], 0 -> one broadcast device scalar (what .mean() feeds);
- *                      NULL -> zero
+ *                      [n_neg*B,S^4], 0 -> one broadcast device scalar (the per-element value .mean() feeds),
+ *                      -1 -> one device scalar that is the upstream of loss_means[2] (the kernel spreads it over the
+ *                      n_neg*B*S^4 elements); NULL -> zero
  *   g_intra_cd, g_inter_cd, g_neg_cd : optional dense upstreams of the cd outputs (NULL -> 0)
  *   d_code, d_code_pos : OUT, channels-last dense [B,H,W,K] (i.e. grad.permute(0,2,3,1)), overwritten.
  *   workspace        : stego_corr_bwd_workspace_bytes()

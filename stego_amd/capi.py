@@ -61,6 +61,7 @@ SIGNATURES = {
     "stego_corr_fwd_prepared": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
+    "stego_fast_draws": (c_int32, [_P, ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_finish_draws": (c_int32, [_P, _P, ctypes.c_int64, POINTER(ctypes.c_void_p), c_int32, c_int32, _P, _P, _P, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
                                + [c_int32, POINTER(c_float)]),
@@ -186,7 +187,7 @@ def _fwd_buffers(lib, desc, dev, need_grad, flat=False, keep_ws=False):
     B, S, n_neg = desc.B, desc.S, desc.n_neg
     f32 = dict(dtype=torch.float32, device=dev)
     shp = (S ** 4,) if flat else (S, S, S, S)
-    loss_means = torch.empty(2, **f32)
+    loss_means = torch.empty(3, **f32)
     intra_cd = torch.empty(B, *shp, **f32)
     inter_cd = torch.empty(B, *shp, **f32)
     neg_loss = torch.empty(n_neg * B, *shp, **f32)
@@ -199,7 +200,7 @@ def _fwd_buffers(lib, desc, dev, need_grad, flat=False, keep_ws=False):
 
 
 def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad):
-    """stego_corr_fwd on torch tensors. Returns (loss_means[2], intra_cd, inter_cd, neg_loss, neg_cd,
+    """stego_corr_fwd on torch tensors. Returns (loss_means[3], intra_cd, inter_cd, neg_loss, neg_cd,
     saved) where saved = (saved_w, saved_mean, saved_ctx) or None."""
     _require_dev(feats, feats_pos, code, code_pos, coords1, coords2, perms)
     lib = load()
@@ -233,6 +234,19 @@ def finish_draws(u1, u2, raw_perms, B):
     return c1, c2, perms
 
 
+def fast_draws(seed, shape, n_neg, B):
+    """(coords1, coords2, perms) of the reference's distributions from ONE launch (stego_fast_draws); `seed`: int64 [1] on the
+    device, drawn by the caller from the torch generator.  Not the reference's random stream (cfg.fast_draws)."""
+    lib = load()
+    dev = seed.device
+    c1 = torch.empty(shape, dtype=torch.float32, device=dev)
+    c2 = torch.empty(shape, dtype=torch.float32, device=dev)
+    perms = torch.empty(n_neg, B, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.stego_fast_draws(_ptr(seed), c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+    return c1, c2, perms
+
+
 def corr_fwd_launches(desc, feats, feats_pos, code, code_pos):
     """Kernel launches stego_corr_fwd_prepared needs for these maps: 1 = the fused forward, 3 = sample / tile / finalize."""
     lib = load()
@@ -259,8 +273,9 @@ def corr_fwd_profile(desc, feats, feats_pos, code, code_pos, coords1, coords2, p
 
 
 def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, inter_cd, neg_cd,
-             g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd):
-    """stego_corr_bwd. g_* may be None. Returns (d_code, d_code_pos) as [B,K,H,W] views of channels-last buffers."""
+             g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd, neg_is_mean=False):
+    """stego_corr_bwd. g_* may be None. Returns (d_code, d_code_pos) as [B,K,H,W] views of channels-last buffers.
+    neg_is_mean: g_neg_loss is ONE device scalar, the upstream of loss_means[2] (stride -1 of the C ABI)."""
     saved_w, saved_mean, saved_ctx = saved
     _require_dev(code, code_pos, saved_w)
     lib = load()
@@ -268,7 +283,10 @@ def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, int
     B, K, H, W = desc.B, desc.K, desc.H, desc.W
     perms = _dense(perms, torch.int64) if desc.n_neg else None
     stride = 1
-    if g_neg_loss is not None and g_neg_loss.numel() > 0:
+    if neg_is_mean:
+        stride = -1
+        g_neg_loss = None if g_neg_loss is None else _dense(g_neg_loss, torch.float32)
+    elif g_neg_loss is not None and g_neg_loss.numel() > 0:
         if all(s == 0 for s in g_neg_loss.stride()):
             stride = 0                      # expanded scalar: hand over the one element
         else:

@@ -14,6 +14,8 @@ hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 bool fused_supported(const FusedParams& prm, int precision);
 hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, bool prepared, hipStream_t stream, hipEvent_t* ev);
 hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStream_t stream);
+hipError_t launch_fast_draws(const long long* seed, long long n_coord, int n_neg, int B, float* c1, float* c2, long long* perms,
+                             hipStream_t stream);
 hipError_t launch_finish_draws(const float* u1, const float* u2, long long n_coord, const long long* const* raw, int n_neg,
                                int B, float* c1, float* c2, long long* perms, hipStream_t stream);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
@@ -340,6 +342,16 @@ int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const 
                                       coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
 }
 
+int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2,
+                     int64_t* perms, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_coord < 0 || n_neg < 0 || B < 1 || B > 6000) return STEGO_ERR_SHAPE;          // (keys of a permutation live in LDS)
+    if (!seed || (n_coord > 0 && (!coords1 || !coords2)) || (n_neg > 0 && !perms)) return STEGO_ERR_NULL;
+    return hip_rc(launch_fast_draws(reinterpret_cast<const long long*>(seed), n_coord, n_neg, B, coords1, coords2,
+                                    reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+}
+
 int stego_corr_fwd_launches(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code,
                             const StegoMap* code_pos)
 {
@@ -429,7 +441,7 @@ int stego_corr_bwd(const StegoCorrDesc* d, const int64_t* perms, const float* sa
     if (rc) return rc;
     if (!saved_w || !saved_mean || !pos_intra_cd || !pos_inter_cd || !d_code || !d_code_pos) return STEGO_ERR_NULL;
     if (d->n_neg > 0 && (!perms || !neg_inter_cd)) return STEGO_ERR_NULL;
-    if (g_neg_loss_stride != 0 && g_neg_loss_stride != 1) return STEGO_ERR_SHAPE;
+    if (g_neg_loss_stride < -1 || g_neg_loss_stride > 1) return STEGO_ERR_SHAPE;
     BwdParams prm{};
     if ((rc = fill_bwd_ctx(d, false, saved_ctx, workspace, workspace_bytes, &prm))) return rc;
     prm.perms = reinterpret_cast<const long long*>(perms);

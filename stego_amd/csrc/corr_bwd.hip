@@ -123,10 +123,11 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
         float gl_scale = 0.f;
         if (direct || p >= 2) {
             if (prm.g_neg_loss) {
-                const bool dense = direct || prm.g_neg_loss_stride != 0;
+                const bool dense = direct || prm.g_neg_loss_stride > 0;
                 glp = dense ? prm.g_neg_loss + t0 : prm.g_neg_loss;
                 gl_mul = dense ? 1 : 0;
-                gl_scale = 1.f;
+                // stride -1: the upstream of torch.cat(neg losses).mean(): one scalar, spread over n_neg B P^2 elements
+                gl_scale = (!direct && prm.g_neg_loss_stride < 0) ? inv_numel / (float)prm.n_neg : 1.f;
             }
         } else {
             const float* gs = p == 0 ? prm.g_intra : prm.g_inter;     // .mean() backward (modules.py:393,395)
@@ -344,7 +345,8 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     float gl_b = 0.f;                                 // broadcast / scalar upstream of the loss
     if (p >= 2) {
         if (prm.g_neg_loss) {
-            if (DENSE && prm.g_neg_loss_stride != 0) { glp = prm.g_neg_loss + t0; has_gl = true; }
+            if (DENSE && prm.g_neg_loss_stride > 0) { glp = prm.g_neg_loss + t0; has_gl = true; }
+            else if (prm.g_neg_loss_stride < 0) gl_b = prm.g_neg_loss[0] * (1.f / ((float)B * (float)P2 * (float)prm.n_neg));   // mean upstream
             else gl_b = prm.g_neg_loss[0];
         }
     } else {
@@ -1021,7 +1023,7 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         // fp32 operand images no longer fit LDS (the split kernel walks the channel tiles in two groups)
         const bool split = prm.mode == 0 && !(prm.debug & 64) && (prm.precision == PREC_F16X3 || nt > 5);   // (debug 64: fp32 MFMA kernel)
         const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
-        const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride != 0);
+        const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride > 0);
         const int lds = split ? SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;
         const dim3 grid(prm.n_sets * prm.B), block(NTHREADS);
 #define STEGO_BWD_CASE(N)                                                                                         \

@@ -1115,10 +1115,16 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         }
         const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
         som[tid] = fsum * inv_cnt;
+        som[prm.n_sets + tid] = lsum - omp * csum;                 // sum of this pair-set's loss
         if (prm.saved_mean) prm.saved_mean[tid] = omp;
         if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
     }
     __syncthreads();
+    if (tid == 0) {                              // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
+        float nsum = 0.f;
+        for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
+        prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
+    }
     // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
     bool mine = false;
     for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;

@@ -308,16 +308,26 @@ __global__ void __launch_bounds__(NTHREADS) corr_finalize_kernel(const CorrParam
     const int B = prm.B, P2 = prm.P * prm.P;
     const float inv_cnt = 1.f / ((float)B * (float)P2);
     const int first_loss_set = prm.mode == 1 ? 0 : 2;
-    if (blockIdx.x == 0 && threadIdx.x < prm.n_sets) {
-        const int p = threadIdx.x;
-        float fs = 0.f, ls = 0.f, cs = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float* st = prm.stats + ((size_t)p * B + b) * 4;
-            fs += st[0]; ls += st[1]; cs += st[2];
+    if (blockIdx.x == 0) {
+        __shared__ float set_loss[NTHREADS];
+        if (threadIdx.x < prm.n_sets) {
+            const int p = threadIdx.x;
+            float fs = 0.f, ls = 0.f, cs = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float* st = prm.stats + ((size_t)p * B + b) * 4;
+                fs += st[0]; ls += st[1]; cs += st[2];
+            }
+            const float om = prm.pointwise ? fs * inv_cnt : 0.f;
+            set_loss[p] = ls - om * cs;
+            if (prm.saved_mean) prm.saved_mean[p] = om;
+            if (prm.mode == 0 && p < 2) prm.loss_means[p] = (ls - om * cs) * inv_cnt;
         }
-        const float om = prm.pointwise ? fs * inv_cnt : 0.f;
-        if (prm.saved_mean) prm.saved_mean[p] = om;
-        if (prm.mode == 0 && p < 2) prm.loss_means[p] = (ls - om * cs) * inv_cnt;
+        __syncthreads();
+        if (prm.mode == 0 && threadIdx.x == 0) {     // torch.cat(negative losses).mean(), pair-set order
+            float nsum = 0.f;
+            for (int pp = 2; pp < prm.n_sets; ++pp) nsum += set_loss[pp];
+            prm.loss_means[2] = prm.n_sets > 2 ? nsum * inv_cnt / (float)(prm.n_sets - 2) : 0.f;
+        }
     }
     if (!prm.pointwise) return;
     const int n_loss_sets = prm.n_sets - first_loss_set;

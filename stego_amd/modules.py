@@ -167,6 +167,41 @@ class _CorrLossFunction(torch.autograd.Function):
                 None, None, None, None)
 
 
+class _CorrLossMeansFunction(torch.autograd.Function):
+    """The same op returning the three loss MEANS as one tensor [3] = (pos_intra.mean(), pos_inter.mean(),
+    cat(neg).mean()) - all three come out of the forward kernel - so that a training step combines them with one dot
+    product and the backward gets three device scalars (no .mean() pass over the negative loss tensor, no expand)."""
+
+    @staticmethod
+    def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
+        need_grad = bool(code.requires_grad or code_pos.requires_grad)
+        ctx.set_materialize_grads(False)
+        (loss_means, intra_cd, inter_cd, _neg_loss, neg_cd, saved) = _backend.corr_fwd(
+            desc, as_channels_last(feats.detach()), as_channels_last(feats_pos.detach()),
+            as_channels_last(code.detach()), as_channels_last(code_pos.detach()), coords1, coords2, perms, need_grad)
+        ctx.desc = desc
+        if need_grad:
+            ctx.save_for_backward(code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd, *saved)
+        return loss_means, intra_cd, inter_cd, neg_cd
+
+    @staticmethod
+    def backward(ctx, g_means, g_intra_cd, g_inter_cd, g_neg_cd):
+        code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd = ctx.saved_tensors[:8]
+        saved = tuple(ctx.saved_tensors[8:])
+        if g_means is not None:
+            g_means = g_means.contiguous()
+        gi = None if g_means is None else g_means[0:1]
+        ge = None if g_means is None else g_means[1:2]
+        gn = None if (g_means is None or ctx.desc.n_neg == 0) else g_means[2:3]
+        d_code, d_code_pos = _backend.corr_bwd(ctx.desc, code.detach(), code_pos.detach(), coords1, coords2, perms,
+                                               saved, intra_cd, inter_cd, neg_cd, gi, ge, gn, g_intra_cd, g_inter_cd, g_neg_cd,
+                                               neg_is_mean=True)
+        return (None, None,
+                d_code if ctx.needs_input_grad[2] else None,
+                d_code_pos if ctx.needs_input_grad[3] else None,
+                None, None, None, None)
+
+
 class _HelperFunction(torch.autograd.Function):
     """ContrastiveCorrelationLoss.helper on pre-sampled tensors: stego_corr_helper_fwd / _bwd."""
 
@@ -247,10 +282,50 @@ class ContrastiveCorrelationLoss(nn.Module):
                 orig_salience: torch.Tensor, orig_salience_pos: torch.Tensor,
                 orig_code: torch.Tensor, orig_code_pos: torch.Tensor,
                 ):
+        coords1, coords2, perms = self.draw(orig_feats, orig_salience, orig_salience_pos)
+        return self.forward_explicit(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
+
+    def means(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos):
+        """forward() for a training step that only needs the three loss means (train_segmentation.py:176-181 takes
+        .mean() of each): returns (means [3] = (pos_intra, pos_inter, neg_inter), pos_intra_cd, pos_inter_cd, neg_inter_cd).
+        Same draws, same kernel; the negative loss tensor is not handed back, its mean comes out of the forward launch."""
+        coords1, coords2, perms = self.draw(orig_feats, orig_salience, orig_salience_pos)
+        cfg = self.cfg
+        B, C, H, W = orig_feats.shape
+        n_neg = int(perms.shape[0]) if perms is not None else 0
+        if perms is None:
+            perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
+        desc = capi.make_desc(B, C, orig_code.shape[1], H, W, cfg.feature_samples, n_neg, cfg,
+                              (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), _precision_of(cfg))
+        return _CorrLossMeansFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
+
+    def total(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos, weights):
+        """weights = (pos_intra_weight, pos_inter_weight, neg_inter_weight) -> (the weighted sum of the three loss means as one
+        dot product, means [3] detached for logging, pos_intra_cd, pos_inter_cd, neg_inter_cd)."""
+        m, icd, ecd, ncd = self.means(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos)
+        key = (tuple(float(w) for w in weights), m.device)
+        w = self._weights.get(key) if hasattr(self, "_weights") else None
+        if w is None:
+            if not hasattr(self, "_weights"):
+                self._weights = {}
+            w = torch.tensor(key[0], dtype=torch.float32, device=m.device)
+            self._weights[key] = w
+        return torch.dot(m, w), m.detach(), icd, ecd, ncd
+
+    def draw(self, orig_feats, orig_salience, orig_salience_pos):
+        """The RNG draws of forward() (modules.py:355-367, 382-385) -> (coords1, coords2, perms or None)."""
         B = orig_feats.shape[0]
         dev = orig_feats.device
         cfg = self.cfg
-        if dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "finish_draws"):
+        if dev.type == "cuda" and not cfg.use_salience and getattr(cfg, "fast_draws", False) and hasattr(_backend, "fast_draws"):
+            # OPT-IN (cfg.fast_draws, default off): the same distributions from ONE kernel keyed by 64 bits of the torch
+            # generator - not the reference's random stream, ~30 launches fewer per step (torch.randperm alone is 5 kernels)
+            seed = torch.randint(-2 ** 63, 2 ** 63 - 1, (1,), dtype=torch.int64, device=dev)
+            shape = [B, cfg.feature_samples, cfg.feature_samples, 2]
+            coords1, coords2, perms = _backend.fast_draws(seed, shape, cfg.neg_samples, B)
+            if cfg.neg_samples == 0:
+                perms = None
+        elif dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "finish_draws"):
             # The reference's draws in the reference's order on the device generator (:366, :367, :383): torch.rand x2, then
             # one torch.randperm per negative; "* 2 - 1" and the super_perm fix-up run in ONE kernel (stego_finish_draws)
             # instead of nine.  (Forking the ~30 tiny draw kernels onto side streams while a HIP graph is captured was
@@ -267,4 +342,4 @@ class ContrastiveCorrelationLoss(nn.Module):
             # :382-383 - one randperm per negative from the device generator (the reference's draws), one batched fix-up
             raw = [torch.randperm(B, device=dev, dtype=torch.long) for _ in range(cfg.neg_samples)]
             perms = _unfix(torch.stack(raw)) if raw else None
-        return self.forward_explicit(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
+        return coords1, coords2, perms

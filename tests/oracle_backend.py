@@ -32,7 +32,8 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
     out = O.corr_loss_forward(_np(feats), _np(feats_pos), _np(code), _np(code_pos), _np(coords1), _np(coords2),
                               list(_np(perms)) if desc.n_neg else [], cfg)
     S = desc.S
-    loss_means = _t(np.array([out.pos_intra_loss, out.pos_inter_loss]), feats)
+    neg_mean = float(np.mean(out.neg_inter_loss)) if desc.n_neg else 0.0
+    loss_means = _t(np.array([out.pos_intra_loss, out.pos_inter_loss, neg_mean]), feats)
     saved = None
     if need_grad:   # opaque to the host layer; keep what our corr_bwd below needs
         saved = (_t(np.zeros(1), feats), _t(np.zeros(1), feats), _t(np.zeros(1), feats))
@@ -43,14 +44,17 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
 
 
 def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, inter_cd, neg_cd,
-             g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd):
+             g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd, neg_is_mean=False):
     calls.append("corr_bwd")
     cfg = _cfg_from_desc(desc)
     f, fp = corr_fwd.stash
     S = desc.S
     gnl = None
     if g_neg_loss is not None and desc.n_neg:
-        gnl = np.broadcast_to(_np(g_neg_loss), (desc.n_neg * desc.B, S, S, S, S))
+        g = _np(g_neg_loss)
+        if neg_is_mean:                                   # upstream of the mean over all negative losses
+            g = g.reshape(()) / float(desc.n_neg * desc.B * S ** 4)
+        gnl = np.broadcast_to(g, (desc.n_neg * desc.B, S, S, S, S))
     dc, dcp = O.corr_loss_backward(
         f, fp, _np(code), _np(code_pos), _np(coords1), _np(coords2), list(_np(perms)) if desc.n_neg else [], cfg,
         0.0 if g_intra is None else float(g_intra), 0.0 if g_inter is None else float(g_inter), gnl,

@@ -221,3 +221,30 @@ def test_salience_coords_follow_the_reference_draw_order():
     assert torch.equal(c1, e1) and torch.equal(c2, e2)
     assert torch.equal(after, torch.rand(1))                     # generator left in the same state
     assert c1.min() >= -1 and c1.max() <= 1
+
+
+def test_means_and_total_api_equal_the_reference_composition(oracle_backed):
+    """ContrastiveCorrelationLoss.means() / .total(): the three loss means as one tensor (the forward kernel produces all of
+    them) and their weighted sum as one dot product == train_segmentation.py:176-181 on forward()'s outputs, values and
+    gradients, with the same draws."""
+    c = GoldenCase("small_default")
+    t = {k: torch.from_numpy(v) for k, v in c.inputs.items()}
+    loss_fn = M.ContrastiveCorrelationLoss(c.cfg)
+    code = t["code"].clone().requires_grad_(True)
+    code_pos = t["code_pos"].clone().requires_grad_(True)
+    torch.manual_seed(5)
+    out = loss_fn(t["feats"], t["feats_pos"], None, None, code, code_pos)
+    ref_total = 0.67 * out[0] + 0.25 * out[2] + 0.63 * out[4].mean()
+    ref_total.backward()
+    g1, g2 = code.grad.clone(), code_pos.grad.clone()
+    code.grad = None
+    code_pos.grad = None
+    torch.manual_seed(5)
+    total, means, icd, ecd, ncd = loss_fn.total(t["feats"], t["feats_pos"], None, None, code, code_pos, (0.67, 0.25, 0.63))
+    assert means.shape == (3,) and not means.requires_grad
+    assert_close(means.numpy(), np.array([float(out[0]), float(out[2]), float(out[4].mean())]), rtol=1e-5, what="means")
+    assert abs(float(total) - float(ref_total)) < 1e-6 * max(1.0, abs(float(ref_total)))
+    assert torch.equal(icd, out[1]) and torch.equal(ncd, out[5])
+    total.backward()
+    assert_close(code.grad.numpy(), g1.numpy(), rtol=1e-4, atol_frac=1e-5, what="d_code via total()")
+    assert_close(code_pos.grad.numpy(), g2.numpy(), rtol=1e-4, atol_frac=1e-5, what="d_code_pos via total()")

@@ -465,13 +465,11 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
     coords2 = torch.rand(4, 5, 5, 2, generator=g) * 2 - 1
     perms = torch.tensor([[1, 2, 3, 0], [2, 3, 0, 1]])
 
-    def patched_forward(loss_mod, dev):
-        def fwd(of, ofp, s1, s2, oc, ocp):
-            return loss_mod.forward_explicit(of, ofp, oc, ocp, coords1.to(dev), coords2.to(dev), perms.to(dev))
-        return fwd
+    def patched_draw(dev):            # (training_step goes through loss.total() -> loss.draw(): feed the same draws to both sides)
+        return lambda of, s1, s2: (coords1.to(dev), coords2.to(dev), perms.to(dev))
 
-    ref.contrastive_corr_loss_fn.forward = patched_forward(ref.contrastive_corr_loss_fn, "cpu")
-    dev_model.contrastive_corr_loss_fn.forward = patched_forward(dev_model.contrastive_corr_loss_fn, DEV)
+    ref.contrastive_corr_loss_fn.draw = patched_draw("cpu")
+    dev_model.contrastive_corr_loss_fn.draw = patched_draw(DEV)
     try:
         M._backend = oracle_backend
         loss_ref = ref.training_step(batch, 0)
@@ -651,7 +649,7 @@ def test_unprepared_entry_point_accepts_any_workspace_and_prepared_one_stays_cle
     f32 = dict(dtype=torch.float32, device=dev)
 
     def outs():
-        return [torch.empty(2, **f32), torch.empty(B, S ** 4, **f32), torch.empty(B, S ** 4, **f32), torch.empty(n_neg * B, S ** 4, **f32),
+        return [torch.empty(3, **f32), torch.empty(B, S ** 4, **f32), torch.empty(B, S ** 4, **f32), torch.empty(n_neg * B, S ** 4, **f32),
                 torch.empty(n_neg * B, S ** 4, **f32), torch.empty(7 * B, S ** 4, **f32), torch.empty(7, **f32),
                 torch.empty(lib.stego_corr_saved_ctx_bytes(by(desc)), dtype=torch.uint8, device=dev)]
     maps = [capi._map(d[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
@@ -750,3 +748,95 @@ def test_split_fp16_backward_error_stays_in_the_fp32_class():
         err[precision] = max(np.abs(r["d_code"] - dc).max() / np.abs(dc).max(), np.abs(r["d_code_pos"] - dcp).max() / np.abs(dcp).max())
     assert err["f16x3"] <= 2.0 * err["f32"] + 1e-6, err
     assert err["f16x3"] < 2e-5, err
+
+
+def _philox4x32_10(c, k):
+    """Philox-4x32-10 (Salmon et al., SC'11) in plain Python: the generator of stego_fast_draws."""
+    c = list(c)
+    k0, k1 = k
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xffffffff, p1 & 0xffffffff, ((p0 >> 32) ^ c[3] ^ k1) & 0xffffffff, p0 & 0xffffffff]
+        k0 = (k0 + 0x9E3779B9) & 0xffffffff
+        k1 = (k1 + 0xBB67AE85) & 0xffffffff
+    return c
+
+
+def test_fast_draws_kernel_is_philox_with_the_reference_distributions():
+    """cfg.fast_draws (opt-in): coords = 2 u - 1 with u on torch.rand's 2^-24 lattice from Philox-4x32-10 (known-answer vector
+    of Random123 + the kernel's counter layout checked against the Python restatement), perms = uniformly random permutations
+    with super_perm's fix-up (modules.py:307-311); deterministic in the seed; the loss accepts them like the torch draws."""
+    assert _philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]          # Random123 kat_vectors
+    assert _philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    dev = torch.device(DEV)
+    B, S, n_neg = 32, 11, 5
+    seed_val = 0x1234567890abcdef
+    seed = torch.tensor([seed_val - (1 << 64) if seed_val >= (1 << 63) else seed_val], dtype=torch.int64, device=dev)
+    c1, c2, perms = capi.fast_draws(seed, [B, S, S, 2], n_neg, B)
+    c1b, c2b, permsb = capi.fast_draws(seed, [B, S, S, 2], n_neg, B)
+    assert torch.equal(c1, c1b) and torch.equal(c2, c2b) and torch.equal(perms, permsb)
+    k = (seed_val & 0xffffffff, seed_val >> 32)
+    flat1, flat2 = c1.flatten().cpu().numpy(), c2.flatten().cpu().numpy()
+    for i4 in (0, 1, 7, 1000, flat1.size // 4 - 1):
+        a = _philox4x32_10([i4, 0, 0, 0], k)
+        b = _philox4x32_10([i4, 0, 0, 1], k)
+        for e in range(4):
+            assert flat1[4 * i4 + e] == np.float32(np.float32((a[e] >> 8) * 2.0 ** -24) * 2 - 1)
+            assert flat2[4 * i4 + e] == np.float32(np.float32((b[e] >> 8) * 2.0 ** -24) * 2 - 1)
+    assert float(c1.min()) >= -1 and float(c1.max()) < 1 and abs(float(c1.mean())) < 0.02 and abs(float(c1.var()) - 1 / 3) < 0.02
+    # permutations: rank of 64-bit keys, then perm[perm == arange] += 1; perm % B
+    pn = perms.cpu().numpy()
+    for n in range(n_neg):
+        keys = []
+        for i in range(B):
+            c = _philox4x32_10([i, 0, 1 + n, 2], k)
+            keys.append((c[0] << 32) | c[1])
+        order = np.argsort(np.array(keys, dtype=np.uint64), kind="stable")          # order[rank] = element
+        fixed = np.where(order == np.arange(B), order + 1, order) % B
+        assert np.array_equal(pn[n], fixed)
+        assert not (pn[n] == np.arange(B)).any()
+    other = capi.fast_draws(seed + 1, [B, S, S, 2], n_neg, B)
+    assert not torch.equal(other[0], c1) and not torch.equal(other[2], perms)
+    # the module path: forward() with cfg.fast_draws draws these and runs the fused loss
+    import bench
+    cfg = bench.Cfg()
+    cfg.fast_draws = True
+    C, H, W, K = bench.WORKLOADS["vits8_224"]
+    d = bench.make_inputs(8, C, H, W, K, S, n_neg, 3, dev)
+    code = d["code"].detach().clone().requires_grad_(True)
+    torch.manual_seed(11)
+    out = M.ContrastiveCorrelationLoss(cfg)(d["feats"], d["feats_pos"], None, None, code, d["code_pos"])
+    torch.manual_seed(11)
+    out2 = M.ContrastiveCorrelationLoss(cfg)(d["feats"], d["feats_pos"], None, None, code, d["code_pos"])
+    assert torch.equal(out[4], out2[4]) and torch.isfinite(out[4]).all()
+    (out[0] + out[2] + out[4].mean()).backward()
+    assert torch.isfinite(code.grad).all() and float(code.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("layout", ["cl", "nchw"])
+def test_total_api_on_device_equals_forward_composition(layout):
+    """loss_means[2] (the mean over all negative losses, from the forward launch itself: fused path and three-launch path) and the
+    mean-upstream backward (g_neg_loss_stride = -1) against forward() + .mean() + dense/broadcast upstreams, same draws."""
+    import bench
+    dev = torch.device(DEV)
+    cfg = bench.Cfg()
+    C, H, W, K = bench.WORKLOADS["vits8_224"]
+    d = bench.make_inputs(8, C, H, W, K, 11, 5, 9, dev, layout)
+    loss_fn = M.ContrastiveCorrelationLoss(cfg)
+    code = d["code"].detach().clone().requires_grad_(True)
+    code_pos = d["code_pos"].detach().clone().requires_grad_(True)
+    torch.manual_seed(21)
+    out = loss_fn(d["feats"], d["feats_pos"], None, None, code, code_pos)
+    ref = 0.67 * out[0] + 0.25 * out[2] + 0.63 * out[4].mean()
+    ref.backward()
+    g1, g2 = code.grad.clone(), code_pos.grad.clone()
+    code.grad = None
+    code_pos.grad = None
+    torch.manual_seed(21)
+    total, means, icd, ecd, ncd = loss_fn.total(d["feats"], d["feats_pos"], None, None, code, code_pos, (0.67, 0.25, 0.63))
+    assert abs(float(means[2]) - float(out[4].mean())) < 1e-6 * max(abs(float(out[4].mean())), 1e-3) + 1e-9
+    assert abs(float(total) - float(ref)) < 1e-5 * abs(float(ref)) + 1e-9
+    total.backward()
+    for got, want in ((code.grad, g1), (code_pos.grad, g2)):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())

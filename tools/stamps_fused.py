@@ -24,7 +24,7 @@ for prec in (capi.PREC_F16X3,):
         capi.debug_set("STEGO_DEBUG", dbg)
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
         f32 = dict(dtype=torch.float32, device=dev)
-        outs = [torch.empty(2, **f32), torch.empty(B, S**4, **f32), torch.empty(B, S**4, **f32),
+        outs = [torch.empty(3, **f32), torch.empty(B, S**4, **f32), torch.empty(B, S**4, **f32),
                 torch.empty(n_neg * B, S**4, **f32), torch.empty(n_neg * B, S**4, **f32),
                 torch.empty(7 * B, S**4, **f32), torch.empty(7, **f32)]
         nctx = lib.stego_corr_saved_ctx_bytes(byref(desc))
