@@ -372,3 +372,38 @@ def test_trainer_runs_validation_and_writes_a_loadable_checkpoint(tmp_path):
     m2 = LitUnsupervisedSegmenter.load_from_checkpoint(ck)
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2), k1
+
+
+def test_cropped_dataset_tree_round_trip(tmp_path):
+    """crop_datasets.py:76-123 / data.py:370-400: five crops per image under cropped/{ds}_{type}_crop_{ratio}/{img,label}/{split}/
+    {5 i + c}.{jpg,png}; labels stored + 1 (PNG, lossless), unlabelled -> mask."""
+    from stego_amd import data as D
+    g = torch.Generator().manual_seed(3)
+    items = []
+    for _ in range(3):
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, 40), torch.linspace(0, 1, 60), indexing="ij")
+        ph = torch.rand(3, 1, 1, generator=g)
+        img = (0.5 + 0.4 * torch.sin(6.0 * (xx + ph)) * torch.cos(4.0 * (yy + ph))).clamp(0, 1)      # smooth: JPEG keeps it
+        label = torch.randint(-1, 27, (40, 60), generator=g)
+        items.append((img, label))
+    n = D.write_cropped(str(tmp_path), "cocostuff27", "five", 0.5, "val", items)
+    assert n == 15
+    base = tmp_path / "cropped" / "cocostuff27_five_crop_0.5"
+    assert sorted(os.listdir(base / "img" / "val"), key=lambda s: int(s.split(".")[0])) == ["%d.jpg" % i for i in range(15)]
+    assert sorted(os.listdir(base / "label" / "val"), key=lambda s: int(s.split(".")[0])) == ["%d.png" % i for i in range(15)]
+    ds = D.CroppedDataset(str(tmp_path), "cocostuff27", "five", 0.5, "val")
+    assert len(ds) == 15
+    boxes = D.five_crop_boxes(40, 60, 20, 30)
+    assert boxes == [(0, 0), (0, 30), (20, 0), (20, 30), (10, 15)]
+    for idx in (0, 4, 7, 14):
+        image, target, mask = ds[idx]
+        src_img, src_label = items[idx // 5]
+        t, l = boxes[idx % 5]
+        assert image.shape == (3, 20, 30) and target.shape == (20, 30) and mask.shape == (1, 20, 30)
+        assert torch.equal(target, src_label[t:t + 20, l:l + 30])                       # PNG: exact
+        assert torch.equal(mask.squeeze(0), src_label[t:t + 20, l:l + 30] == -1)
+        assert float((image - src_img[:, t:t + 20, l:l + 30]).abs().mean()) < 0.02     # JPEG: lossy
+    D.write_cropped(str(tmp_path), "cocostuff27", "random", 0.5, "train", items[:1])
+    assert len(D.CroppedDataset(str(tmp_path), "cocostuff27", "random", 0.5, "train")) == 5
+    with pytest.raises(ValueError, match="Unknown crop type"):
+        D.write_cropped(str(tmp_path), "x", "center", 0.5, "val", items[:1])
