@@ -170,7 +170,7 @@ def _product_path(sets, cfg, args, kernel_step_s, total=False):
         graphs = []
         for i in range(n):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (RCCL's watchdog thread must not break a capture)
                 step(i)
             graphs.append(g)
         torch.cuda.synchronize()
