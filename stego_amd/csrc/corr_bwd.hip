@@ -1021,7 +1021,7 @@ hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
         const int nt = (prm.KQ + 15) / 16;
         // forward() semantics: split-fp16 GEMMs in F16X3 mode, and - whatever the mode - for code dimensions above 80, whose
         // fp32 operand images no longer fit LDS (the split kernel walks the channel tiles in two groups)
-        const bool split = prm.mode == 0 && !(prm.debug & 64) && (prm.precision == PREC_F16X3 || nt > 5);   // (debug 64: fp32 MFMA kernel)
+        const bool split = prm.mode == 0 && !(prm.debug & 512) && (prm.precision == PREC_F16X3 || nt > 5);  // (debug 512: fp32 MFMA kernel)
         const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
         const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride > 0);
         const int lds = split ? SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * cside + TP * LDG * 4;

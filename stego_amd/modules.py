@@ -138,6 +138,11 @@ def as_channels_last(t, min_numel=1 << 16):
     return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
 
 
+def _relayout_threshold(code):
+    """Code dimensions above 72 exist on the fused (channels-last) path only: such maps are always re-laid out, however small."""
+    return 0 if code.shape[1] > 72 else 1 << 16
+
+
 class _CorrLossFunction(torch.autograd.Function):
     """ContrastiveCorrelationLoss.forward as one op: stego_corr_fwd / stego_corr_bwd."""
 
@@ -145,9 +150,10 @@ class _CorrLossFunction(torch.autograd.Function):
     def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
         need_grad = bool(code.requires_grad or code_pos.requires_grad)
         ctx.set_materialize_grads(False)       # an output nobody differentiated costs no zero-fill and no loads in the backward
+        mn = _relayout_threshold(code)
         (loss_means, intra_cd, inter_cd, neg_loss, neg_cd, saved) = _backend.corr_fwd(
-            desc, as_channels_last(feats.detach()), as_channels_last(feats_pos.detach()),
-            as_channels_last(code.detach()), as_channels_last(code_pos.detach()), coords1, coords2, perms, need_grad)
+            desc, as_channels_last(feats.detach(), mn), as_channels_last(feats_pos.detach(), mn),
+            as_channels_last(code.detach(), mn), as_channels_last(code_pos.detach(), mn), coords1, coords2, perms, need_grad)
         ctx.desc = desc
         if need_grad:
             ctx.n_saved = len(saved)
@@ -176,9 +182,10 @@ class _CorrLossMeansFunction(torch.autograd.Function):
     def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
         need_grad = bool(code.requires_grad or code_pos.requires_grad)
         ctx.set_materialize_grads(False)
+        mn = _relayout_threshold(code)
         (loss_means, intra_cd, inter_cd, _neg_loss, neg_cd, saved) = _backend.corr_fwd(
-            desc, as_channels_last(feats.detach()), as_channels_last(feats_pos.detach()),
-            as_channels_last(code.detach()), as_channels_last(code_pos.detach()), coords1, coords2, perms, need_grad)
+            desc, as_channels_last(feats.detach(), mn), as_channels_last(feats_pos.detach(), mn),
+            as_channels_last(code.detach(), mn), as_channels_last(code_pos.detach(), mn), coords1, coords2, perms, need_grad)
         ctx.desc = desc
         if need_grad:
             ctx.save_for_backward(code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd, *saved)

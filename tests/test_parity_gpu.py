@@ -840,3 +840,13 @@ def test_total_api_on_device_equals_forward_composition(layout):
     total.backward()
     for got, want in ((code.grad, g1), (code_pos.grad, g2)):
         assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_randomised_shapes_against_the_oracle():
+    """tools/fuzz_fused.py as a regression test: 16 random shapes / cfg switches / layouts / precisions inside and outside the
+    fused path's domain, forward + backward against the fp64 oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "16", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "failures: 0", out.stdout[-3000:]

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the product path against the fp64 oracle: random shapes inside the fused path's domain (and a few
+outside it), forward + backward, both precisions.  usage: python tools/fuzz_fused.py [n_cases] [seed]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import corr_oracle as O
+from stego_amd import capi, modules as M
+from conftest import assert_close
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+bad = 0
+for case in range(n_cases):
+    n_neg = int(rng.integers(0, 6))
+    B = int(rng.integers(1, max(2, 256 // (2 + n_neg)) + 1))
+    B = min(B, int(os.environ.get("FUZZ_MAX_B", 12)))     # keep the fp64 oracle quick
+    C = int(rng.choice([384, 768, 384, 64]))
+    S = int(rng.integers(1, 12))
+    H, W = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    K = int(rng.integers(1, 65)) * 2 if C != 64 else int(rng.integers(1, 73))
+    if C == 64:
+        K = min(K, 72)
+    layout = "cl" if rng.random() < 0.8 else "nchw"
+    precision = "f16x3" if rng.random() < 0.6 else "f32"
+    precision = os.environ.get("FUZZ_PREC", precision)
+    cfgkw = dict(feature_samples=S, neg_samples=n_neg, pointwise=bool(rng.random() < 0.85), zero_clamp=bool(rng.random() < 0.8),
+                 stabalize=bool(rng.random() < 0.3))
+    dino = bool(rng.random() < 0.5)
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
+        continue
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=1000 + case, dino_like=dino)
+    cfg = O.CorrCfg(**cfgkw)
+    cfg.corr_precision = precision
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items()}
+    if layout == "cl":
+        for k in ("feats", "feats_pos", "code", "code_pos"):
+            t[k] = t[k].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    code = t["code"].detach().requires_grad_(True)
+    code_pos = t["code_pos"].detach().requires_grad_(True)
+    perms = torch.from_numpy(d["perms"]).to(dev) if n_neg else None
+    tag = dict(case=case, B=B, C=C, H=H, W=W, K=K, S=S, n_neg=n_neg, layout=layout, precision=precision, **{k: v for k, v in cfgkw.items() if k not in ("feature_samples", "neg_samples")})
+    try:
+        out = M.ContrastiveCorrelationLoss(cfg).forward_explicit(t["feats"], t["feats_pos"], code, code_pos, t["coords1"], t["coords2"], perms)
+        total = 0.67 * out[0] + 0.25 * out[2]
+        if n_neg:
+            total = total + 0.63 * out[4].mean()
+        total.backward()
+        torch.cuda.synchronize()
+        ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+        la = 5e-4
+        assert_close(out[1].detach().cpu().numpy(), ref.pos_intra_cd, atol_frac=la, what="intra_cd")
+        assert_close(out[3].detach().cpu().numpy(), ref.pos_inter_cd, atol_frac=la, what="inter_cd")
+        if n_neg:
+            assert_close(out[4].detach().cpu().numpy(), ref.neg_inter_loss, atol_frac=la, what="neg_loss")
+            assert_close(out[5].detach().cpu().numpy(), ref.neg_inter_cd, atol_frac=la, what="neg_cd")
+        sc = max(abs(float(ref.pos_intra_loss)), abs(float(ref.pos_inter_loss)), 1e-3)
+        assert abs(float(out[0]) - float(ref.pos_intra_loss)) < 1e-3 * sc, "intra mean"
+        assert abs(float(out[2]) - float(ref.pos_inter_loss)) < 1e-3 * sc, "inter mean"
+        numel = B * S ** 4
+        g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * numel)) if n_neg else None
+        dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+        # gradients: d loss / d cd jumps at the clamp bounds, so an element of cd within fp32 rounding of 0 / 0.8 may flip its mask
+        # against the fp64 oracle and move the ~4 K gradient entries of one sample point: tolerate 0.3 % such entries
+        for got, want, what in ((code.grad.cpu().numpy(), dc, "d_code"), (code_pos.grad.cpu().numpy(), dcp, "d_code_pos")):
+            want = np.asarray(want, dtype=np.float64)
+            tol = 1e-3 * np.abs(want).mean() + 1e-3 * np.abs(want)
+            frac = float((np.abs(got - want) > tol).mean())
+            assert frac <= 3e-3, "%s: %.4f %% of the entries off" % (what, 100 * frac)
+            assert np.abs(got - want).max() <= 0.2 * np.abs(want).max() + 1e-12, what
+        desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46))
+        tag["launches"] = capi.corr_fwd_launches(desc, M.as_channels_last(t["feats"]), M.as_channels_last(t["feats_pos"]),
+                                                 M.as_channels_last(t["code"]), M.as_channels_last(t["code_pos"]))
+        print("ok  ", tag, flush=True)
+    except RuntimeError as e:
+        if "unsupported" in str(e):
+            print("unsupported (by design)", tag, flush=True)
+        else:
+            bad += 1
+            print("FAIL", tag, repr(e)[:300], flush=True)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", tag, str(e)[:300], flush=True)
+print("failures:", bad)
