@@ -178,10 +178,12 @@ __device__ __forceinline__ void point_taps(const FusedParams& prm, const f32x2 c
     if (q < prm.P) make_taps(cxy[0], cxy[1], prm.H, prm.W, yx, w);
 }
 
-// Staging area of phase 1 (in the ring, which is idle then), rows = the points of this pass in image order:
-//   features [stage s2][plane][ROWS][row bytes]   (H: 2 planes of 64-byte rows, F: 1 plane of 128-byte rows)
-//   codes, ring format F [stage][ROWS][128 B]     (operand of the forward)
-//   codes, context rows  [ROWS][LDK floats]       (what the backward reads)
+// Staging area of phase 1, rows = the points of this pass in image order.  Phase 1 belongs to the MFMA team (round 2b): the gather
+// team fills the B sides of the four ring slots meanwhile, so the staging lives in the four A sides (16 KB pieces, RS_STAGE apart),
+// which nothing touches before the team's first LDS-DMA:
+//   pieces 0-1: features [stage s2][plane][ROWS][row bytes]   (H: 2 planes of 64-byte rows, F: 1 plane of 128-byte rows)
+//   piece 2:    codes, ring format F [stage][ROWS][128 B]     (operand of the forward)
+//   piece 3:    codes, context rows  [ROWS][LDK floats]       (what the backward reads)
 // so that every plane leaves as ONE contiguous run per anchor (scattered sc1 stores straight from the registers ran at
 // 0.4 TB/s chip-wide: 22 us for 8.6 MB).
 template <int NJ, int PREC>
@@ -189,19 +191,29 @@ struct P1Layout {
     static constexpr int NCH2 = 4 * NJ;
     static constexpr int PLANES = PREC == PREC_F16X3 ? 2 : 1;
     static constexpr int RB = PREC == PREC_F16X3 ? 64 : 128;
+    static constexpr int G = NJ <= 3 ? 2 : 1;                  // points per half-wave and pass (register budget: 48 NJ G)
+    static constexpr int ROWS = 4 * 2 * G;                     // rows of a pass: four waves
+    static constexpr int STAGE_BYTES = ROWS * 128;             // one feature stage of a pass (either format)
+    static constexpr int SPP = RS_SIDE / STAGE_BYTES;          // feature stages per piece
+    static_assert(NCH2 <= 2 * SPP, "feature stages fit pieces 0-1");
+    static_assert(4 * ROWS * 128 <= RS_SIDE && ROWS * (128 + 4) * 4 <= RS_SIDE, "code stages fit piece 2, context rows piece 3");
+    static constexpr int CF = 2 * RS_STAGE;
+    static constexpr int CX = 3 * RS_STAGE;
+    __device__ static __forceinline__ int feat_plane(int s2, int pp) { return (s2 / SPP) * RS_STAGE + (s2 % SPP) * STAGE_BYTES + pp * ROWS * RB; }
 };
 
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
-// staging area.  ROWS = rows per pass of the staging area.
-template <int NJ, int PREC, int G>
-__device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int ROWS, int lane,
+// staging area.
+template <int NJ, int PREC, int NKCT>
+__device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane,
                                                unsigned char* lds, unsigned long long* tsd)
 {
     typedef P1Layout<NJ, PREC> LY;
+    constexpr int G = LY::G, ROWS = LY::ROWS;
     const int hl = lane & 31, hw = lane >> 5;
     const int crow = prm.LDK * 4;
-    unsigned char* lds_cf = lds + LY::NCH2 * LY::PLANES * ROWS * LY::RB;
-    unsigned char* lds_cx = lds_cf + prm.NKC * ROWS * 128;
+    unsigned char* lds_cf = lds + LY::CF;
+    unsigned char* lds_cx = lds + LY::CX;
     const MapV mf = prm.feats, mc = prm.code;
     int4 yx[G];
     float4 w[G];
@@ -238,23 +250,27 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         for (int j = 0; j < NJ; ++j) {       // inactive points re-read pixel (0,0) of a valid image: harmless
             t[g][j][0] = p0[32 * j]; t[g][j][1] = p1[32 * j]; t[g][j][2] = p2[32 * j]; t[g][j][3] = p3[32 * j];
         }
+    }
+    auto code_loads = [&](int g) {
         const int4 oc = taps_to_offsets(yx[g], mc.sh, mc.sw);
         const float* cimg = mc.p + (long long)ba[g] * mc.sn;
         ct[g].a[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c0);
         ct[g].a[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c0);
         ct[g].a[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c0);
         ct[g].a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
-        if (prm.K > 64) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
+        // (K > 64 needs three K-chunks, K > 96 four: the registers of the unused groups do not exist)
+        if constexpr (NKCT > 2) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
         else { ct[g].b[0] = ct[g].b[1] = ct[g].b[2] = ct[g].b[3] = 0.f; }
-        if (prm.K > 96) { ct[g].c[0] = cimg[oc.x + c2]; ct[g].c[1] = cimg[oc.y + c2]; ct[g].c[2] = cimg[oc.z + c2]; ct[g].c[3] = cimg[oc.w + c2]; }
+        if constexpr (NKCT > 3) { ct[g].c[0] = cimg[oc.x + c2]; ct[g].c[1] = cimg[oc.y + c2]; ct[g].c[2] = cimg[oc.z + c2]; ct[g].c[3] = cimg[oc.w + c2]; }
         else { ct[g].c[0] = ct[g].c[1] = ct[g].c[2] = ct[g].c[3] = 0.f; }
-    }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) code_loads(g);
     if (tsd) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tsd[1] = __builtin_amdgcn_s_memrealtime();
     }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
+    auto feat_part = [&](int g) {
         const int lr = lr0 + 2 * g + hw;                          // row inside the staging area
         const int qq = q[g];
         const bool valid = act[g] && qq < prm.P;
@@ -279,7 +295,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
             if constexpr (PREC == PREC_F32) {
                 const int c = 128 * j + 4 * hl;
                 const int u = ((c & 31) >> 2) ^ ((qq >> 1) & 7);
-                *reinterpret_cast<f32x4*>(lds + ((c >> 5) * ROWS + lr) * 128 + u * 16) = vn;
+                *reinterpret_cast<f32x4*>(lds + LY::feat_plane(c >> 5, 0) + lr * 128 + u * 16) = vn;
             } else {
                 unsigned h0, l0, h1, l1;
                 split_f16_pair(vn[0], vn[1], h0, l0);
@@ -290,9 +306,15 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
                 const u32x4 d = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
                 const int c = 128 * j + 4 * (hl & ~1);
                 const int u = ((c & 31) >> 3) ^ ((qq >> 2) & 3);
-                *reinterpret_cast<u32x4*>(lds + (((c >> 5) * 2 + (odd ? 1 : 0)) * ROWS + lr) * 64 + u * 16) = d;
+                *reinterpret_cast<u32x4*>(lds + LY::feat_plane(c >> 5, odd ? 1 : 0) + lr * 64 + u * 16) = d;
             }
         }
+    };
+    auto code_part = [&](int g) {
+        const int lr = lr0 + 2 * g + hw;
+        const int qq = q[g];
+        const bool valid = act[g] && qq < prm.P;
+        const float4 wg = w[g];
         // ---- code: normalised; once as K-chunk operand stages (forward), once as a context row (backward)
         f32x2 r0 = wg.x * ct[g].a[0] + wg.y * ct[g].a[1] + wg.z * ct[g].a[2] + wg.w * ct[g].a[3];
         float r1 = wg.x * ct[g].b[0] + wg.y * ct[g].b[1] + wg.z * ct[g].b[2] + wg.w * ct[g].b[3];
@@ -310,62 +332,75 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         r2 = r2 * cinv;
         const int kall = prm.NKC * prm.kper;
         if (2 * hl < kall) {
-            const int k = 2 * hl, sc = k / prm.kper, col = k - sc * prm.kper;
+            const int k = 2 * hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<f32x2*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r0;
         }
         if (64 + hl < kall) {
-            const int k = 64 + hl, sc = k / prm.kper, col = k - sc * prm.kper;
+            const int k = 64 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r1;
         }
         if (2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(lds_cx + lr * crow + 8 * hl) = r0;
         if (64 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (64 + hl)) = r1;
         if (96 + hl < kall) {
-            const int k = 96 + hl, sc = k / prm.kper, col = k - sc * prm.kper;
+            const int k = 96 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r2;
         }
         if (96 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (96 + hl)) = r2;
         if (act[g] && hl == 0) prm.nrm[(size_t)ba[g] * TP + qq] = nr;
-    }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) feat_part(g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) code_part(g);
 }
 
 // Writes staged rows [row0, row0 + nrows) (global point index blk0 + row) out: the planes `first`, `first + step`, ...
 // of the plane list {feature planes, code stages, context} by this wave, 16 bytes per lane, write-through.
 template <int NJ, int PREC>
-__device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int blk0, int row0, int nrows, int ROWS, int first,
+__device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int blk0, int row0, int nrows, int first,
                                             int step, int lane, const unsigned char* lds, __amdgpu_buffer_rsrc_t fs_rsrc,
                                             __amdgpu_buffer_rsrc_t csf_rsrc, __amdgpu_buffer_rsrc_t cs_rsrc)
 {
     typedef P1Layout<NJ, PREC> LY;
-    constexpr int NFP = LY::NCH2 * LY::PLANES;
+    constexpr int NFP = LY::NCH2 * LY::PLANES, ROWS = LY::ROWS;
     const int crow = prm.LDK * 4;
-    const unsigned char* lds_cf = lds + NFP * ROWS * LY::RB;
-    const unsigned char* lds_cx = lds_cf + prm.NKC * ROWS * 128;
+    const unsigned char* lds_cf = lds + LY::CF;
+    const unsigned char* lds_cx = lds + LY::CX;
     const int nplanes = NFP + prm.NKC + 1;
-    for (int pl = first; pl < nplanes; pl += step) {
-        int rb;                         // bytes per row of this plane
-        const unsigned char* src;
-        if (pl < NFP) { rb = LY::RB; src = lds + pl * ROWS * LY::RB; }
-        else if (pl < NFP + prm.NKC) { rb = 128; src = lds_cf + (pl - NFP) * ROWS * 128; }
-        else { rb = crow; src = lds_cx; }
-        const int upr = rb >> 4;
-        for (int u = lane; u < nrows * upr; u += 64) {
-            const int row = row0 + u / upr, within = u % upr;
-            const int idx = blk0 + row;
-            const int set = xa + 8 * (idx >> 7), qq = idx & (TP - 1);
-            const u32x4 d = *reinterpret_cast<const u32x4*>(src + row * rb + within * 16);
-            if (pl < NFP) {
-                const int s2 = pl / LY::PLANES, pp = pl - s2 * LY::PLANES;
-                const unsigned off = (unsigned)(((size_t)set * LY::NCH2 + s2) * RS_SIDE + pp * 8192 + qq * LY::RB + within * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(d, fs_rsrc, off, 0, 16);
-            } else if (pl < NFP + prm.NKC) {
-                const unsigned off = (unsigned)(((size_t)set * prm.NKC + (pl - NFP)) * RS_SIDE + qq * 128 + within * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(d, csf_rsrc, off, 0, 16);
-            } else {
-                const unsigned off = (unsigned)(((size_t)set * TP + qq) * crow + within * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(d, cs_rsrc, off, 0, 16);
-            }
-        }
+    // all rows of a call belong to one anchor (the caller splits a pass at an anchor boundary)
+    const int set = xa + 8 * ((blk0 + row0) >> 7), q0 = (blk0 + row0) & (TP - 1);
+    int pl = first;
+    for (; pl < NFP; pl += step) {                                   // feature planes: 16-byte units, a power of two per row
+        constexpr int UPR = LY::RB / 16;
+        const int s2 = pl / LY::PLANES, pp = pl - s2 * LY::PLANES;
+        const unsigned char* src = lds + LY::feat_plane(s2, pp) + row0 * LY::RB;
+        const unsigned base = (unsigned)(((size_t)set * LY::NCH2 + s2) * RS_SIDE + pp * 8192 + q0 * LY::RB);
+        for (int u = lane; u < nrows * UPR; u += 64)                 // (staged rows are contiguous, and so is the run they leave as)
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), fs_rsrc, base + u * 16, 0, 16);
     }
+    for (; pl < NFP + prm.NKC; pl += step) {                         // code operand stages: 128-byte rows
+        const unsigned char* src = lds_cf + ((pl - NFP) * ROWS + row0) * 128;
+        const unsigned base = (unsigned)(((size_t)set * prm.NKC + (pl - NFP)) * RS_SIDE + q0 * 128);
+        for (int u = lane; u < nrows * 8; u += 64)
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), csf_rsrc, base + u * 16, 0, 16);
+    }
+    if (pl < nplanes) {                                              // context rows (LDK floats: whole 16-byte units)
+        const unsigned char* src = lds_cx + row0 * crow;
+        const unsigned base = (unsigned)(((size_t)set * TP + q0) * crow);
+        for (int u = lane; u < (nrows * crow) >> 4; u += 64)
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), cs_rsrc, base + u * 16, 0, 16);
+    }
+}
+
+// Barrier of a team of waves inside the workgroup, through an LDS counter that only grows (s_barrier would take in the waves of
+// the other team): everything this wave did in LDS before is visible to whoever sees the count (the LDS executes a wave's
+// operations in order).  `target` = waves x (barriers so far).
+__device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned target, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
 }
 
 // publish `n` finished points starting at flat index `first` of the list "anchors xa, xa + 8, ..." (one lane)
@@ -473,6 +508,77 @@ struct GSet {
     f32x4 tv[GI][4];         // [item][tap]
 };
 
+// ------------------------------------------------------------------------------------------ the last workgroup of the launch
+// The three scalars and the saved means from the per-tile sums in image order (modules.py:331,393,395):
+//   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
+// tiles whose rendezvous gave up (applied == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
+// same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
+__device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, float* Tfd, int tid, int n_tiles)
+{
+    const int B = prm.B, P2 = prm.P * prm.P;
+    const float cmin = prm.cmin, cmax = prm.cmax;
+    unsigned long long* gst = prm.gran + n_tiles;                  // [n_tiles][3]: sum lp, sum clamp, old_mean applied
+    float* sst = Tfd;                            // [n_tiles][4] staged copy of the sums (the ring is dead)
+    float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS) {
+            const int t = i >> 2, k = i & 3;
+            const unsigned long long* src = k == 0 ? prm.gran + t : gst + (size_t)t * 3 + (k - 1);
+            unsigned long long x;
+            for (;;) {
+                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((x >> 32) == 1ull) break;
+                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sst[i] = __builtin_bit_cast(float, (unsigned)x);
+        }
+    }
+    __syncthreads();
+    const float inv_cnt = 1.f / ((float)B * (float)P2);
+    if (tid < prm.n_sets) {
+        float fsum = 0.f, lsum = 0.f, csum = 0.f;
+        for (int bb = 0; bb < B; ++bb) {
+            const float* st = sst + ((size_t)tid * B + bb) * 4;
+            fsum += st[0]; lsum += st[1]; csum += st[2];
+        }
+        const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
+        som[tid] = fsum * inv_cnt;
+        som[prm.n_sets + tid] = lsum - omp * csum;                 // sum of this pair-set's loss
+        if (prm.saved_mean) prm.saved_mean[tid] = omp;
+        if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {                              // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
+        float nsum = 0.f;
+        for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
+        prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
+    }
+    // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
+    bool mine = false;
+    for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;
+    if (prm.pointwise && __syncthreads_or(mine)) {
+        for (int t = 2 * B; t < n_tiles; ++t) {
+            if (sst[t * 4 + 3] != 0.f) continue;                   // (workgroup-uniform)
+            const float omp = som[t / B];
+            float* lossr = prm.neg_loss + (size_t)(t - 2 * B) * P2;
+            const float* cdr = prm.neg_cd + (size_t)(t - 2 * B) * P2;
+            for (int e = tid; e < P2; e += FUSED_THREADS) {
+                const float cdv = __hip_atomic_load(cdr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float lpv = __hip_atomic_load(lossr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float cl = fminf(fmaxf(cdv, cmin), cmax);
+                lossr[e] = __builtin_fmaf(-omp, cl, lpv);
+            }
+        }
+    }
+    for (int i = tid; i < B; i += FUSED_THREADS)
+        __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
+        __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------ the kernel
 template <int PREC, int NJ, int NKCT>
 __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedParams prm)
@@ -505,13 +611,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     const int n_tiles = prm.n_sets * B;
 
     unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.stats + (size_t)n_tiles * 4 + 256) + (size_t)me * 16;
-    const bool stamp_on = (prm.debug & 256) && tid == 0;
+    const bool helper = me >= n_tiles;           // no tile: phase 1 only (the launch covers every CU)
+    const bool stamp_on = (prm.debug & 256) && tid == 0 && !helper;
     if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
 #ifdef STEGO_FUSED_TIMELINE
     // (tools/timeline_fused.py builds with -DSTEGO_FUSED_TIMELINE) per-stage timeline of wave 0 (MFMA team) and wave 4
     // (gather team), 4 stamps per stage each; enabled at run time by debug bit 512
     unsigned long long* tl = reinterpret_cast<unsigned long long*>(prm.stats + (size_t)n_tiles * 4 + 256) + (size_t)n_tiles * 16 + (size_t)me * 128 + (mfma_team ? 0 : 64);
-    const bool tl_on = (prm.debug & 512) && (tid == 0 || tid == 256);
+    const bool tl_on = (prm.debug & 512) && (tid == 0 || tid == 256) && !helper;
 #define TL(n, k) do { if (tl_on && (n) < 16) tl[(n) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TL(n, k) do { } while (0)
@@ -521,73 +628,77 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     const __amdgpu_buffer_rsrc_t csf_rsrc = __builtin_amdgcn_make_buffer_rsrc(prm.csf, 0, prm.csf_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t cs_rsrc = __builtin_amdgcn_make_buffer_rsrc(prm.cs, 0, prm.cs_bytes, 0x00020000);
 
-    int pref0[ASSIGN_NB];
-    assign_prefetch(prm, lane, pref0);           // (perms loads in flight under phase 1)
+    // ---- hand-off words inside the workgroup (LDS comes up with whatever the previous workgroup left)
+    int* tile_slot = reinterpret_cast<int*>(red + 56);
+    unsigned* team_cnt = reinterpret_cast<unsigned*>(red + 57);
+    float* fin = red + 48;                       // [0] 1 = I am the last workgroup
+    if (tid == 0) { tile_slot[0] = -1; team_cnt[0] = 0u; }
+    __syncthreads();
 
-    // ---- phase 1 (all waves): my share of the anchor sets of my XCD, 2 points per wave and pass
-    constexpr int G1 = 1;
-    constexpr int P1ROWS = FUSED_WAVES * 2 * G1;
-    // Which tile am I: the LAST wave works it out (ballots over perms, ~1.3 us) while the others sample - with ~18 anchor rows
-    // per workgroup and two rows per wave it has none of its own - and leaves it in LDS behind phase 1's barriers.
-    float* tile_slot = red + 56;
-    const bool p1_here = me < prm.n_owner && !(prm.debug & 64);
-    if (p1_here && wave8 == FUSED_WAVES - 1) {
-        const int t = assign_tile(prm, me, lane, pref0);
-        if (lane == 0) tile_slot[0] = __builtin_bit_cast(float, t);
-        // ... and the tap table of the tile's B points (two per lane) for the whole gather team: its coordinate round trip is
-        // off the team's critical path (the first four B stages, which the MFMA team waits for)
-        const int tb = t % B, tp = t / B;
-        if (tp != 0) {
-            const MapV mf = tp == 1 ? prm.feats_pos : prm.feats;
-            const int tsB = tp * B + tb;
-            f32x2 cxy[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                cxy[h] = *reinterpret_cast<const f32x2*>(prm.coords2 + (size_t)tb * P * 2 + coord_index(prm, lane + 64 * h));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q = lane + 64 * h;
-                int4 yx;
-                float4 w;
-                point_taps(prm, cxy[h], q, yx, w);
-                tapof[q] = taps_to_offsets(yx, mf.sh, mf.sw);
-                tapoc[q] = yx;                                      // (y << 16 | x) of the four taps: code offsets are rebuilt from it
-                tapw[q] = w;
-                prm.tapyx[(size_t)tsB * TP + q] = yx;               // saved context of the backward
-                prm.tapw[(size_t)tsB * TP + q] = w;
-            }
-        }
-    }
-    if (p1_here) {     // (debug 64: nobody samples, every tile takes the give-up path)
+    // ---- phase 1 (the MFMA team, 4 waves): my share of the anchor sets of my XCD, 2 G points per wave and pass.  The team
+    // syncs through an LDS counter, not s_barrier: the gather team is not part of it - it works out the tile, builds its tap
+    // table and fills the B sides of the first four ring slots meanwhile (none of which needs an anchor).
+    const bool p1_here = me < prm.n_owner && !(prm.debug & 64);       // (debug 64: nobody samples, every tile takes the give-up path)
+    if (mfma_team && p1_here) {
         const int x = me & 7, r = me >> 3;
         const int nb = x < B ? (B - x + 7) >> 3 : 0;
         const int nslot = (prm.n_owner - x + 7) >> 3;
         const long long L = (long long)nb * TP;
         const int beg = (int)(L * r / nslot), end = (int)(L * (r + 1) / nslot);
-        if (beg >= end) __syncthreads();             // (no rows here: still publish the last wave's tile to the others)
-        for (int blk0 = beg; blk0 < end; blk0 += P1ROWS) {
-            if (blk0 + 2 * G1 * wave8 < end)         // (a wave without rows in this pass goes straight to the barrier)
-                p1_sample_rows<NJ, PREC, G1>(prm, x, blk0, end, 2 * G1 * wave8, P1ROWS, lane, ring, stamp_on ? ts + 8 : nullptr);
-            __syncthreads();
-            const int nrows = min(P1ROWS, end - blk0);
+        unsigned epoch = 0;
+        // the team shares its SIMDs with two gather waves each, and everybody's anchors wait for it: it goes first
+        __builtin_amdgcn_s_setprio(3);
+        for (int blk0 = beg; blk0 < end; blk0 += LY::ROWS) {
+            if (blk0 + 2 * LY::G * wave < end)       // (a wave without rows in this pass goes straight to the barrier)
+                p1_sample_rows<NJ, PREC, NKCT>(prm, x, blk0, end, 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
+            if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
+            epoch += 4;
+            team_barrier(team_cnt, epoch, lane);
+            if (stamp_on) ts[13] = __builtin_amdgcn_s_memrealtime();
+            const int nrows = min(LY::ROWS, end - blk0);
             // a run must stay inside one anchor: split the pass at an anchor boundary
             const int to_edge = (((blk0 >> 7) + 1) << 7) - blk0;
             const int n0 = min(nrows, to_edge);
-            p1_copy_out<NJ, PREC>(prm, x, blk0, 0, n0, P1ROWS, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
-            if (n0 < nrows) p1_copy_out<NJ, PREC>(prm, x, blk0, n0, nrows - n0, P1ROWS, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+            p1_copy_out<NJ, PREC>(prm, x, blk0, 0, n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+            if (n0 < nrows) p1_copy_out<NJ, PREC>(prm, x, blk0, n0, nrows - n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
             if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have landed
-            __syncthreads();
+            if (stamp_on) ts[14] = __builtin_amdgcn_s_memrealtime();
+            epoch += 4;
+            team_barrier(team_cnt, epoch, lane);
             if (tid == 0) p1_publish(prm, x, blk0, nrows);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
+    if (helper) {
+        // a workgroup without a tile (the CUs the tiles leave free): phase 1 was all; it still takes a ticket, because the
+        // LAST ticket is what says that nobody will touch the hand-off words of this launch any more
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (fin[0] != 0.f) last_workgroup_tail(prm, Tfd, tid, n_tiles);
+        return;
+    }
 
-    // ---- which tile am I
+    // ---- which tile am I: the first gather wave works it out (ballots over perms, ~1.3 us), everybody else picks it up from LDS
     int tile;
-    if (p1_here) tile = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tile_slot[0]));
-    else tile = assign_tile(prm, me, lane, pref0);       // (every wave for itself: no barrier before the teams part ways)
-    if (stamp_on) ts[6] = __builtin_amdgcn_s_memrealtime();
+    if (wave8 == 4) {
+        int pref0[ASSIGN_NB];
+        assign_prefetch(prm, lane, pref0);
+        tile = assign_tile(prm, me, lane, pref0);
+        if (lane == 0) __hip_atomic_store(tile_slot, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((prm.debug & 256) && lane == 0) ts[6] = __builtin_amdgcn_s_memrealtime();
+    } else {
+        for (;;) {
+            tile = __hip_atomic_load(tile_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tile >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        tile = __builtin_amdgcn_readfirstlane(tile);
+    }
     const int b = tile % B, p = tile / B;
     const bool sameAB = p == 0;
     const int sA = b;
@@ -622,17 +733,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 const unsigned c = __hip_atomic_load(prm.anchor_cnt + (size_t)sA * ANCHOR_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_readfirstlane(c) >= (unsigned)TP) { ready = true; break; }
                 if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
-                __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_s_sleep(10);
             }
             if (!ready) {
                 // The owners did not show up in time (not co-resident: a shared or over-subscribed device).  Sample the
-                // whole anchor here, this wave alone (staging in ring slots 2-3, which nothing touches before B(0)):
+                // whole anchor here, this wave alone (staging in the A sides, which nothing touches before my own LDS-DMA below):
                 // identical inputs give identical bytes, so racing with a late owner is benign; nothing else in the
                 // launch depends on the counter being exact.
-                unsigned char* solo = ring + 2 * RS_STAGE;
-                for (int q0 = 0; q0 < TP; q0 += 2 * G1) {
-                    p1_sample_rows<NJ, PREC, G1>(prm, sA, q0, TP, 0, 2 * G1, lane, solo, nullptr);
-                    p1_copy_out<NJ, PREC>(prm, sA, q0, 0, 2 * G1, 2 * G1, 0, 1, lane, solo, fs_rsrc, csf_rsrc, cs_rsrc);
+                for (int q0 = 0; q0 < TP; q0 += 2 * LY::G) {
+                    p1_sample_rows<NJ, PREC, NKCT>(prm, sA, q0, TP, 0, lane, ring, nullptr);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    p1_copy_out<NJ, PREC>(prm, sA, q0, 0, 2 * LY::G, 0, 1, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 }
             }
             if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
@@ -697,8 +808,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         float ss[GI], bsc[GI], ssc[GI];
 #pragma unroll
         for (int j = 0; j < GI; ++j) { ss[j] = 0.f; bsc[j] = 0.f; ssc[j] = 0.f; }
-        if (!p1_here && lane < 8 * GI) {
-            // (only without phase 1 here: otherwise the last wave built the whole table before phase 1's barriers)
+        if (lane < 8 * GI) {
             // tap table of the B points: every wave computes the 8 GI entries it reads itself (no barrier needed)
             const int q = GP * (lane >> 3) + 8 * gwave + (lane & 7);
             const f32x2 cxy = *reinterpret_cast<const f32x2*>(coordsB + coord_index(prm, q));
@@ -849,6 +959,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         // of ONE round trip: three stages in flight at once (a third register set that only lives here), the fourth
         // behind the first commit.  None of this depends on the anchor, so it runs while the MFMA team still waits for it.
         static_assert(NT >= 8, "the static head covers the code chunks and the first feature stages");
+        const bool gstamp = (prm.debug & 256) && tid == NTHREADS;
+        if (gstamp) ts[15] = __builtin_amdgcn_s_memrealtime();
         {
             GSet gc;
             issue(ga, 0);
@@ -860,6 +972,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             commit(gc, 2);
             commit(ga, 3);
         }
+        if (gstamp) ts[11] = __builtin_amdgcn_s_memrealtime();
         // after B(n): commit stage n + 2 (gathered two barriers ago; the head did it for n < 2), then re-issue its registers
         // for stage n + 4 (interleaving the two item by item was measured slower).  Stages alternate between the sets.
 #pragma unroll
@@ -1067,7 +1180,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     // ---- my sums as {tag, value} granules, then one ticket, WITHOUT waiting for the stores in between (a store-ack round
     // trip per workgroup at the very end of the launch): the LAST workgroup of the launch finishes the job below and polls
     // the granules it needs - by then they have been in flight for at least an atomic's round trip.
-    float* fin = red + 48;                       // [0] 1 = I am the last workgroup
     unsigned long long* gst = prm.gran + n_tiles;                  // [n_tiles][3]: sum lp, sum clamp, old_mean applied
     if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
@@ -1077,76 +1189,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, omv[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fin[0] = t == (unsigned)(n_tiles - 1) ? 1.f : 0.f;
+        fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
     }
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (fin[0] == 0.f) return;
 
-    // ================================================================= the last workgroup of the launch
-    // The three scalars and the saved means from the per-tile sums in image order (modules.py:331,393,395):
-    //   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
-    // tiles whose rendezvous gave up (applied == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
-    // same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
-    float* sst = Tfd;                            // [n_tiles][4] staged copy of the sums (the ring is dead)
-    float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set
-    {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS) {
-            const int t = i >> 2, k = i & 3;
-            const unsigned long long* src = k == 0 ? prm.gran + t : gst + (size_t)t * 3 + (k - 1);
-            unsigned long long x;
-            for (;;) {
-                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((x >> 32) == 1ull) break;
-                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            sst[i] = __builtin_bit_cast(float, (unsigned)x);
-        }
-    }
-    __syncthreads();
-    const float inv_cnt = 1.f / ((float)B * (float)P2);
-    if (tid < prm.n_sets) {
-        float fsum = 0.f, lsum = 0.f, csum = 0.f;
-        for (int bb = 0; bb < B; ++bb) {
-            const float* st = sst + ((size_t)tid * B + bb) * 4;
-            fsum += st[0]; lsum += st[1]; csum += st[2];
-        }
-        const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
-        som[tid] = fsum * inv_cnt;
-        som[prm.n_sets + tid] = lsum - omp * csum;                 // sum of this pair-set's loss
-        if (prm.saved_mean) prm.saved_mean[tid] = omp;
-        if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
-    }
-    __syncthreads();
-    if (tid == 0) {                              // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
-        float nsum = 0.f;
-        for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
-        prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
-    }
-    // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
-    bool mine = false;
-    for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;
-    if (prm.pointwise && __syncthreads_or(mine)) {
-        for (int t = 2 * B; t < n_tiles; ++t) {
-            if (sst[t * 4 + 3] != 0.f) continue;                   // (workgroup-uniform)
-            const float omp = som[t / B];
-            float* lossr = prm.neg_loss + (size_t)(t - 2 * B) * P2;
-            const float* cdr = prm.neg_cd + (size_t)(t - 2 * B) * P2;
-            for (int e = tid; e < P2; e += FUSED_THREADS) {
-                const float cdv = __hip_atomic_load(cdr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float lpv = __hip_atomic_load(lossr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float cl = fminf(fmaxf(cdv, cmin), cmax);
-                lossr[e] = __builtin_fmaf(-omp, cl, lpv);
-            }
-        }
-    }
-    for (int i = tid; i < B; i += FUSED_THREADS)
-        __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
-        __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_workgroup_tail(prm, Tfd, tid, n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch
@@ -1186,15 +1235,15 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     FusedParams prm = prm_in;
     const int n_tiles = prm.n_sets * prm.B;
     const int cus = device_cu_count();
-    prm.n_owner = n_tiles < (cus & ~7) ? n_tiles : (cus & ~7);
-    if (prm.n_owner < 1) prm.n_owner = 1;
+    prm.n_owner = (cus & ~7) < 8 ? 8 : (cus & ~7);
     prm.timeout_ticks = (prm.debug & 64) ? 100 : 20000;           // 200 us of the 100 MHz clock
     const int lds = RING_LDS_BYTES;
     hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (!prepared && (e = prepare_corr_fused(prm, sync_bytes, stream)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    const dim3 grid(n_tiles), block(FUSED_THREADS);
+    // every CU gets a workgroup: those beyond the tiles only help with phase 1 (the tiles' own MFMA teams do the rest of it)
+    const dim3 grid(n_tiles > prm.n_owner ? n_tiles : prm.n_owner), block(FUSED_THREADS);
 #define STEGO_FUSED_LAUNCH(PR, N, NK)                                                                  \
     do {                                                                                               \
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK>), lds);     \
