@@ -651,10 +651,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         for (int blk0 = beg; blk0 < end; blk0 += LY::ROWS) {
             if (blk0 + 2 * LY::G * wave < end)       // (a wave without rows in this pass goes straight to the barrier)
                 p1_sample_rows<NJ, PREC, NKCT>(prm, x, blk0, end, 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
-            if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
             epoch += 4;
             team_barrier(team_cnt, epoch, lane);
-            if (stamp_on) ts[13] = __builtin_amdgcn_s_memrealtime();
             const int nrows = min(LY::ROWS, end - blk0);
             // a run must stay inside one anchor: split the pass at an anchor boundary
             const int to_edge = (((blk0 >> 7) + 1) << 7) - blk0;
@@ -663,7 +661,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             if (n0 < nrows) p1_copy_out<NJ, PREC>(prm, x, blk0, n0, nrows - n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
             if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have landed
-            if (stamp_on) ts[14] = __builtin_amdgcn_s_memrealtime();
             epoch += 4;
             team_barrier(team_cnt, epoch, lane);
             if (tid == 0) p1_publish(prm, x, blk0, nrows);
@@ -1063,7 +1060,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         if (lane == 0) red[wave] = s;
+        if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
+        if (stamp_on) ts[13] = __builtin_amdgcn_s_memrealtime();
         park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
+        if (stamp_on) ts[14] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();                             // E1: Tfd and the four partial sums are complete
     if (tid == 0) {
@@ -1075,7 +1075,77 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     float* omv = red + 8;                        // [0] old_mean, [1] applied
     if (mfma_team) {
         park_flat(accc, Tcd + a, P, cscc, lane, wr, wc);
-        if (wave == 0) {
+    } else {
+        // row means of fd (fd.mean([3,4]), modules.py:332) from the parked tile, four lanes per row over the 8 gather waves, while
+        // the MFMA team parks cd.  A fixed trip count with predicated, independent loads: with a data-dependent loop every
+        // ds_read waited for the one before (60 serial round trips, 2.5 us on every tile's way out).
+        const int row = gt >> 2, t = gt & 3;
+        const float* srcr = Tfd + a + (row < P ? row : 0) * P;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TP / 4; i += 2) {
+            const int c0 = 4 * i + t, c1 = c0 + 4;
+            const float v0 = srcr[c0 < P ? c0 : 0], v1 = srcr[c1 < P ? c1 : 0];
+            s0 += c0 < P ? v0 : 0.f;
+            s1 += c1 < P ? v1 : 0.f;
+        }
+        float sfull = s0 + s1;
+        sfull += __shfl_xor(sfull, 1, 64);
+        sfull += __shfl_xor(sfull, 2, 64);
+        if (t == 0 && row < TP) rowmean[row] = (prm.pointwise && row < P) ? sfull / (float)P : 0.f;
+    }
+    __syncthreads();                             // E2: Tcd, rowmean
+    if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- output sweep, in two parts: cd and the backward's w (+ the two sums) do not need old_mean and leave first, so that
+    // the rendezvous of the pair-set - which waits for its slowest tile - is hidden behind two thirds of the stores; the
+    // negative loss follows from a second pass over the parked tiles
+    const float cmin = prm.cmin, cmax = prm.cmax;
+    const float invP = 1.f / (float)P;
+    float loss_part = 0.f, clamp_part = 0.f;
+    const int nvec = (a + P2 + 3) >> 2;
+    // element k of vector f0: w = fd_centred - shift (pass bit in the lsb), cl = clamp(cd), lp = loss without the old_mean term
+    auto element = [&](int f0, int k, float fd, float cd, float& w, float& cl, float& lp, bool& ok) {
+        const int e = f0 + k - a;
+        ok = e >= 0 && e < P2;
+        const int r = min(max((int)(((float)e + 0.5f) * invP), 0), P - 1);
+        const float wv = fd - (rowmean[r] + shift);
+        cl = fminf(fmaxf(cd, cmin), cmax);
+        lp = -cl * wv;
+        const unsigned pass = (cd >= cmin && cd <= cmax) ? 1u : 0u;
+        w = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, wv) & ~1u) | pass);
+    };
+    for (int v = tid; v < nvec; v += FUSED_THREADS) {
+        const int f0 = 4 * v;
+        const f32x4 fd4 = *reinterpret_cast<const f32x4*>(Tfd + f0);
+        const f32x4 cd4 = *reinterpret_cast<const f32x4*>(Tcd + f0);
+        f32x4 w4;
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float w, cl, lp;
+            element(f0, k, fd4[k], cd4[k], w, cl, lp, ok[k]);
+            w4[k] = w;
+            if (ok[k]) { loss_part += lp; clamp_part += cl; }
+        }
+        const int e0 = f0 - a;
+        if (vec_ok && ok[0] && ok[3]) {
+            // streaming stores: nobody in this launch reads the outputs again, and lines that never become dirty in the
+            // L2s do not have to be written back when the kernel ends
+            __builtin_nontemporal_store(cd4, reinterpret_cast<f32x4*>(cd_out + e0));
+            if (w_out) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(w_out + e0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    cd_out[e0 + k] = cd4[k];
+                    if (w_out) w_out[e0 + k] = w4[k];
+                }
+        }
+    }
+    bool gave_up = false;
+    if (loss_out) {                              // (workgroup-uniform)
+        if (wave8 == 0) {
             // old_mean of my pair-set = sum of its B tile sums / (B P^2), summed in image order (as the scalar kernel does)
             float om = 0.f, applied = 1.f;
             if (rendezvous) {
@@ -1101,70 +1171,33 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 }
                 if (ok_all) om = acc * (1.f / ((float)B * (float)P2));     // same expression as the scalar kernel
                 else applied = 0.f;
-            } else if (loss_out != nullptr && prm.pointwise) {
-                applied = 0.f;                   // debug & 32: leave it to the scalar kernel
+            } else if (prm.pointwise) {
+                applied = 0.f;                   // debug & 32: leave it to the last workgroup
             }
             if (lane == 0) { omv[0] = om; omv[1] = applied; }
         }
-    } else {
-        // row means of fd (fd.mean([3,4]), modules.py:332) by two lanes per row (the first four gather waves)
-        const int row = gt < NTHREADS ? gt >> 1 : TP, half = gt & 1;
-        const int hlf = (P + 1) >> 1;
-        float s0 = 0.f, s1 = 0.f;
-        if (row < P) {
-            const float* srcr = Tfd + a + row * P;
-            const int c1 = half ? P : hlf;
-            int c = half ? hlf : 0;
-            for (; c + 2 <= c1; c += 2) { s0 += srcr[c]; s1 += srcr[c + 1]; }
-            if (c < c1) s0 += srcr[c];
-        }
-        float sfull = s0 + s1;
-        sfull += __shfl_xor(sfull, 1, 64);
-        if (half == 0 && row < TP) rowmean[row] = prm.pointwise ? sfull / (float)P : 0.f;
-    }
-    __syncthreads();                             // E2: Tcd, rowmean, old_mean
-    if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
-
-    const float om = omv[0];
-    const float cmin = prm.cmin, cmax = prm.cmax;
-    const float invP = 1.f / (float)P;
-    float loss_part = 0.f, clamp_part = 0.f;
-    {
-        const int nvec = (a + P2 + 3) >> 2;
+        __syncthreads();                         // E3: old_mean
+        const float om = omv[0];
+        gave_up = omv[1] == 0.f;
         for (int v = tid; v < nvec; v += FUSED_THREADS) {
             const int f0 = 4 * v;
             const f32x4 fd4 = *reinterpret_cast<const f32x4*>(Tfd + f0);
             const f32x4 cd4 = *reinterpret_cast<const f32x4*>(Tcd + f0);
-            f32x4 w4, lo4;
+            f32x4 lo4;
             bool ok[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int e = f0 + k - a;
-                ok[k] = e >= 0 && e < P2;
-                const int r = min(max((int)(((float)e + 0.5f) * invP), 0), P - 1);
-                const float w = fd4[k] - (rowmean[r] + shift);                 // fd_centred - shift
-                const float cl = fminf(fmaxf(cd4[k], cmin), cmax);
-                const float lp = -cl * w;                                      // loss without the old_mean term
-                const unsigned pass = (cd4[k] >= cmin && cd4[k] <= cmax) ? 1u : 0u;
-                w4[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, w) & ~1u) | pass);
+                float w, cl, lp;
+                element(f0, k, fd4[k], cd4[k], w, cl, lp, ok[k]);
                 lo4[k] = __builtin_fmaf(-om, cl, lp);                          // loss = -clamp(cd) * (fd_centred + old_mean - shift)
-                if (ok[k]) { loss_part += lp; clamp_part += cl; }
             }
             const int e0 = f0 - a;
             if (vec_ok && ok[0] && ok[3]) {
-                // streaming stores: nobody in this launch reads the outputs again, and lines that never become dirty in the
-                // L2s do not have to be written back when the kernel ends
-                __builtin_nontemporal_store(cd4, reinterpret_cast<f32x4*>(cd_out + e0));
-                if (loss_out) __builtin_nontemporal_store(lo4, reinterpret_cast<f32x4*>(loss_out + e0));
-                if (w_out) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(w_out + e0));
+                __builtin_nontemporal_store(lo4, reinterpret_cast<f32x4*>(loss_out + e0));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (ok[k]) {
-                        cd_out[e0 + k] = cd4[k];
-                        if (loss_out) loss_out[e0 + k] = lo4[k];
-                        if (w_out) w_out[e0 + k] = w4[k];
-                    }
+                    if (ok[k]) loss_out[e0 + k] = lo4[k];
             }
         }
     }
@@ -1174,7 +1207,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         clamp_part += __shfl_xor(clamp_part, m, 64);
     }
     if (lane == 0) { red[16 + wave8 * 2] = loss_part; red[16 + wave8 * 2 + 1] = clamp_part; }
-    const bool gave_up = omv[1] == 0.f;
     if (gave_up) __threadfence();                // (rare) whoever repairs this tile must see its cd / loss: release my stores
     __syncthreads();
     // ---- my sums as {tag, value} granules, then one ticket, WITHOUT waiting for the stores in between (a store-ack round
@@ -1187,7 +1219,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         unsigned long long* g3 = gst + (size_t)tile * 3;
         __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, omv[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, gave_up ? 0.f : 1.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
     }

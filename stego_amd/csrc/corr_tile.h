@@ -224,6 +224,10 @@ __device__ __forceinline__ void gather_commit(const GatherRegs<V>& g, const floa
 __device__ __forceinline__ void park_flat(const f32x16 (&acc)[2][2], float* __restrict__ T, int P, const float* colscale,
                                           int lane, int wr, int wc)
 {
+    // Branch-free: elements of the padding rows / columns go to a per-lane dummy word in the unused tail of the tile region
+    // (P * P + 6 <= TP * LDT - 72).  With a branch per element the compiler put every ds_write into its own block behind an
+    // s_waitcnt lgkmcnt(0): 64 serialised LDS round trips, 2.1 us per tile (measured, tools/stamps_fused.py).
+    const int dummy = TP * LDT - 72 + lane;          // (T may be shifted by up to 3 floats)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = 64 * wc + 32 * ni + (lane & 31);
@@ -233,7 +237,7 @@ __device__ __forceinline__ void park_flat(const f32x16 (&acc)[2][2], float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < P && col < P) T[row * P + col] = acc[mi][ni][r] * sc;
+                T[(row < P && col < P) ? row * P + col : dummy] = acc[mi][ni][r] * sc;
             }
     }
 }

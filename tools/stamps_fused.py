@@ -18,8 +18,8 @@ sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 1000 + i, dev) for i in range
 lib = capi.load()
 nt = (2 + n_neg) * B
 names = ["start", "phase1 done", "anchor ready", "main loop end (E0)", "parked+rowmean+om (E2)", "end", "tile assigned", "own codes done",
-         "p1: taps done", "p1: gathers landed", "p1: stores issued", "gather head done", "p1: rows staged", "p1: team barrier 1",
-         "p1: stores acked", "gather head start"]
+         "p1: taps done", "p1: gathers landed", "p1: stores issued", "gather head done", "epi: sum fd done", "epi: row sums done",
+         "epi: fd parked", "gather head start"]
 for prec in (capi.PREC_F16X3,):
     for dbg in [int(x) for x in (sys.argv[1:] or ["256"])]:
         capi.debug_set("STEGO_DEBUG", dbg)
@@ -44,7 +44,7 @@ for prec in (capi.PREC_F16X3,):
         t0 = ts[:, 0].min()
         rel = (ts[:, :16] - t0) / 100.0
         print("prec=%d debug=%d  (us since the first workgroup started; p0 / p50 / p100 over %d workgroups)" % (prec, dbg, nt))
-        for k in (0, 8, 9, 12, 13, 10, 14, 1, 6, 15, 11, 7, 2, 3, 4, 5):
+        for k in (0, 8, 9, 10, 1, 6, 15, 11, 7, 2, 3, 12, 13, 14, 4, 5):
             print("   %-26s %7.2f %7.2f %7.2f" % ((names[k],) + tuple(np.percentile(rel[:, k], [0, 50, 100]))))
         loop = rel[:, 3] - rel[:, 2]
         print("   ring loop (anchor ready -> E0) percentiles 0/10/25/50/75/90/100:", np.round(np.percentile(loop, [0, 10, 25, 50, 75, 90, 100]), 1))
