@@ -493,6 +493,52 @@ __device__ __forceinline__ void mma_stage_f(const unsigned char* __restrict__ As
     }
 }
 
+// one CODE stage for the split-fp16 matrix cores: operands stay in format F (fp32 in LDS: phase 1, the gather team's commit and the
+// backward's context are unchanged), each wave splits its fragments into hi / lo halves in registers (8 channels of a row = two
+// 16-byte units) - ~300 VALU instructions against 1.3 us of fp32 MFMAs (which run at the VALU rate on gfx950).  The B side is
+// prescaled by the gather team (a power of two per point: exact), the A side is normalised.  Channels >= kper of a 16-wide
+// k-step are masked: the pad of the anchor operand is whatever the workspace held.
+__device__ __forceinline__ void split_f16x8(const f32x4 x0, const f32x4 x1, bool live, f16x8& hi, f16x8& lo)
+{
+    unsigned h[4], l[4];
+    split_f16_pair(x0[0], x0[1], h[0], l[0]);
+    split_f16_pair(x0[2], x0[3], h[1], l[1]);
+    split_f16_pair(x1[0], x1[1], h[2], l[2]);
+    split_f16_pair(x1[2], x1[3], h[3], l[3]);
+    const u32x4 hv = live ? u32x4{h[0], h[1], h[2], h[3]} : u32x4{0u, 0u, 0u, 0u};
+    const u32x4 lv = live ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{0u, 0u, 0u, 0u};
+    hi = __builtin_bit_cast(f16x8, hv);
+    lo = __builtin_bit_cast(f16x8, lv);
+}
+
+__device__ __forceinline__ void mma_stage_fh(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int kper,
+                                             f32x16 (&acc)[2][2], int lane, int wr, int wc)
+{
+    const int r = lane & 31, half = lane >> 5;
+    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb0 = 64 * wc + r, rb1 = rb0 + 32;
+    for (int ks = 0; 16 * ks < kper; ++ks) {
+        const int u = 4 * ks + 2 * half;
+        const bool live = 16 * ks + 8 * half < kper;
+        f16x8 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+        split_f16x8(*reinterpret_cast<const f32x4*>(As + swz_f(ra0, u)), *reinterpret_cast<const f32x4*>(As + swz_f(ra0, u + 1)), live, ah0, al0);
+        split_f16x8(*reinterpret_cast<const f32x4*>(As + swz_f(ra1, u)), *reinterpret_cast<const f32x4*>(As + swz_f(ra1, u + 1)), live, ah1, al1);
+        split_f16x8(*reinterpret_cast<const f32x4*>(Bs + swz_f(rb0, u)), *reinterpret_cast<const f32x4*>(Bs + swz_f(rb0, u + 1)), live, bh0, bl0);
+        split_f16x8(*reinterpret_cast<const f32x4*>(Bs + swz_f(rb1, u)), *reinterpret_cast<const f32x4*>(Bs + swz_f(rb1, u + 1)), live, bh1, bl1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ ring: gather side
 // The gather team is instruction-bound (measured: 1.1 us of blend / split / LDS work + 0.6 us of load issue per stage with
 // four waves, against 0.7 us for the MFMA team), so it gets GW = 8 of the workgroup's 12 waves.
@@ -780,7 +826,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         for (int n = 0; n < NKC; ++n) {
             stage_head(n);
             const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
-            mma_stage_f(As, sameAB ? As : As + RS_SIDE, kper, accc, lane, wr, wc);
+            if constexpr (PREC == PREC_F32) mma_stage_f(As, sameAB ? As : As + RS_SIDE, kper, accc, lane, wr, wc);
+            else mma_stage_fh(As, sameAB ? As : As + RS_SIDE, kper, accc, lane, wr, wc);
             TL(n, 3);
         }
         // ... then the feature stages
@@ -802,9 +849,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         // ================================================================= gather team
         const int g8 = gt & 7, prow = gt >> 3;
         const int gwave = wave8 - 4;
-        float ss[GI], bsc[GI], ssc[GI];
+        float ss[GI], bsc[GI], ssc[GI], bscc[GI];
 #pragma unroll
-        for (int j = 0; j < GI; ++j) { ss[j] = 0.f; bsc[j] = 0.f; ssc[j] = 0.f; }
+        for (int j = 0; j < GI; ++j) { ss[j] = 0.f; bsc[j] = 0.f; ssc[j] = 0.f; bscc[j] = 0.f; }
         if (lane < 8 * GI) {
             // tap table of the B points: every wave computes the 8 GI entries it reads itself (no barrier needed)
             const int q = GP * (lane >> 3) + 8 * gwave + (lane & 7);
@@ -908,6 +955,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             }
         };
         // commit a CODE stage m: raw fp32 samples to the B side of its ring slot
+        // F16X3: the MFMA team splits these operands into fp16 halves, so the raw samples get a power-of-two prescale per point,
+        // chosen from the first code stage in which the point is non-zero among the first two (as for the features)
         auto commit_code = [&](const GSet& g, int m) {
             unsigned char* dst = ring + (m & (RS_NS - 1)) * RS_STAGE + RS_SIDE;
 #pragma unroll
@@ -916,7 +965,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 float v[4];
                 blend(g, j, v);
                 ssc[j] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                *reinterpret_cast<f32x4*>(dst + swz_f(q, g8)) = f32x4{v[0], v[1], v[2], v[3]};
+                float sc = 1.f;
+                if constexpr (PREC == PREC_F16X3) {
+                    if (m < 2 && bscc[j] == 0.f) {
+                        float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+                        for (int mm = 4; mm >= 1; mm >>= 1) mx = fmaxf(mx, __shfl_xor(mx, mm, 64));
+                        if (mx > 0.f) bscc[j] = __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx));
+                    }
+                    sc = bscc[j] == 0.f ? 1.f : bscc[j];
+                }
+                *reinterpret_cast<f32x4*>(dst + swz_f(q, g8)) = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
             }
         };
         // after the last code stage: norms -> column scale of cd; normalised rows + norms -> the backward's context.
@@ -931,13 +990,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 const bool valid = q < P;
                 const float nr = valid ? sqrtf(sq) : 0.f;
                 const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
-                if (g8 == 0) { cscc[q] = inv; prm.nrm[(size_t)sB * TP + q] = nr; }
+                const float unsc = (PREC == PREC_F16X3 && bscc[j] != 0.f) ? 1.f / bscc[j] : 1.f;     // (a power of two: exact)
+                if (g8 == 0) { cscc[q] = inv * unsc; prm.nrm[(size_t)sB * TP + q] = nr; }
                 float* crow = prm.cs + ((size_t)sB * TP + q) * prm.LDK;
 #pragma unroll
                 for (int m = 0; m < NKC; ++m) {
                     const int k = m * kper + 4 * g8;
                     if (4 * g8 < kper && k < prm.KQ)
-                        *reinterpret_cast<f32x4*>(crow + k) = *reinterpret_cast<const f32x4*>(ring + m * RS_STAGE + RS_SIDE + swz_f(q, g8)) * inv;
+                        *reinterpret_cast<f32x4*>(crow + k) = *reinterpret_cast<const f32x4*>(ring + m * RS_STAGE + RS_SIDE + swz_f(q, g8)) * (inv * unsc);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
