@@ -559,8 +559,9 @@ struct GSet {
 //   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
 // tiles whose rendezvous gave up (applied == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
 // same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
-__device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, float* Tfd, int tid, int n_tiles)
+__device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, float* Tfd, int tid, int n_tiles, unsigned long long* ts)
 {
+    if (ts && tid == 0) ts[12] = __builtin_amdgcn_s_memrealtime();        // (debug 256: the tail's own stamps, over the epilogue's)
     const int B = prm.B, P2 = prm.P * prm.P;
     const float cmin = prm.cmin, cmax = prm.cmax;
     unsigned long long* gst = prm.gran + n_tiles;                  // [n_tiles][3]: sum lp, sum clamp, old_mean applied
@@ -582,13 +583,29 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
         }
     }
     __syncthreads();
+    if (ts && tid == 0) ts[13] = __builtin_amdgcn_s_memrealtime();
     const float inv_cnt = 1.f / ((float)B * (float)P2);
-    if (tid < prm.n_sets) {
-        float fsum = 0.f, lsum = 0.f, csum = 0.f;
-        for (int bb = 0; bb < B; ++bb) {
-            const float* st = sst + ((size_t)tid * B + bb) * 4;
-            fsum += st[0]; lsum += st[1]; csum += st[2];
+    // (pair-set, quantity) per thread, image order; independent LDS reads in flight eight at a time (one thread per pair-set walking
+    // all three was 3 B dependent round trips: 1.1 us at the very end of every launch)
+    float* sums3 = som + 2 * prm.n_sets;         // [n_sets][3]
+    if (tid < 3 * prm.n_sets) {
+        const int ps = tid / 3, k = tid - 3 * ps;
+        const float* st = sst + (size_t)ps * B * 4 + k;
+        float acc = 0.f;
+        int bb = 0;
+        for (; bb + 8 <= B; bb += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = st[(bb + i) * 4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
         }
+        for (; bb < B; ++bb) acc += st[bb * 4];
+        sums3[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < prm.n_sets) {
+        const float fsum = sums3[3 * tid], lsum = sums3[3 * tid + 1], csum = sums3[3 * tid + 2];
         const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
         som[tid] = fsum * inv_cnt;
         som[prm.n_sets + tid] = lsum - omp * csum;                 // sum of this pair-set's loss
@@ -601,6 +618,7 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
         for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
         prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
     }
+    if (ts && tid == 0) ts[14] = __builtin_amdgcn_s_memrealtime();
     // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
     bool mine = false;
     for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;
@@ -623,6 +641,7 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
     for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
         __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ts && tid == 0) ts[15] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
@@ -722,7 +741,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
         }
         __syncthreads();
-        if (fin[0] != 0.f) last_workgroup_tail(prm, Tfd, tid, n_tiles);
+        if (fin[0] != 0.f) last_workgroup_tail(prm, Tfd, tid, n_tiles, nullptr);
         return;
     }
 
@@ -1287,7 +1306,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     __syncthreads();
     if (fin[0] == 0.f) return;
 
-    last_workgroup_tail(prm, Tfd, tid, n_tiles);
+    last_workgroup_tail(prm, Tfd, tid, n_tiles, (prm.debug & 256) ? ts : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch

@@ -50,6 +50,9 @@ for prec in (capi.PREC_F16X3,):
         print("   ring loop (anchor ready -> E0) percentiles 0/10/25/50/75/90/100:", np.round(np.percentile(loop, [0, 10, 25, 50, 75, 90, 100]), 1))
         print("   ring loop mean by XCD (workgroup %% 8):", [round(float(loop[x::8].mean()), 1) for x in range(8)])
         print("   ring loop mean by slot (workgroup // 8) quartiles:", [round(float(loop[8 * a: 8 * a + 56].mean()), 1) for a in (0, 7, 14, 21)])
+        last = int(np.argmax(rel[:, 5]))
+        print("   last workgroup %d: end %.2f | tail start %.2f  granules in %.2f  sums done %.2f  tail end %.2f" %
+              ((last, rel[last, 5]) + tuple(rel[last, 12:16])))
         if os.environ.get("DUMP"):
             np.save(os.path.join(ROOT, "gpurun_out", "stamps_fused.npy"), rel)
         capi.debug_set("STEGO_DEBUG", 0)
