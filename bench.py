@@ -584,10 +584,9 @@ def main():
             "metric": "image-pairs/sec through correspondence loss, B=32 224^2, ViT-S/8",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3 (f32 inputs / outputs / accumulation; products of the feature "
-                                                                   "correlation and of the backward's code GEMMs as fp16 hi+lo splits, 22-bit, on the "
-                                                                   "matrix cores - error vs fp64 in the fp32 class, bounded by tests on adversarial inputs; "
-                                                                   "code correlation of the forward exact f32)",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3 (f32 inputs / outputs / accumulation; products of the feature and "
+                                                                   "code correlations and of the backward's code GEMMs as fp16 hi+lo splits, 22-bit, on the "
+                                                                   "matrix cores - error vs fp64 in the fp32 class, bounded by tests on adversarial inputs)",
             "data": "synthetic" if not dry else "none (dry run of the multi-rank protocol on CPU: no kernels ran, value is not a measurement)",
             "config": {"workload": "%s: B=%d/GPU, C=%d, %dx%d map, K=%d, S=%d, %d negatives, self+KNN+random "
                                    "correlation loss, %s" % (args.workload, B, C, H, W, K, S, n_neg,

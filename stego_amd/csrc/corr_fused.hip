@@ -12,33 +12,41 @@
 //   * tile -> workgroup placement by the XCD of the tile's B-side SOURCE image (block b runs on XCD b % 8, observed):
 //     all workgroups that gather from image j - the intra / inter tiles of anchor j and every negative tile (i, b) with
 //     perm_i[b] = j - sit on XCD j % 8, so every feature / code map is fetched into exactly one L2, once;
-//   * phase 1 (all 12 waves of every workgroup, first thing): the anchor sets are sampled + normalised ONCE, ~18 points per
-//     workgroup by the same XCD affinity (anchor b is sampled on XCD b % 8, so the same fetch of image b serves its
-//     negatives), staged through LDS into ready-made operand stages and written with coalesced write-through (sc1)
-//     stores; one counter per anchor publishes them.  A tile waits for its anchor's counter (one polling wave, bounded
-//     spin; on timeout that wave recomputes the anchor itself - same values, so duplicate stores are benign) and then
-//     streams the anchor operand with sc1 LDS-DMA copies.  The compact operand (196 KB) is what crosses XCDs, never
-//     the raw taps of a second image (550 KB).  The last wave (it has no rows: 12 waves x 2 rows > 18) meanwhile works out
-//     which tile this workgroup owns (ballots over perms) and builds the gather team's tap table;
+//   * phase 1 (the 4 waves of every workgroup's MFMA team, first thing; the launch covers EVERY CU, workgroups beyond the
+//     tiles do nothing else): the anchor sets are sampled + normalised ONCE, 16 points per workgroup by the same XCD
+//     affinity (anchor b is sampled on XCD b % 8, so the same fetch of image b serves its negatives), staged through the
+//     A sides of the idle ring into ready-made operand stages and written with coalesced write-through (sc1) stores; one
+//     counter per anchor publishes them.  The team syncs through an LDS counter, not s_barrier, because the gather team
+//     does not take part: its first wave works out which tile the workgroup owns (ballots over perms), every gather wave
+//     builds its taps and the team fills the B sides of the first four ring slots - none of which needs an anchor - while
+//     phase 1 runs.  A tile waits for its anchor's counter (one polling wave, bounded spin; on timeout that wave recomputes
+//     the anchor itself - same values, so duplicate stores are benign) and then streams the anchor operand with sc1
+//     LDS-DMA copies.  The compact operand (196 KB) is what crosses XCDs, never the raw taps of a second image (550 KB);
 //   * the main loop is a RING of four 32-channel stages (A side: LDS-DMA issued three stages ahead from inline asm, so
 //     that neither the compiler nor a barrier drains it; B side: gathered by a team of 8 waves two stages ahead into
 //     registers - tap offsets and weights register-resident - and committed one stage ahead); one raw s_barrier per
 //     stage, which is also a scheduling fence.  With two 64-channel stages every barrier waited for a whole round trip
 //     (period = latency + transfer);
-//   * the codes go through the same ring as K-chunks of exact-fp32 operands AHEAD of the features: their fp32 MFMAs
-//     (VALU rate) run while the ring fills with feature stages; the B-side codes are gathered by the gather team with
-//     the feature taps (same points), their norm becomes a column scale of cd, the backward's context is written on the way;
+//   * the codes go through the same ring as K-chunks of fp32 operands (format F) AHEAD of the features.  PREC_F32 multiplies
+//     them on the fp32 MFMA (VALU rate: 2.0 us per chunk); PREC_F16X3 has the MFMA team split each fragment into fp16 hi / lo
+//     halves in registers and use the fp16 matrix cores like the features (1.3 us per chunk; the B-side codes get a
+//     power-of-two prescale per point).  The B-side codes are gathered by the gather team with the feature taps (same points),
+//     their norm becomes a column scale of cd, the backward's context is written on the way;
 //   * the batch-global old_mean (:331) - the reason the old forward had a third launch that re-read and re-wrote the
 //     negative loss tensor - is a rendezvous INSIDE the launch: every negative tile publishes its sum(fd) as one
-//     tagged 8-byte granule before it parks its tiles, and reads the B granules of its pair-set just before the
-//     output sweep (measured 1.2 us mean / 1.7 us worst after the last publisher, hidden behind the parking).  The spin
+//     tagged 8-byte granule before it parks its tiles, and reads the B granules of its pair-set between the two parts of
+//     the output sweep (measured 1.2 us mean / 1.7 us worst after the last publisher).  The spin
 //     is bounded: a tile that gives up writes the loss without the old_mean term and flags itself;
 //   * every workgroup ends with a ticket; the LAST one computes the three scalars from the per-tile sums in a fixed
 //     order, repairs flagged tiles (normally none) and writes the hand-off words back to zero, so that a prepared
-//     workspace serves launch after launch without a memset (stego_corr_workspace_prepare / stego_corr_fwd_prepared).
+//     workspace serves launch after launch without a memset (stego_corr_workspace_prepare / stego_corr_fwd_prepared);
+//   * the way out is branch-free: the accumulators are parked in the flat output layout with predicated ADDRESSES (a
+//     branch per element had put each ds_write behind its own s_waitcnt: 64 serialised LDS round trips, 2.1 us per tile),
+//     the row means are taken from the parked tile by the idle gather waves with independent loads, and the sweep runs in
+//     two parts around the old_mean rendezvous (cd and the backward's w first, the negative loss after it).
 //
-// Arithmetic: PREC_F16X3 split-fp16 feature products (hi*hi + hi*lo + lo*hi, fp32 accumulate), exact fp32 code
-// products, fp32 epilogue.  No atomics on data, fixed summation orders: bitwise repeatable.
+// Arithmetic: PREC_F16X3 split-fp16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate) for features and codes, PREC_F32 exact
+// fp32 products, fp32 epilogue.  No atomics on data, fixed summation orders: bitwise repeatable.
 #include "corr_tile.h"
 #include "host_util.h"
 

@@ -259,6 +259,39 @@ def test_split_fp16_error_bound_on_adversarial_inputs():
     assert err["f16x3"] <= 2.0 * err["f32"] + 2e-7, err
 
 
+def test_split_fp16_code_correlation_on_adversarial_codes():
+    """Round 2b: in f16x3 mode the fused forward also multiplies the CODE K-chunks as fp16 hi/lo halves (the MFMA team splits the
+    fp32 operands in registers; raw B-side codes get a per-point power-of-two prescale from their first chunk).  cd is a cosine:
+    both modes must stay within 2.5e-6 of the fp64 oracle on every cd output where the split is stressed - per-channel dynamic
+    range 2^14 inside a point, tiny / huge code magnitudes, exact zeros, one dominant channel - and f16x3 within 2x of f32."""
+    B, C, H, W, K, S, n_neg = 4, 384, 12, 12, 70, 11, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=405, dino_like=True)
+    rng = np.random.default_rng(405)
+    c = d["code"].copy()
+    cp = d["code_pos"].copy()
+    spread = np.exp2(rng.integers(-14, 1, size=(1, K, 1, 1))).astype(np.float32)        # per-channel 2^-14 .. 1
+    c[0] *= spread[0]
+    cp[0] *= spread[0]
+    c[1] *= np.float32(3e-7)                                                            # tiny overall magnitude
+    cp[1] *= np.float32(2e4)                                                            # huge overall magnitude
+    c[2, ::3] = 0.0                                                                     # exact zeros
+    c[3, 5] += 50.0                                                                     # one dominant channel
+    cp[3, 40] -= 50.0                                                                   # ... in another K-chunk
+    inputs = dict(feats=d["feats"], feats_pos=d["feats_pos"], code=c, code_pos=cp, coords1=d["coords1"], coords2=d["coords2"])
+    cfg = O.CorrCfg(neg_samples=n_neg)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    err = {}
+    for precision in ("f32", "f16x3"):
+        r = _run(inputs, d["perms"], cfg, layout="cl", grad=False, precision=precision)
+        out = r["out"]
+        e = max(np.abs(out[1].astype(np.float64) - ref.pos_intra_cd).max(), np.abs(out[3].astype(np.float64) - ref.pos_inter_cd).max(),
+                np.abs(out[5].astype(np.float64) - ref.neg_inter_cd).max())
+        err[precision] = e
+        assert np.isfinite(out[5]).all()
+        assert e < 2.5e-6, (precision, e)
+    assert err["f16x3"] <= 2.0 * err["f32"] + 2e-7, err
+
+
 @pytest.mark.parametrize("shape", [
     dict(B=1, C=8, H=4, W=4, K=4, S=1, n_neg=1),        # single sample point, B=1 (perm = [0])
     dict(B=2, C=5, H=3, W=9, K=3, S=2, n_neg=3),        # odd channel counts -> scalar gather path
