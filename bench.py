@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="steps captured per HIP graph (0 = one graph holding one step of every rotated input set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shared-device", choices=["auto", "0", "1"], default="auto",
+                    help="STEGO_SHARED_DEVICE for the fused forward (one workgroup per tile instead of one per CU); auto = when a collective runs")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the per-step all-reduce even with one rank (exercises the N > 1 path)")
     ap.add_argument("--fwd-only", action="store_true", help="time the forward alone (reported in config)")
@@ -308,6 +310,9 @@ def main():
         args.launch = "eager"
     else:
         from stego_amd import capi
+        if args.shared_device == "1" or (args.shared_device == "auto" and dist is not None):
+            # the all-reduce of step t overlaps the kernels of step t + 1: the fused forward leaves the CUs beyond its tiles alone
+            capi.set_shared_device(True)
         sets = [make_inputs(B, C, H, W, K, S, n_neg, 1234 + 97 * rank + i, dev, args.layout) for i in range(args.sets)]
         # upstream gradients exactly as train_segmentation.py:169-181 produces them
         g_intra = torch.tensor(cfg.pos_intra_weight, device=dev)
@@ -595,7 +600,8 @@ def main():
                        "launch_trial_ms_per_step": trial,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
                        "collective": ("all_reduce(%d f32 head grads)/step, FlatGradReducer.allreduce_mean(async)" % grad_buf.numel())
-                       if dist is not None else None},
+                       if dist is not None else None,
+                       "shared_device": (args.shared_device == "1" or (args.shared_device == "auto" and dist is not None)) and not dry},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
             "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt,
             "cpu_baseline": cpu,

@@ -89,7 +89,10 @@ const char* stego_error_string(int code);
 
 /* Measurement / ablation knobs for tools (never needed by a caller of the product path).  The library reads
  * STEGO_DEBUG, STEGO_DEBUG_SAMPLE, STEGO_DEBUG_BWD, STEGO_DEBUG_VIT, STEGO_DEBUG_KNN, STEGO_FWD_VARIANT from the
- * environment ONCE, when it is loaded (no getenv in any call); this overrides knob `which` (0..5 in that order). */
+ * environment ONCE, when it is loaded (no getenv in any call); this overrides knob `which` (0..5 in that order).
+ * Knob 6, STEGO_SHARED_DEVICE (default 0), is a deployment setting: 1 tells the fused forward that other kernels run on
+ * the device at the same time (the gradient all-reduce of a data-parallel job overlapping the next step): it then launches one
+ * workgroup per tile only instead of one per compute unit, so that it never waits for a compute unit somebody else holds. */
 int stego_debug_set(int32_t which, int32_t value);
 
 /* Buffer sizes (bytes; depend only on the descriptor; 0 for an invalid/unsupported descriptor).

@@ -102,7 +102,13 @@ def load():
 
 
 KNOBS = {"STEGO_DEBUG": 0, "STEGO_DEBUG_SAMPLE": 1, "STEGO_DEBUG_BWD": 2, "STEGO_DEBUG_VIT": 3, "STEGO_DEBUG_KNN": 4,
-         "STEGO_FWD_VARIANT": 5}
+         "STEGO_FWD_VARIANT": 5, "STEGO_SHARED_DEVICE": 6}
+
+
+def set_shared_device(shared=True):
+    """Tell the fused forward that other kernels (collectives) run on the device beside it: one workgroup per tile instead of one per
+    compute unit (include/stego_corr.h, knob 6).  ddp.FlatGradReducer and bench.py set it when world_size > 1."""
+    _check(load().stego_debug_set(KNOBS["STEGO_SHARED_DEVICE"], 1 if shared else 0))
 
 
 def debug_set(name, value):

@@ -210,6 +210,12 @@ struct P1Layout {
     __device__ static __forceinline__ int feat_plane(int s2, int pp) { return (s2 / SPP) * RS_STAGE + (s2 % SPP) * STAGE_BYTES + pp * ROWS * RB; }
 };
 
+// bilinear blend of the four taps with a FIXED rounding sequence (one multiply, three fmas)
+__device__ __forceinline__ float blend4(const float4 w, float t0, float t1, float t2, float t3)
+{
+    return __builtin_fmaf(w.w, t3, __builtin_fmaf(w.z, t2, __builtin_fmaf(w.y, t1, w.x * t0)));
+}
+
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
 template <int NJ, int PREC, int NKCT>
@@ -289,9 +295,11 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = wg.x * t[g][j][0][e] + wg.y * t[g][j][1][e] + wg.z * t[g][j][2][e] + wg.w * t[g][j][3][e];
+                // (explicit fma chain: the two inlined instances of this code - g = 0, 1 - must round alike, or an anchor row's bits
+                // would depend on which wave slot sampled it)
+                const float x = blend4(wg, t[g][j][0][e], t[g][j][1][e], t[g][j][2][e], t[g][j][3][e]);
                 v[j][e] = x;
-                ss += x * x;
+                ss = __builtin_fmaf(x, x, ss);
             }
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
@@ -324,13 +332,14 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         const bool valid = act[g] && qq < prm.P;
         const float4 wg = w[g];
         // ---- code: normalised; once as K-chunk operand stages (forward), once as a context row (backward)
-        f32x2 r0 = wg.x * ct[g].a[0] + wg.y * ct[g].a[1] + wg.z * ct[g].a[2] + wg.w * ct[g].a[3];
-        float r1 = wg.x * ct[g].b[0] + wg.y * ct[g].b[1] + wg.z * ct[g].b[2] + wg.w * ct[g].b[3];
+        f32x2 r0 = f32x2{blend4(wg, ct[g].a[0][0], ct[g].a[1][0], ct[g].a[2][0], ct[g].a[3][0]),
+                         blend4(wg, ct[g].a[0][1], ct[g].a[1][1], ct[g].a[2][1], ct[g].a[3][1])};
+        float r1 = blend4(wg, ct[g].b[0], ct[g].b[1], ct[g].b[2], ct[g].b[3]);
         if (2 * hl >= prm.K) r0 = f32x2{0.f, 0.f};
-        float r2 = wg.x * ct[g].c[0] + wg.y * ct[g].c[1] + wg.z * ct[g].c[2] + wg.w * ct[g].c[3];
+        float r2 = blend4(wg, ct[g].c[0], ct[g].c[1], ct[g].c[2], ct[g].c[3]);
         if (64 + hl >= prm.K) r1 = 0.f;
         if (96 + hl >= prm.K) r2 = 0.f;
-        float cs2 = r0[0] * r0[0] + r0[1] * r0[1] + r1 * r1 + r2 * r2;
+        float cs2 = __builtin_fmaf(r2, r2, __builtin_fmaf(r1, r1, __builtin_fmaf(r0[1], r0[1], r0[0] * r0[0])));
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) cs2 += __shfl_xor(cs2, m, 64);
         const float nr = valid ? sqrtf(cs2) : 0.f;
@@ -1354,14 +1363,18 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     FusedParams prm = prm_in;
     const int n_tiles = prm.n_sets * prm.B;
     const int cus = device_cu_count();
-    prm.n_owner = (cus & ~7) < 8 ? 8 : (cus & ~7);
+    // Every CU gets a workgroup: those beyond the tiles only help with phase 1.  That needs the WHOLE device at once; when other
+    // kernels run beside the loss (STEGO_SHARED_DEVICE: the gradient all-reduce of step t overlaps the forward of step t + 1), a
+    // helper that cannot be placed would hold up its anchors - and their 7 tiles each - for as long as the other kernel runs.
+    // Then the tiles' own workgroups share phase 1 (a third of them take a second pass) and the CUs beyond the tiles stay free.
+    const int all = (cus & ~7) < 8 ? 8 : (cus & ~7);
+    prm.n_owner = knob(KNOB_SHARED_DEVICE) ? (n_tiles < all ? n_tiles : all) : all;
     prm.timeout_ticks = (prm.debug & 64) ? 100 : 20000;           // 200 us of the 100 MHz clock
     const int lds = RING_LDS_BYTES;
     hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (!prepared && (e = prepare_corr_fused(prm, sync_bytes, stream)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    // every CU gets a workgroup: those beyond the tiles only help with phase 1 (the tiles' own MFMA teams do the rest of it)
     const dim3 grid(n_tiles > prm.n_owner ? n_tiles : prm.n_owner), block(FUSED_THREADS);
 #define STEGO_FUSED_LAUNCH(PR, N, NK)                                                                  \
     do {                                                                                               \

@@ -29,6 +29,7 @@ struct Knobs {
         v[KNOB_DEBUG_VIT] = env_int("STEGO_DEBUG_VIT", 0);
         v[KNOB_DEBUG_KNN] = env_int("STEGO_DEBUG_KNN", 0);
         v[KNOB_FWD_VARIANT] = env_int("STEGO_FWD_VARIANT", -1);
+        v[KNOB_SHARED_DEVICE] = env_int("STEGO_SHARED_DEVICE", 0);
     }
 };
 Knobs g_knobs;      // initialised when the library is loaded

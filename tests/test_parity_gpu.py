@@ -883,3 +883,24 @@ def test_randomised_shapes_against_the_oracle():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "16", "7"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "failures: 0", out.stdout[-3000:]
+
+
+def test_fused_forward_shared_device_mode_matches():
+    """STEGO_SHARED_DEVICE (set by ddp.FlatGradReducer / bench.py when a collective overlaps the step): the fused forward launches one
+    workgroup per tile instead of one per compute unit, a third of them take a second phase-1 pass.  Same bytes out."""
+    c = GoldenCase("cfg1_B4_vits8_dinolike")
+    base = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]
+    capi.set_shared_device(True)
+    try:
+        alt = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]
+        B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5            # the full-size launch: 224 tiles, 18.3 anchor rows per workgroup
+        d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=77, dino_like=True)
+        inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+        cfg = O.CorrCfg(neg_samples=n_neg)
+        big_alt = _run(inputs, d["perms"], cfg, layout="cl", grad=False, precision="f16x3")["out"]
+    finally:
+        capi.set_shared_device(False)
+    big = _run(inputs, d["perms"], cfg, layout="cl", grad=False, precision="f16x3")["out"]
+    for x, y in list(zip(base, alt)) + list(zip(big, big_alt)):
+        np.testing.assert_array_equal(x, y)
+
