@@ -200,7 +200,9 @@ struct P1Layout {
     static constexpr int PLANES = PREC == PREC_F16X3 ? 2 : 1;
     static constexpr int RB = PREC == PREC_F16X3 ? 64 : 128;
     static constexpr int G = NJ <= 3 ? 2 : 1;                  // points per half-wave and pass (register budget: 48 NJ G)
-    static constexpr int ROWS = 4 * 2 * G;                     // rows of a pass: four waves
+    static constexpr int MROWS = 4 * 2 * G;                    // rows the four waves of the MFMA team take per pass
+    static constexpr int XW = NJ <= 3 ? 2 : 0;                 // gather waves (8, 9) that take two overflow rows each in the FIRST pass
+    static constexpr int ROWS = MROWS + 2 * XW;                // rows of a pass = geometry of the staging area
     static constexpr int STAGE_BYTES = ROWS * 128;             // one feature stage of a pass (either format)
     static constexpr int SPP = RS_SIDE / STAGE_BYTES;          // feature stages per piece
     static_assert(NCH2 <= 2 * SPP, "feature stages fit pieces 0-1");
@@ -218,12 +220,12 @@ __device__ __forceinline__ float blend4(const float4 w, float t0, float t1, floa
 
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
-template <int NJ, int PREC, int NKCT>
+template <int NJ, int PREC, int NKCT, int G>
 __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane,
                                                unsigned char* lds, unsigned long long* tsd)
 {
     typedef P1Layout<NJ, PREC> LY;
-    constexpr int G = LY::G, ROWS = LY::ROWS;
+    constexpr int ROWS = LY::ROWS;
     const int hl = lane & 31, hw = lane >> 5;
     const int crow = prm.LDK * 4;
     unsigned char* lds_cf = lds + LY::CF;
@@ -412,6 +414,12 @@ __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int 
 // Barrier of a team of waves inside the workgroup, through an LDS counter that only grows (s_barrier would take in the waves of
 // the other team): everything this wave did in LDS before is visible to whoever sees the count (the LDS executes a wave's
 // operations in order).  `target` = waves x (barriers so far).
+__device__ __forceinline__ void team_arrive(unsigned* cnt, int lane)     // a guest: counted, does not wait
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned target, int lane)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -721,21 +729,29 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     // syncs through an LDS counter, not s_barrier: the gather team is not part of it - it works out the tile, builds its tap
     // table and fills the B sides of the first four ring slots meanwhile (none of which needs an anchor).
     const bool p1_here = me < prm.n_owner && !(prm.debug & 64);       // (debug 64: nobody samples, every tile takes the give-up path)
+    // The share is 16 rows when every CU has a workgroup; one workgroup per tile (STEGO_SHARED_DEVICE) makes it 18-19, and a second
+    // pass for two or three rows would repeat the whole latency chain (+3 us): gather waves 8 and 9 - idle until the tile is known -
+    // take two overflow rows each in the first pass, stage them like everybody else and ARRIVE at the team's first barrier (they
+    // do not wait: copying out and publishing stay with the MFMA team).
+    const int p1x = me & 7, p1r = me >> 3;
+    const int p1nb = p1x < B ? (B - p1x + 7) >> 3 : 0;
+    const int p1nslot = (prm.n_owner - p1x + 7) >> 3;
+    const long long p1L = (long long)p1nb * TP;
+    const int p1beg = (int)(p1L * p1r / p1nslot), p1end = (int)(p1L * (p1r + 1) / p1nslot);
     if (mfma_team && p1_here) {
-        const int x = me & 7, r = me >> 3;
-        const int nb = x < B ? (B - x + 7) >> 3 : 0;
-        const int nslot = (prm.n_owner - x + 7) >> 3;
-        const long long L = (long long)nb * TP;
-        const int beg = (int)(L * r / nslot), end = (int)(L * (r + 1) / nslot);
+        const int x = p1x, beg = p1beg, end = p1end;
         unsigned epoch = 0;
         // the team shares its SIMDs with two gather waves each, and everybody's anchors wait for it: it goes first
         __builtin_amdgcn_s_setprio(3);
-        for (int blk0 = beg; blk0 < end; blk0 += LY::ROWS) {
-            if (blk0 + 2 * LY::G * wave < end)       // (a wave without rows in this pass goes straight to the barrier)
-                p1_sample_rows<NJ, PREC, NKCT>(prm, x, blk0, end, 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
-            epoch += 4;
+        bool first = true;
+        for (int blk0 = beg; blk0 < end; first = false) {
+            const int cap = first ? LY::ROWS : LY::MROWS;
+            const int nrows = min(cap, end - blk0);
+            const int n_extra = nrows > LY::MROWS ? (nrows - LY::MROWS + 1) >> 1 : 0;          // gather waves arriving at this barrier
+            if (2 * LY::G * wave < min(nrows, LY::MROWS))       // (a wave without rows in this pass goes straight to the barrier)
+                p1_sample_rows<NJ, PREC, NKCT, LY::G>(prm, x, blk0, min(end, blk0 + LY::MROWS), 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
+            epoch += 4 + n_extra;
             team_barrier(team_cnt, epoch, lane);
-            const int nrows = min(LY::ROWS, end - blk0);
             // a run must stay inside one anchor: split the pass at an anchor boundary
             const int to_edge = (((blk0 >> 7) + 1) << 7) - blk0;
             const int n0 = min(nrows, to_edge);
@@ -746,8 +762,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             epoch += 4;
             team_barrier(team_cnt, epoch, lane);
             if (tid == 0) p1_publish(prm, x, blk0, nrows);
+            blk0 += cap;
         }
         __builtin_amdgcn_s_setprio(0);
+    } else if (p1_here && LY::XW > 0 && wave8 >= 8 && wave8 < 8 + LY::XW) {
+        const int lr0 = LY::MROWS + 2 * (wave8 - 8);
+        if (p1beg + lr0 < p1end) {
+            p1_sample_rows<NJ, PREC, NKCT, 1>(prm, p1x, p1beg, p1end, lr0, lane, ring, nullptr);
+            team_arrive(team_cnt, lane);
+        }
     }
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
     if (helper) {
@@ -820,7 +843,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 // identical inputs give identical bytes, so racing with a late owner is benign; nothing else in the
                 // launch depends on the counter being exact.
                 for (int q0 = 0; q0 < TP; q0 += 2 * LY::G) {
-                    p1_sample_rows<NJ, PREC, NKCT>(prm, sA, q0, TP, 0, lane, ring, nullptr);
+                    p1_sample_rows<NJ, PREC, NKCT, LY::G>(prm, sA, q0, TP, 0, lane, ring, nullptr);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     p1_copy_out<NJ, PREC>(prm, sA, q0, 0, 2 * LY::G, 0, 1, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 }
