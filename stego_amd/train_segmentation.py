@@ -301,6 +301,7 @@ class SyntheticContrastiveDataset(torch.utils.data.Dataset):
 
     n_cache_items = property(lambda self: 2 * self.n)          # anchors [0, n) + their positives [n, 2n)
     deterministic_items = True                                 # the same index always yields the same pixels
+    per_rank = True                                            # my_app seeds it by rank: already a different slice on every rank
 
     def __getitem__(self, ind):
         g = torch.Generator().manual_seed(self.seed * 100003 + ind)
@@ -343,12 +344,17 @@ class Trainer:
                                  "(loader_crop_type=%r re-crops every epoch)" % crop)
             n_items = int(getattr(ds, "n_cache_items", len(ds)))
             model.net.enable_token_cache(n_items, (model.cfg.res, model.cfg.res), self.device)
+        loader = self._shard_loader(loader)
         if len(loader) == 0:
             raise ValueError("empty loader (dataset of %d items, batch size %s, drop_last): nothing to train on"
                              % (len(loader.dataset), getattr(loader, "batch_size", "?")))
         step = 0
+        epoch = 0
         history = []
         while step < self.max_steps:
+            if isinstance(getattr(loader, "sampler", None), torch.utils.data.distributed.DistributedSampler):
+                loader.sampler.set_epoch(epoch)      # a new shuffle per epoch, the same on every rank (Lightning does this)
+            epoch += 1
             for batch in loader:
                 batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 loss = model.training_step(batch, step)
@@ -364,6 +370,20 @@ class Trainer:
         if self.checkpoint_path and self.rank == 0:
             model.save_checkpoint(self.checkpoint_path)
         return history
+
+    def _shard_loader(self, loader):
+        """Data parallelism needs every rank to see its own slice: a loader without a DistributedSampler over a dataset that is
+        not already different per rank (``dataset.per_rank``, the synthetic set is seeded by rank) is rebuilt with one - what
+        Lightning's ``replace_sampler_ddp`` does for the reference (train_segmentation.py:461-468)."""
+        ds = loader.dataset
+        if self.world <= 1 or getattr(ds, "per_rank", False) or \
+                isinstance(getattr(loader, "sampler", None), torch.utils.data.distributed.DistributedSampler):
+            return loader
+        shuffle = isinstance(getattr(loader, "sampler", None), torch.utils.data.RandomSampler)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle, seed=0,
+                                                                 drop_last=loader.drop_last)
+        return torch.utils.data.DataLoader(ds, batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
+                                           collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last)
 
     def _validate(self, model):
         model.eval()

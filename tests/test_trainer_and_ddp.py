@@ -407,3 +407,35 @@ def test_cropped_dataset_tree_round_trip(tmp_path):
     assert len(D.CroppedDataset(str(tmp_path), "cocostuff27", "random", 0.5, "train")) == 5
     with pytest.raises(ValueError, match="Unknown crop type"):
         D.write_cropped(str(tmp_path), "x", "center", 0.5, "val", items[:1])
+
+
+def test_trainer_shards_a_plain_loader_across_ranks(monkeypatch):
+    """a real dataset without a DistributedSampler gave every rank the same batches.  Trainer.fit rebuilds such a loader with
+    one (as Lightning does for the reference); a dataset that is already per-rank, a single process and a loader that has one stay."""
+    from stego_amd import train_segmentation as T
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 20
+
+        def __getitem__(self, i):
+            return {"ind": i}
+
+    seen = {}
+    for rank in (0, 1):
+        tr = T.Trainer(max_steps=1)
+        tr.rank, tr.world = rank, 2
+        ld = tr._shard_loader(torch.utils.data.DataLoader(DS(), batch_size=5, shuffle=True, drop_last=True))
+        assert isinstance(ld.sampler, torch.utils.data.distributed.DistributedSampler)
+        ld.sampler.set_epoch(0)
+        seen[rank] = sorted(int(i) for b in ld for i in b["ind"])
+        assert len(seen[rank]) == 10
+    assert not set(seen[0]) & set(seen[1]) and sorted(seen[0] + seen[1]) == list(range(20))
+    tr = T.Trainer(max_steps=1)
+    tr.rank, tr.world = 0, 1
+    plain = torch.utils.data.DataLoader(DS(), batch_size=5)
+    assert tr._shard_loader(plain) is plain
+    tr.world = 2
+    syn = torch.utils.data.DataLoader(T.SyntheticContrastiveDataset(8, 32, 5, seed=0), batch_size=4)
+    assert tr._shard_loader(syn) is syn
+
