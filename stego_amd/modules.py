@@ -143,8 +143,27 @@ def _relayout_threshold(code):
     return 0 if code.shape[1] > 72 else 1 << 16
 
 
+class _NegLossMap(torch.Tensor):
+    """The negative loss tensor forward() returns (modules.py:390, ``torch.cat(neg_losses)``), carrying the mean the forward launch
+    computed anyway.  The reference's training step only ever takes ``neg_inter_loss.mean()`` (train_segmentation.py:176): that call
+    is answered with the kernel's scalar - no 9 MB reduction pass, and the backward gets one device scalar instead of a dense
+    upstream (which would also push it onto the slower dense-upstream kernels).  Every other use behaves like the plain tensor
+    (results are plain tensors; gradients flow to the same autograd node)."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.Tensor.mean, torch.mean) and len(args) == 1 and not kwargs:
+            m = getattr(args[0], "_stego_mean", None)
+            if m is not None:
+                return m
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
 class _CorrLossFunction(torch.autograd.Function):
-    """ContrastiveCorrelationLoss.forward as one op: stego_corr_fwd / stego_corr_bwd."""
+    """ContrastiveCorrelationLoss.forward as one op: stego_corr_fwd / stego_corr_bwd.  Seventh output: the mean over the negative
+    loss tensor (loss_means[2]), for _NegLossMap."""
 
     @staticmethod
     def forward(ctx, feats, feats_pos, code, code_pos, coords1, coords2, perms, desc):
@@ -158,15 +177,22 @@ class _CorrLossFunction(torch.autograd.Function):
         if need_grad:
             ctx.n_saved = len(saved)
             ctx.save_for_backward(code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd, *saved)
-        return loss_means[0], intra_cd, loss_means[1], inter_cd, neg_loss, neg_cd
+        return loss_means[0], intra_cd, loss_means[1], inter_cd, neg_loss, neg_cd, loss_means[2]
 
     @staticmethod
-    def backward(ctx, g_intra, g_intra_cd, g_inter, g_inter_cd, g_neg_loss, g_neg_cd):
+    def backward(ctx, g_intra, g_intra_cd, g_inter, g_inter_cd, g_neg_loss, g_neg_cd, g_neg_mean):
         code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd = ctx.saved_tensors[:8]
         saved = tuple(ctx.saved_tensors[8:])
+        neg_is_mean = False
+        if g_neg_mean is not None and ctx.desc.n_neg > 0:
+            if g_neg_loss is None:
+                g_neg_loss, neg_is_mean = g_neg_mean.reshape(1), True        # the training case: one device scalar
+            else:                                                            # both the map and its mean were differentiated
+                g_neg_loss = g_neg_loss + g_neg_mean / float(g_neg_loss.numel())
         d_code, d_code_pos = _backend.corr_bwd(ctx.desc, code.detach(), code_pos.detach(), coords1, coords2, perms,
                                                saved, intra_cd, inter_cd, neg_cd,
-                                               g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd)
+                                               g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd,
+                                               neg_is_mean=neg_is_mean)
         return (None, None,
                 d_code if ctx.needs_input_grad[2] else None,
                 d_code_pos if ctx.needs_input_grad[3] else None,
@@ -281,8 +307,12 @@ class ContrastiveCorrelationLoss(nn.Module):
             perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg,
                               (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), _precision_of(cfg))
-        return _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos,
-                                       coords1, coords2, perms, desc)
+        out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
+        neg_loss = out[4]
+        if n_neg > 0:
+            neg_loss = neg_loss.as_subclass(_NegLossMap)          # (an alias: same storage, same autograd node)
+            neg_loss._stego_mean = out[6]
+        return out[0], out[1], out[2], out[3], neg_loss, out[5]
 
     def forward(self,
                 orig_feats: torch.Tensor, orig_feats_pos: torch.Tensor,

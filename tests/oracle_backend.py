@@ -24,6 +24,7 @@ def _t(a, like):
 
 
 calls = []
+last_neg_is_mean = None
 
 
 def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, need_grad):
@@ -46,6 +47,8 @@ def corr_fwd(desc, feats, feats_pos, code, code_pos, coords1, coords2, perms, ne
 def corr_bwd(desc, code, code_pos, coords1, coords2, perms, saved, intra_cd, inter_cd, neg_cd,
              g_intra, g_inter, g_neg_loss, g_intra_cd, g_inter_cd, g_neg_cd, neg_is_mean=False):
     calls.append("corr_bwd")
+    global last_neg_is_mean
+    last_neg_is_mean = bool(neg_is_mean)
     cfg = _cfg_from_desc(desc)
     f, fp = corr_fwd.stash
     S = desc.S

@@ -75,6 +75,38 @@ def test_autograd_wiring_train_weights(oracle_backed):
     assert_close(code_pos.grad.numpy(), c.g["d_code_pos_train"], rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
 
 
+def test_negative_loss_mean_comes_from_the_kernel(oracle_backed):
+    """forward() hands the negative loss back as a tensor whose .mean() - all the reference's training step takes from it - is the
+    scalar the forward launch computed, with a one-scalar upstream in the backward; any other use is the plain tensor's."""
+    c = GoldenCase("small_default")
+    t = {k: torch.from_numpy(v) for k, v in c.inputs.items()}
+
+    def run(use):
+        code = t["code"].clone().requires_grad_(True)
+        code_pos = t["code_pos"].clone().requires_grad_(True)
+        out = M.ContrastiveCorrelationLoss(c.cfg).forward_explicit(
+            t["feats"], t["feats_pos"], code, code_pos, t["coords1"], t["coords2"], torch.from_numpy(c.perms))
+        oracle_backend.last_neg_is_mean = None
+        (0.67 * out[0] + 0.25 * out[2] + 0.63 * use(out[4])).backward()
+        return out, code.grad.numpy(), code_pos.grad.numpy()
+
+    out, g1, gp1 = run(lambda x: x.mean())                               # answered by the kernel's scalar
+    assert oracle_backend.last_neg_is_mean is True
+    _, g2, gp2 = run(lambda x: x.sum() / x.numel())                      # the plain tensor path (dense upstream)
+    assert oracle_backend.last_neg_is_mean is False
+    _, g3, gp3 = run(lambda x: 0.5 * x.mean() + 0.5 * torch.mean(torch.Tensor.as_subclass(x, torch.Tensor)))     # both at once
+    for g, gp in ((g2, gp2), (g3, gp3)):
+        assert_close(g1, g, rtol=1e-4, atol_frac=1e-5, what="d_code")
+        assert_close(gp1, gp, rtol=1e-4, atol_frac=1e-5, what="d_code_pos")
+    assert_close(g1, c.g["d_code_train"], rtol=1e-3, atol_frac=1e-3, what="d_code")
+    x = out[4]
+    assert isinstance(x, torch.Tensor) and x.mean().dim() == 0
+    np.testing.assert_allclose(float(x.mean()), float(x.detach().numpy().mean()), rtol=1e-5)
+    assert type(x + 1) is torch.Tensor and type(x.reshape(-1)) is torch.Tensor and type(x.detach()) is torch.Tensor
+    assert type(torch.cat([x, x])) is torch.Tensor and x.mean(dim=0).shape == x.shape[1:]
+    assert x.numel() == c.g["neg_inter_loss"].size
+
+
 def test_autograd_wiring_general_upstream(oracle_backed):
     c = GoldenCase("small_stab")
     g = c.g
