@@ -1395,7 +1395,12 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     // helper that cannot be placed would hold up its anchors - and their 7 tiles each - for as long as the other kernel runs.
     // Then the tiles' own workgroups share phase 1 (a third of them take a second pass) and the CUs beyond the tiles stay free.
     const int all = (cus & ~7) < 8 ? 8 : (cus & ~7);
-    prm.n_owner = knob(KNOB_SHARED_DEVICE) ? (n_tiles < all ? n_tiles : all) : all;
+    const int sd = knob(KNOB_SHARED_DEVICE);
+    prm.n_owner = sd == 0 ? all : (n_tiles < all ? n_tiles : all);
+    if (sd > 8) {                          // (tools: an explicit number of phase-1 owners between the two, a multiple of 8)
+        const int want = sd & ~7;
+        prm.n_owner = want < prm.n_owner ? prm.n_owner : (want > all ? all : want);
+    }
     prm.timeout_ticks = (prm.debug & 64) ? 100 : 20000;           // 200 us of the 100 MHz clock
     const int lds = RING_LDS_BYTES;
     hipError_t e = hipSuccess;

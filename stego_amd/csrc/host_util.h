@@ -14,7 +14,8 @@ int device_cu_count();
 
 // Measurement / ablation knobs: STEGO_DEBUG, STEGO_DEBUG_SAMPLE, STEGO_DEBUG_BWD, STEGO_DEBUG_VIT, STEGO_DEBUG_KNN, STEGO_FWD_VARIANT,
 // and one deployment knob, STEGO_SHARED_DEVICE (1: other kernels - the collectives of a data-parallel job - run on the device while the
-// loss does: the fused forward then launches no phase-1 helper workgroups and so leaves the compute units beyond its tiles free).
+// loss does: the fused forward then launches no phase-1 helper workgroups and so leaves the compute units beyond its tiles free;
+// a value > 8 is an explicit number of phase-1 owner workgroups, for measurements: 232 .. 256 time alike, 224 costs ~1 us).
 // Read from the environment once, when the library is loaded; stego_debug_set() (C ABI, tools only) overrides them
 // afterwards.  The product path never calls getenv.
 enum { KNOB_DEBUG = 0, KNOB_DEBUG_SAMPLE, KNOB_DEBUG_BWD, KNOB_DEBUG_VIT, KNOB_DEBUG_KNN, KNOB_FWD_VARIANT, KNOB_SHARED_DEVICE, KNOB_COUNT };
