@@ -6,7 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench
 from stego_amd import capi
-occ = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "lib", "liboccupy.so"))
+_so = os.path.join(ROOT, "tools", "ubench", "lib", "liboccupy.so")
+if not os.path.exists(_so):          # (git-ignored build product: hipcc --offload-arch=gfx950 -O3 -fPIC -shared tools/ubench/occupy.hip)
+    import subprocess
+    os.makedirs(os.path.dirname(_so), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared",
+                           os.path.join(ROOT, "tools", "ubench", "occupy.hip"), "-o", _so])
+occ = ctypes.CDLL(_so)
 occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda:0")
 cfg = bench.Cfg()
