@@ -42,10 +42,13 @@ enum {
 /* Arithmetic used for the channel contraction (the einsum of modules.py:283-284). */
 enum {
     STEGO_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulate (runs at the VALU rate) */
-    STEGO_PREC_F16X3 = 1     /* RECOMMENDED: feature correlation with every fp32 operand split into fp16 hi+lo */
-                             /* (22 mantissa bits), hi*hi + hi*lo + lo*hi on the fp16 matrix cores, fp32         */
-                             /* accumulate: measured error on the loss equals the F32 mode (2.6e-8 mean abs);    */
-                             /* the code correlation (which carries gradients) stays exact fp32 in both modes    */
+    STEGO_PREC_F16X3 = 1     /* RECOMMENDED: every fp32 operand split into fp16 hi+lo (22 mantissa bits after a   */
+                             /* per-point power-of-two prescale), hi*hi + hi*lo + lo*hi on the fp16 matrix cores, */
+                             /* fp32 accumulate: measured error on the loss equals the F32 mode (2.6e-8 mean abs, */
+                             /* bounds on adversarial inputs in tests/test_parity_gpu.py).  Feature correlation in */
+                             /* every forward path; in the single-launch forward also the code correlation, and    */
+                             /* in the backward the two code GEMMs (the three-launch forward keeps the code        */
+                             /* correlation in exact fp32)                                                         */
 };
 
 /* hipStream_t without dragging the HIP headers into C callers. */
