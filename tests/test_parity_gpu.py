@@ -904,3 +904,35 @@ def test_fused_forward_shared_device_mode_matches():
     for x, y in list(zip(base, alt)) + list(zip(big, big_alt)):
         np.testing.assert_array_equal(x, y)
 
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_fused_forward_at_the_largest_batch_of_a_launch(shared):
+    """B = 36 with 5 negatives: 252 tiles on 256 CUs, five anchors on XCDs 0-3, i.e. 20 anchor rows per workgroup when every CU has one
+    (19 and 23 per tile workgroup in the one-per-tile launch, which then needs a second phase-1 pass): the gather waves that take the
+    overflow rows of phase 1 are all busy.  Fused forward against the three-launch path of the same library."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 36, 384, 14, 14, 70, 11, 5
+    cfg = bench.Cfg()
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 5151, dev)
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+
+    def run():
+        o = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (o[0],) + tuple(o[1:5]) + (o[5][0],)]
+
+    try:
+        capi.debug_set("STEGO_FWD_VARIANT", 1)
+        ref = run()
+        capi.debug_set("STEGO_FWD_VARIANT", 0)
+        capi.set_shared_device(shared)
+        assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
+        for rep in range(5):
+            for g, r in zip(run(), ref):
+                assert not torch.isnan(g).any()
+                assert float((g - r).abs().max()) < 2e-6
+    finally:
+        capi.debug_set("STEGO_FWD_VARIANT", 0)
+        capi.set_shared_device(False)
+
