@@ -591,7 +591,9 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
     const float cmin = prm.cmin, cmax = prm.cmax;
     unsigned long long* gst = prm.gran + n_tiles;                  // [n_tiles][3]: sum lp, sum clamp, old_mean applied
     float* sst = Tfd;                            // [n_tiles][4] staged copy of the sums (the ring is dead)
-    float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set
+    float* som = sst + n_tiles * 4;              // [n_sets] old_mean per pair-set, [n_sets] sum of its loss
+    float* sums3 = som + 2 * prm.n_sets;         // [n_sets][3]
+    bool mine = false;                           // one of my flags says "rendezvous gave up"
     {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS) {
@@ -604,50 +606,63 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
                 if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            sst[i] = __builtin_bit_cast(float, (unsigned)x);
+            const float v = __builtin_bit_cast(float, (unsigned)x);
+            sst[i] = v;
+            mine |= k == 3 && t >= 2 * B && v == 0.f;
         }
     }
-    __syncthreads();
+    // one barrier: the staged sums are complete AND the vote on the repair path (a serial scan of the flags cost 160 dependent LDS
+    // reads = 6.7 us at the very end of every launch)
+    const bool repair = __syncthreads_or(mine) && prm.pointwise;
     if (ts && tid == 0) ts[13] = __builtin_amdgcn_s_memrealtime();
-    const float inv_cnt = 1.f / ((float)B * (float)P2);
-    // (pair-set, quantity) per thread, image order; independent LDS reads in flight eight at a time (one thread per pair-set walking
-    // all three was 3 B dependent round trips: 1.1 us at the very end of every launch)
-    float* sums3 = som + 2 * prm.n_sets;         // [n_sets][3]
-    if (tid < 3 * prm.n_sets) {
-        const int ps = tid / 3, k = tid - 3 * ps;
-        const float* st = sst + (size_t)ps * B * 4 + k;
-        float acc = 0.f;
-        int bb = 0;
-        for (; bb + 8 <= B; bb += 8) {
-            float v[8];
+    if (tid >= 64) {
+        // every hand-off word has been copied: waves 1.. write them back to zero while wave 0 does the arithmetic
+        constexpr int NZ = FUSED_THREADS - 64;
+        for (int i = tid - 64; i < B; i += NZ)
+            __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid - 64; i < n_tiles * 4; i += NZ)
+            __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        // wave 0, no workgroup barriers in between (the LDS executes a wave's operations in order).  (pair-set, quantity) per lane,
+        // image order; independent LDS reads in flight eight at a time (one thread per pair-set walking all three was 3 B
+        // dependent round trips: 1.1 us)
+        const float inv_cnt = 1.f / ((float)B * (float)P2);
+        for (int idx = tid; idx < 3 * prm.n_sets; idx += 64) {
+            const int ps = idx / 3, k = idx - 3 * ps;
+            const float* st = sst + (size_t)ps * B * 4 + k;
+            float acc = 0.f;
+            int bb = 0;
+            for (; bb + 8 <= B; bb += 8) {
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = st[(bb + i) * 4];
+                for (int i = 0; i < 8; ++i) v[i] = st[(bb + i) * 4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += v[i];
+                for (int i = 0; i < 8; ++i) acc += v[i];
+            }
+            for (; bb < B; ++bb) acc += st[bb * 4];
+            sums3[idx] = acc;
         }
-        for (; bb < B; ++bb) acc += st[bb * 4];
-        sums3[tid] = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int ps = tid; ps < prm.n_sets; ps += 64) {
+            const float fsum = sums3[3 * ps], lsum = sums3[3 * ps + 1], csum = sums3[3 * ps + 2];
+            const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
+            som[ps] = fsum * inv_cnt;
+            som[prm.n_sets + ps] = lsum - omp * csum;               // sum of this pair-set's loss
+            if (prm.saved_mean) prm.saved_mean[ps] = omp;
+            if (ps < 2) prm.loss_means[ps] = (lsum - omp * csum) * inv_cnt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {                          // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
+            float nsum = 0.f;
+            for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
+            prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
+        }
+        if (ts && tid == 0) ts[14] = __builtin_amdgcn_s_memrealtime();
     }
-    __syncthreads();
-    if (tid < prm.n_sets) {
-        const float fsum = sums3[3 * tid], lsum = sums3[3 * tid + 1], csum = sums3[3 * tid + 2];
-        const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
-        som[tid] = fsum * inv_cnt;
-        som[prm.n_sets + tid] = lsum - omp * csum;                 // sum of this pair-set's loss
-        if (prm.saved_mean) prm.saved_mean[tid] = omp;
-        if (tid < 2) prm.loss_means[tid] = (lsum - omp * csum) * inv_cnt;
-    }
-    __syncthreads();
-    if (tid == 0) {                              // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
-        float nsum = 0.f;
-        for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
-        prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
-    }
-    if (ts && tid == 0) ts[14] = __builtin_amdgcn_s_memrealtime();
-    // (a serial scan of the flags cost 160 dependent LDS reads = 6.7 us at the very end of every launch: vote first)
-    bool mine = false;
-    for (int t = 2 * B + tid; t < n_tiles; t += FUSED_THREADS) mine |= sst[t * 4 + 3] == 0.f;
-    if (prm.pointwise && __syncthreads_or(mine)) {
+    if (repair) {                                // (workgroup-uniform; never taken in normal operation)
+        __syncthreads();                         // old means of wave 0
         for (int t = 2 * B; t < n_tiles; ++t) {
             if (sst[t * 4 + 3] != 0.f) continue;                   // (workgroup-uniform)
             const float omp = som[t / B];
@@ -661,11 +676,7 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
             }
         }
     }
-    for (int i = tid; i < B; i += FUSED_THREADS)
-        __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < n_tiles * 4; i += FUSED_THREADS)
-        __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 64) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ts && tid == 0) ts[15] = __builtin_amdgcn_s_memrealtime();
 }
 
