@@ -1,0 +1,39 @@
+"""Build-time guard for the fused forward: its 12-wave workgroups run on a 168-register budget and the compiler has answered small
+source changes with 40-300 spilled registers in the ring loop before.  The headline instantiation must keep its
+spills where they are today - a handful, all in phase 1 / the fallback path - and every instantiation must fit the budget."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_fused_forward_register_budget(tmp_path):
+    src = os.path.join(ROOT, "stego_amd", "csrc", "corr_fused.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+           "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "cf.o"), "-Rpass-analysis=kernel-resource-usage"]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels = {}
+    name = None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1)] = int(m.group(2))
+    fused = {k: v for k, v in kernels.items() if "corr_fused_kernel" in k}
+    assert len(fused) == 16, sorted(kernels)                    # 2 precisions x 2 widths x 4 code-chunk counts
+    for k, v in fused.items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 168, (k, v)    # 12 waves per workgroup = 3 per SIMD
+        assert v["Occupancy [waves/SIMD]"] >= 3, (k, v)
+    head = fused["_ZN5stego17corr_fused_kernelILi1ELi3ELi3EEEvNS_11FusedParamsE"]      # f16x3, C = 384, K <= 96: BASELINE config 2
+    assert head["VGPRs Spill"] <= 24 and head["ScratchSize [bytes/lane]"] <= 96, head
