@@ -156,8 +156,9 @@ class DinoFeaturizer(nn.Module):
         if native_ok:
             if self._native is None:
                 self._native = vit_native.NativeViT(self.model)
-            self.backbone_path = "native"
-            return self._native.forward_tokens(img), None
+            if self._native.shape_supported(*[int(img.shape[i]) for i in (0, 2, 3)]):      # (else: the torch module below)
+                self.backbone_path = "native"
+                return self._native.forward_tokens(img), None
         self.backbone_path = "torch"
         feat, _, qkv = self.model.get_intermediate_feat(img, n=n)
         return feat[0], qkv[0]

@@ -54,6 +54,13 @@ class NativeViT:
         return capi.StegoVitDesc(B, H, W, m.patch_embed.patch_size, m.embed_dim, len(m.blocks), m.blocks[0].attn.num_heads,
                                  m.blocks[0].mlp.fc1.out_features)
 
+    def shape_supported(self, B, H, W):
+        """Does this build have kernels for a [B,3,H,W] batch through this backbone?  (include/stego_vit.h: H, W multiples of the patch
+        size, B * tokens < 2^20, ...)  A host call: the caller keeps the torch module for what it rejects."""
+        if B <= 0 or H <= 0 or W <= 0:
+            return False
+        return int(capi.load().stego_vit_workspace_bytes(ctypes.byref(self._desc(B, H, W)))) > 0
+
     def invalidate(self):
         """Call after loading new weights into the torch module."""
         self._packed.clear()

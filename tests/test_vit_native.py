@@ -27,6 +27,17 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
+def test_shape_supported_is_a_host_side_answer():
+    """a batch the native kernels do not take (B * tokens >= 2^20, sizes that are not multiples of the patch) must fall back
+    to the torch module instead of raising from inside DinoFeaturizer: NativeViT.shape_supported asks the library on the host."""
+    model, _, _ = _golden_model()
+    nv = vit_native.NativeViT(model)
+    assert nv.shape_supported(2, 32, 32)
+    assert not nv.shape_supported(2, 30, 32)                  # not a multiple of the 8-pixel patch
+    assert not nv.shape_supported(1 << 17, 32, 32)            # 2^17 images x 17 tokens >= 2^20
+    assert not nv.shape_supported(0, 32, 32)
+
+
 # ------------------------------------------------------------------ CPU: the torch mirror is pinned to the reference
 def test_torch_mirror_reproduces_reference_golden_cpu():
     model, img, feat = _golden_model()
