@@ -32,7 +32,9 @@ class TokenCache:
     five-crop dataset").  The backbone is frozen and the reference's `img` / `img_pos` of dataset index i are the same
     pixels every epoch (data.py:520-565: deterministic resize + crop; only `img_aug` is random), so their tokens are a
     pure function of i: computed once, stored as fp16 (ViT-S/8 at 224^2: 603 KB per image - a 118 k-image epoch is 71 GB,
-    a quarter of one MI355X's 288 GB, or sharded with the data over the ranks), served from memory afterwards.  A
+    a quarter of one MI355X's 288 GB), served from memory afterwards.  Under data parallelism every rank holds the WHOLE
+    table: the reference's DistributedSampler reshuffles globally every epoch, so every rank meets every index over time (a
+    rank-stable partition would let the table shard with the data, at the price of a different sampling order).  A
     training step then skips the backbone: 8.4 -> ~1.3 ms at B = 32 pairs (tools/bench_step.py)."""
 
     def __init__(self, n_items, ntok, dim, device, dtype=torch.float16):
