@@ -209,6 +209,17 @@ def test_library_validates_before_enqueueing():
     assert lib.stego_error_string(0) == b"ok"
 
 
+def test_deployment_and_measurement_knobs_are_host_side():
+    """stego_debug_set: knobs 0-5 are measurement switches, knob 6 (STEGO_SHARED_DEVICE) is the deployment setting that
+    ddp.FlatGradReducer / bench.py flip when a collective shares the device; all of it is host state (no GPU needed), an index
+    outside the table is refused."""
+    lib = capi.load()
+    assert sorted(capi.KNOBS.values()) == list(range(7)) and capi.KNOBS["STEGO_SHARED_DEVICE"] == 6
+    capi.set_shared_device(True)
+    capi.set_shared_device(False)
+    assert lib.stego_debug_set(99, 1) == 2 and lib.stego_debug_set(-1, 1) == 2        # STEGO_ERR_SHAPE
+
+
 # ------------------------------------------------------------------ salience-guided coordinates (cfg.use_salience)
 def test_salience_coords_follow_the_reference_draw_order():
     """modules.py:355-365 + sample_nonzero_locations :298-311: per image one randint over its non-zero salience pixels
