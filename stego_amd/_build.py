@@ -3,19 +3,24 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
 ``stego_amd/lib/libstego_corr.so`` is git-ignored but travels to the GPU box with the
 repo snapshot.  No torch headers are involved: the library is plain C ABI.
+
+Every source is compiled to its own object (``stego_amd/lib/obj/*.o``, in parallel, only when it or a header
+changed) and the objects are linked into the one shared library: a one-kernel edit rebuilds in seconds.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libstego_corr.so")
-SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "vit_forward.hip", "host_util.hip", "draws.hip", "c_api.hip"]
+SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "vit_forward.hip", "host_util.hip", "draws.hip", "head_fused.hip", "c_api.hip"]
 HEADERS = ["corr_common.h", "corr_tile.h", "host_util.h", os.path.join("..", "..", "include", "stego_corr.h"), os.path.join("..", "..", "include", "stego_vit.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
 
 
 def _hipcc():
@@ -29,28 +34,66 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _headers():
+    return [p for p in (os.path.join(CSRC, h) for h in HEADERS) if os.path.exists(p)]
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _obj_stale(src):
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + _headers())
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library. Returns the library path."""
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + ".tmp"
-    cmd = [_hipcc()] + FLAGS + sources() + ["-o", tmp]
+def _compile(src, extra, verbose):
+    cmd = [_hipcc()] + CFLAGS + list(extra) + ["-c", src, "-o", _obj(src) + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+    os.replace(_obj(src) + ".tmp", _obj(src))
+    return res.stderr
+
+
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every HIP source (objects cached per file) and link the shared library. Returns the library path.
+    `extra_flags` (e.g. -DSTEGO_FUSED_TIMELINE) force a full rebuild into `out` without touching the object cache."""
+    out = out or LIB_PATH
+    if not force and not extra_flags and out == LIB_PATH and not is_stale():
+        return LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sources()
+    if extra_flags:                       # one-off variant build: everything in one go, no cache
+        cmd = [_hipcc()] + CFLAGS + list(extra_flags) + ["-shared"] + srcs + ["-o", out + ".tmp"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        os.replace(out + ".tmp", out)
+        return out
+    todo = [s for s in srcs if force or _obj_stale(s)]
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(lambda s: _compile(s, (), verbose), todo))
+    cmd = [_hipcc()] + LDFLAGS + [_obj(s) for s in srcs] + ["-o", out + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_fused_forward_register_budget(tmp_path):
     src = os.path.join(ROOT, "stego_amd", "csrc", "corr_fused.hip")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
            "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "cf.o"), "-Rpass-analysis=kernel-resource-usage"]
     res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
     assert res.returncode == 0, res.stderr[-2000:]
