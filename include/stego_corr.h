@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define STEGO_ABI_VERSION 2   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128 */
+#define STEGO_ABI_VERSION 3   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
+                                * 3: StegoCorrDesc.flags (STEGO_FLAG_SHARED_DEVICE is per call, no longer a process-wide knob) */
 
 enum {
     STEGO_OK = 0,
@@ -77,7 +78,16 @@ typedef struct StegoCorrDesc {
     float pos_inter_shift;     /* cfg.pos_inter_shift (:378)                                   */
     float neg_inter_shift;     /* cfg.neg_inter_shift (:387)                                   */
     int32_t precision;         /* STEGO_PREC_*                                                 */
+    int32_t flags;             /* STEGO_FLAG_* (0 = defaults)                                  */
 } StegoCorrDesc;
+
+/* StegoCorrDesc.flags */
+enum {
+    STEGO_FLAG_SHARED_DEVICE = 1   /* other kernels (the gradient all-reduce of a data-parallel job overlapping the next step) run on the
+                                    * device while this call does: the fused forward launches one workgroup per tile only, instead of one
+                                    * per compute unit, so that it never waits for a compute unit somebody else holds.  Same results,
+                                    * bit for bit; ~2 us slower on an otherwise idle device.  Per call: part of the descriptor. */
+};
 
 /* Limits of this build: S*S <= 128 (S <= 11); K (cfg.dim; the reference ships 70) <= 128 on the fused path (K even,
  * channels-last maps with C = 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
@@ -93,10 +103,13 @@ const char* stego_error_string(int code);
 /* Measurement / ablation knobs for tools (never needed by a caller of the product path).  The library reads
  * STEGO_DEBUG, STEGO_DEBUG_SAMPLE, STEGO_DEBUG_BWD, STEGO_DEBUG_VIT, STEGO_DEBUG_KNN, STEGO_FWD_VARIANT from the
  * environment ONCE, when it is loaded (no getenv in any call); this overrides knob `which` (0..5 in that order).
- * Knob 6, STEGO_SHARED_DEVICE (default 0), is a deployment setting: 1 tells the fused forward that other kernels run on
- * the device at the same time (the gradient all-reduce of a data-parallel job overlapping the next step): it then launches one
- * workgroup per tile only instead of one per compute unit, so that it never waits for a compute unit somebody else holds. */
+ * Knob 6, STEGO_SHARED_DEVICE: tools only since ABI 3 (the deployment setting is StegoCorrDesc.flags); a value > 8 still forces
+ * that many phase-1 owner workgroups for measurements.  The knobs are atomics: flipping one while another thread launches is safe. */
 int stego_debug_set(int32_t which, int32_t value);
+
+/* Test hook: n_workgroups workgroups of 256 threads holding lds_bytes of LDS each spin for `microseconds` on `stream` - a
+ * stand-in for a foreign kernel (a collective) that occupies compute units while the loss runs (tests/test_parity_gpu.py). */
+int stego_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microseconds, stego_stream_t stream);
 
 /* Buffer sizes (bytes; depend only on the descriptor; 0 for an invalid/unsupported descriptor).
  *   workspace : scratch of one forward call (sampled operand images + per-tile partial sums)
@@ -190,10 +203,9 @@ int stego_corr_fwd_prepared(const StegoCorrDesc* desc,
                    void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
 /*
- * Measurement hook: exactly stego_corr_fwd, run `iters` times with HIP events recorded on `stream`
- * around each of the three launches; ms_kernels[3] (host) receives the mean duration in milliseconds
- * of { sample_norm_kernel, corr_tile_kernel, corr_finalize_kernel } after synchronising.
- * bench.py derives roofline.achieved from these.
+ * Measurement hook: exactly stego_corr_fwd_prepared, run `iters` times with HIP events recorded on `stream` around each launch;
+ * ms_kernels[3] (host) receives the mean durations in milliseconds after synchronising: fused path { 0, corr_fused_kernel, 0 },
+ * three-launch path { sample_norm_kernel, corr_tile_kernel, corr_finalize_kernel }.  bench.py derives roofline.achieved from these.
  */
 int stego_corr_fwd_profile(const StegoCorrDesc* desc,
                            const StegoMap* feats, const StegoMap* feats_pos,

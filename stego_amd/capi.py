@@ -12,6 +12,8 @@ import torch
 
 from . import _build
 
+ABI_VERSION = 3
+FLAG_SHARED_DEVICE = 1          # StegoCorrDesc.flags
 PREC_F32 = 0
 PREC_F16X3 = 1
 PREC_BF16X3 = PREC_F16X3        # old name of the split mode (it used bf16 halves until round 1, third design)
@@ -26,7 +28,7 @@ class StegoCorrDesc(Structure):
     _fields_ = [("B", c_int32), ("C", c_int32), ("K", c_int32), ("H", c_int32), ("W", c_int32),
                 ("S", c_int32), ("n_neg", c_int32), ("pointwise", c_int32), ("zero_clamp", c_int32),
                 ("stabalize", c_int32), ("pos_intra_shift", c_float), ("pos_inter_shift", c_float),
-                ("neg_inter_shift", c_float), ("precision", c_int32)]
+                ("neg_inter_shift", c_float), ("precision", c_int32), ("flags", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/stego_corr.h declares
@@ -47,6 +49,7 @@ SIGNATURES = {
     "stego_vit_forward": (c_int32, [_V, _P, _P, _P, _P, c_size_t, _P]),
     "stego_abi_version": (c_int32, []),
     "stego_debug_set": (c_int32, [c_int32, c_int32]),
+    "stego_debug_occupy": (c_int32, [c_int32, c_int32, c_int32, _P]),
     "stego_error_string": (ctypes.c_char_p, [c_int32]),
     "stego_corr_workspace_bytes": (c_size_t, [_D]),
     "stego_corr_saved_ctx_bytes": (c_size_t, [_D]),
@@ -95,7 +98,7 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the .so is stale / symbol missing
         fn.restype = res
         fn.argtypes = args
-    if lib.stego_abi_version() != 2:
+    if lib.stego_abi_version() != ABI_VERSION:
         raise RuntimeError("stego_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib
@@ -105,10 +108,16 @@ KNOBS = {"STEGO_DEBUG": 0, "STEGO_DEBUG_SAMPLE": 1, "STEGO_DEBUG_BWD": 2, "STEGO
          "STEGO_FWD_VARIANT": 5, "STEGO_SHARED_DEVICE": 6}
 
 
+_shared_device_default = False
+
+
 def set_shared_device(shared=True):
-    """Tell the fused forward that other kernels (collectives) run on the device beside it: one workgroup per tile instead of one per
-    compute unit (include/stego_corr.h, knob 6).  ddp.FlatGradReducer and bench.py set it when world_size > 1."""
-    _check(load().stego_debug_set(KNOBS["STEGO_SHARED_DEVICE"], 1 if shared else 0))
+    """Default of the per-call flag STEGO_FLAG_SHARED_DEVICE for descriptors made by make_desc() from now on: other kernels
+    (collectives) run on the device beside the loss, so the fused forward launches one workgroup per tile instead of one per
+    compute unit (include/stego_corr.h).  A per-call property of the descriptor since ABI 3 - nothing in the library is global;
+    `cfg.shared_device` (ContrastiveCorrelationLoss) or make_desc(..., shared_device=...) override this default."""
+    global _shared_device_default
+    _shared_device_default = bool(shared)
 
 
 def debug_set(name, value):
@@ -146,10 +155,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def make_desc(B, C, K, H, W, S, n_neg, cfg, shifts, precision=PREC_F32):
+def make_desc(B, C, K, H, W, S, n_neg, cfg, shifts, precision=PREC_F32, shared_device=None):
+    if shared_device is None:
+        shared_device = getattr(cfg, "shared_device", None)
+    if shared_device is None:
+        shared_device = _shared_device_default
     return StegoCorrDesc(B, C, K, H, W, S, n_neg, int(bool(cfg.pointwise)), int(bool(cfg.zero_clamp)),
                          int(bool(cfg.stabalize)), float(shifts[0]), float(shifts[1]), float(shifts[2]),
-                         int(precision))
+                         int(precision), FLAG_SHARED_DEVICE if shared_device else 0)
+
+
+def occupy(n_workgroups, lds_bytes=64 * 1024, microseconds=80, stream=None):
+    """Test hook (stego_debug_occupy): a stand-in for a foreign kernel holding compute units while the loss runs."""
+    _check(load().stego_debug_occupy(int(n_workgroups), int(lds_bytes), int(microseconds),
+                                     stream.cuda_stream if stream is not None else _stream()))
 
 
 def _dense(t, dtype):

@@ -12,7 +12,7 @@ hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_
 hipError_t launch_corr_tile(const CorrParams& prm, int precision, hipStream_t stream);
 hipError_t launch_corr_finalize(const CorrParams& prm, hipStream_t stream);
 bool fused_supported(const FusedParams& prm, int precision);
-hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, bool prepared, hipStream_t stream, hipEvent_t* ev);
+hipError_t launch_corr_fused(const FusedParams& prm, int precision, size_t sync_bytes, bool prepared, bool shared_device, hipStream_t stream, hipEvent_t* ev);
 hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStream_t stream);
 hipError_t launch_fast_draws(const long long* seed, long long n_coord, int n_neg, int B, float* c1, float* c2, long long* perms,
                              hipStream_t stream);
@@ -65,6 +65,7 @@ int check_desc(const StegoCorrDesc* d, bool helper)
         if (d->n_neg + 2 > 256) return STEGO_ERR_UNSUPPORTED;
     }
     if (d->precision != STEGO_PREC_F32 && d->precision != STEGO_PREC_F16X3) return STEGO_ERR_UNSUPPORTED;
+    if (d->flags & ~STEGO_FLAG_SHARED_DEVICE) return STEGO_ERR_UNSUPPORTED;
     return STEGO_OK;
 }
 
@@ -134,6 +135,7 @@ struct FwdPlan {
     FusedParams fused;
     size_t sync_bytes;
     bool use_fused;
+    bool shared_device;
     int precision;
 };
 
@@ -205,6 +207,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     out->tile = prm;
     out->samp = sp;
     out->precision = d->precision;
+    out->shared_device = (d->flags & STEGO_FLAG_SHARED_DEVICE) != 0;
 
     // the fused single-launch forward (corr_fused.hip) covers forward() on channels-last maps of the ViT widths;
     // everything else (helper mode, generic strides, other widths) takes the three-launch path
@@ -242,7 +245,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
 hipError_t run_fwd(const FwdPlan& pl, hipStream_t s, hipEvent_t* ev /* null or [4] */, bool prepared = false)
 {
     hipError_t e;
-    if (pl.use_fused) return launch_corr_fused(pl.fused, pl.precision, pl.sync_bytes, prepared, s, ev);
+    if (pl.use_fused) return launch_corr_fused(pl.fused, pl.precision, pl.sync_bytes, prepared, pl.shared_device, s, ev);
     if (ev) (void)hipEventRecord(ev[0], s);
     if ((e = launch_corr_sample(pl.samp, pl.precision, s)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], s);
@@ -264,6 +267,13 @@ int stego_debug_set(int32_t which, int32_t value)
     if (which < 0 || which >= KNOB_COUNT) return STEGO_ERR_SHAPE;
     set_knob(which, value);
     return STEGO_OK;
+}
+
+int stego_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t microseconds, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_workgroups <= 0 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 100000) return STEGO_ERR_SHAPE;
+    return hip_rc(launch_occupy(n_workgroups, lds_bytes, microseconds, static_cast<hipStream_t>(stream)));
 }
 
 const char* stego_error_string(int code)

@@ -584,7 +584,8 @@ struct GSet {
 //   old_mean_p = sum_b sum(fd) / (B P^2);   mean(loss_p) = (sum lp - old_mean_p * sum clamp) / (B P^2);
 // tiles whose rendezvous gave up (applied == 0) get their old_mean term now: loss = lp - old_mean * clamp(cd), the
 // same fma the tile itself uses; and the hand-off words go back to zero for the next launch on this workspace.
-__device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, float* Tfd, int tid, int n_tiles, unsigned long long* ts)
+__device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, float* Tfd, float* timed_out, int tid, int n_tiles,
+                                                    unsigned long long* ts)
 {
     if (ts && tid == 0) ts[12] = __builtin_amdgcn_s_memrealtime();        // (debug 256: the tail's own stamps, over the epilogue's)
     const int B = prm.B, P2 = prm.P * prm.P;
@@ -603,7 +604,9 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
             for (;;) {
                 x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((x >> 32) == 1ull) break;
-                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
+                // A granule that never arrives (its workgroup cannot have finished: every workgroup has taken its ticket) means
+                // the launch is broken, not slow: the scalars become NaN - loudly wrong - instead of folding in a stale value.
+                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) { timed_out[0] = 1.f; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             const float v = __builtin_bit_cast(float, (unsigned)x);
@@ -649,15 +652,16 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
             const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
             som[ps] = fsum * inv_cnt;
             som[prm.n_sets + ps] = lsum - omp * csum;               // sum of this pair-set's loss
-            if (prm.saved_mean) prm.saved_mean[ps] = omp;
-            if (ps < 2) prm.loss_means[ps] = (lsum - omp * csum) * inv_cnt;
+            const float poison = timed_out[0] != 0.f ? __builtin_nanf("") : 0.f;       // (written before the barrier above)
+            if (prm.saved_mean) prm.saved_mean[ps] = omp + poison;
+            if (ps < 2) prm.loss_means[ps] = (lsum - omp * csum) * inv_cnt + poison;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (tid == 0) {                          // torch.cat(negative losses).mean() (:390, train_segmentation.py:176), pair-set order
             float nsum = 0.f;
             for (int pp = 2; pp < prm.n_sets; ++pp) nsum += som[prm.n_sets + pp];
-            prm.loss_means[2] = prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f;
+            prm.loss_means[2] = (prm.n_neg > 0 ? nsum * inv_cnt / (float)prm.n_neg : 0.f) + (timed_out[0] != 0.f ? __builtin_nanf("") : 0.f);
         }
         if (ts && tid == 0) ts[14] = __builtin_amdgcn_s_memrealtime();
     }
@@ -733,7 +737,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     int* tile_slot = reinterpret_cast<int*>(red + 56);
     unsigned* team_cnt = reinterpret_cast<unsigned*>(red + 57);
     float* fin = red + 48;                       // [0] 1 = I am the last workgroup
-    if (tid == 0) { tile_slot[0] = -1; team_cnt[0] = 0u; }
+    if (tid == 0) { tile_slot[0] = -1; team_cnt[0] = 0u; fin[1] = 0.f; }       // fin[1]: the tail saw a hand-off word time out
     __syncthreads();
 
     // ---- phase 1 (the MFMA team, 4 waves): my share of the anchor sets of my XCD, 2 G points per wave and pass.  The team
@@ -792,7 +796,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
         }
         __syncthreads();
-        if (fin[0] != 0.f) last_workgroup_tail(prm, Tfd, tid, n_tiles, nullptr);
+        if (fin[0] != 0.f) last_workgroup_tail(prm, Tfd, fin + 1, tid, n_tiles, nullptr);
         return;
     }
 
@@ -845,7 +849,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             for (;;) {
                 const unsigned c = __hip_atomic_load(prm.anchor_cnt + (size_t)sA * ANCHOR_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_readfirstlane(c) >= (unsigned)TP) { ready = true; break; }
-                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) break;
+                if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > ((prm.debug & 64) ? 100 : prm.timeout_ticks)) break;
                 __builtin_amdgcn_s_sleep(10);
             }
             if (!ready) {
@@ -1361,7 +1365,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     __syncthreads();
     if (fin[0] == 0.f) return;
 
-    last_workgroup_tail(prm, Tfd, tid, n_tiles, (prm.debug & 256) ? ts : nullptr);
+    last_workgroup_tail(prm, Tfd, fin + 1, tid, n_tiles, (prm.debug & 256) ? ts : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch
@@ -1395,8 +1399,8 @@ hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStre
     return hipMemsetAsync(prm.anchor_cnt, 0, sync_bytes, stream);
 }
 
-hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sync_bytes, bool prepared, hipStream_t stream,
-                             hipEvent_t* ev /* null or [4]: before the memset, before / after the kernel, end */)
+hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sync_bytes, bool prepared, bool shared_device,
+                             hipStream_t stream, hipEvent_t* ev /* null or [4]: before the memset, before / after the kernel, end */)
 {
     FusedParams prm = prm_in;
     const int n_tiles = prm.n_sets * prm.B;
@@ -1406,13 +1410,13 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     // helper that cannot be placed would hold up its anchors - and their 7 tiles each - for as long as the other kernel runs.
     // Then the tiles' own workgroups share phase 1 (a third of them take a second pass) and the CUs beyond the tiles stay free.
     const int all = (cus & ~7) < 8 ? 8 : (cus & ~7);
-    const int sd = knob(KNOB_SHARED_DEVICE);
+    const int sd = shared_device ? 1 : knob(KNOB_SHARED_DEVICE);       // (the knob: tools only - a per-call setting is a descriptor flag)
     prm.n_owner = sd == 0 ? all : (n_tiles < all ? n_tiles : all);
     if (sd > 8) {                          // (tools: an explicit number of phase-1 owners between the two, a multiple of 8)
         const int want = sd & ~7;
         prm.n_owner = want < prm.n_owner ? prm.n_owner : (want > all ? all : want);
     }
-    prm.timeout_ticks = (prm.debug & 64) ? 100 : 20000;           // 200 us of the 100 MHz clock
+    prm.timeout_ticks = 20000;                                    // 200 us of the 100 MHz clock (debug 64: the anchor wait gives up after 1 us)
     const int lds = RING_LDS_BYTES;
     hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);

@@ -22,4 +22,7 @@ enum { KNOB_DEBUG = 0, KNOB_DEBUG_SAMPLE, KNOB_DEBUG_BWD, KNOB_DEBUG_VIT, KNOB_D
 int knob(int which);
 void set_knob(int which, int value);
 
+// test hook (stego_debug_occupy): n_wg workgroups of 256 threads with lds_bytes of LDS each spin for `micros`
+hipError_t launch_occupy(int n_wg, int lds_bytes, int micros, hipStream_t stream);
+
 }  // namespace stego

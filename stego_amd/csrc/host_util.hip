@@ -1,4 +1,5 @@
 // Per-device caches and measurement knobs (see host_util.h).
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -20,7 +21,7 @@ int env_int(const char* name, int dflt)
 }
 
 struct Knobs {
-    int v[KNOB_COUNT];
+    std::atomic<int> v[KNOB_COUNT];
     Knobs()
     {
         v[KNOB_DEBUG] = env_int("STEGO_DEBUG", 0);
@@ -61,11 +62,29 @@ int device_cu_count()
     return n;
 }
 
-int knob(int which) { return (which >= 0 && which < KNOB_COUNT) ? g_knobs.v[which] : 0; }
+int knob(int which) { return (which >= 0 && which < KNOB_COUNT) ? g_knobs.v[which].load(std::memory_order_relaxed) : 0; }
 
 void set_knob(int which, int value)
 {
-    if (which >= 0 && which < KNOB_COUNT) g_knobs.v[which] = value;
+    if (which >= 0 && which < KNOB_COUNT) g_knobs.v[which].store(value, std::memory_order_relaxed);
+}
+
+// ---- test hook: a kernel that just holds compute units (stego_debug_occupy)
+__global__ void occupy_kernel(long long ticks, int* sink)
+{
+    extern __shared__ int occupy_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    occupy_lds[threadIdx.x] = threadIdx.x;
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+    if (occupy_lds[threadIdx.x] == -1 && sink) sink[0] = 1;
+}
+
+hipError_t launch_occupy(int n_wg, int lds_bytes, int micros, hipStream_t stream)
+{
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&occupy_kernel), lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(256), lds_bytes, stream, (long long)micros * 100, (int*)nullptr);
+    return hipGetLastError();
 }
 
 }  // namespace stego

@@ -55,7 +55,6 @@ class FlatGradReducer:
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.group = process_group
-        self._shared_device_set = False
         off = 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
@@ -94,11 +93,9 @@ class FlatGradReducer:
         if not is_distributed() and not (single_rank_ok and dist.is_available() and dist.is_initialized()):
             return None                  # (single_rank_ok: run the collective on a group of one - bench.py --force-collective)
         if dist.get_backend(self.group) == "nccl":
-            if not self._shared_device_set:
-                # the collective overlaps the next step's kernels: the fused forward must not count on every compute unit
-                from . import capi
-                capi.set_shared_device(True)
-                self._shared_device_set = True
+            # (A caller that really enqueues the next step's loss before it waits for this collective sets cfg.shared_device /
+            # capi.set_shared_device so that the fused forward leaves the compute units beyond its tiles alone; the trainer waits
+            # right after the backward, so it keeps the faster one-workgroup-per-CU launch.  Nothing global is flipped here.)
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             if async_op:
                 return work

@@ -17,6 +17,7 @@ There is no CPU / pure-PyTorch fallback for the loss: non-HIP tensors raise.
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import capi
 from .featurizers import (ClusterLookup, ContrastiveCRFLoss, Decoder, DinoFeaturizer, DoubleConv,  # noqa: F401
@@ -48,6 +49,7 @@ class _DenseCorrFunction(torch.autograd.Function):
         return capi.dense_corr(a.detach(), b.detach())
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         if g is None:
@@ -180,6 +182,7 @@ class _CorrLossFunction(torch.autograd.Function):
         return loss_means[0], intra_cd, loss_means[1], inter_cd, neg_loss, neg_cd, loss_means[2]
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_intra, g_intra_cd, g_inter, g_inter_cd, g_neg_loss, g_neg_cd, g_neg_mean):
         code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd = ctx.saved_tensors[:8]
         saved = tuple(ctx.saved_tensors[8:])
@@ -218,6 +221,7 @@ class _CorrLossMeansFunction(torch.autograd.Function):
         return loss_means, intra_cd, inter_cd, neg_cd
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_means, g_intra_cd, g_inter_cd, g_neg_cd):
         code, code_pos, coords1, coords2, perms, intra_cd, inter_cd, neg_cd = ctx.saved_tensors[:8]
         saved = tuple(ctx.saved_tensors[8:])
@@ -249,6 +253,7 @@ class _HelperFunction(torch.autograd.Function):
         return loss, cd
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_loss, g_cd):
         c1, c2, cd = ctx.saved_tensors[:3]
         d1, d2 = _backend.helper_bwd(ctx.desc, c1.detach(), c2.detach(), tuple(ctx.saved_tensors[3:]), cd, g_loss, g_cd)

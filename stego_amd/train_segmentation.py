@@ -53,6 +53,8 @@ def load_config(path=None, overrides=()):
 
 MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: even, channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
+MAX_CODE_DIM_ANY_PATH = 72       # above it: the single-launch forward only (its conditions are checked in __init__)
+MI355X_COMPUTE_UNITS = 256
 
 
 class LitUnsupervisedSegmenter(nn.Module):
@@ -90,6 +92,21 @@ class LitUnsupervisedSegmenter(nn.Module):
             if cfg.feature_samples > MAX_FEATURE_SAMPLES:
                 raise ValueError("cfg.feature_samples=%d: this build supports up to %d (S*S <= 128 sample points per image; "
                                  "train_config.yml:51 ships 11)" % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
+            if dim > MAX_CODE_DIM_ANY_PATH:
+                # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
+                # csrc/corr_fused.hip): the same conditions here, with the cfg keys named
+                tiles = (2 + cfg.neg_samples) * cfg.batch_size
+                why = []
+                if dim % 2:
+                    why.append("cfg.dim must be even")
+                if cfg.arch != "dino":
+                    why.append("cfg.arch must be 'dino' (channels-last feature maps of width 384 / 768)")
+                if tiles > MI355X_COMPUTE_UNITS:
+                    why.append("(2 + cfg.neg_samples) * cfg.batch_size = %d must not exceed the %d compute units "
+                               "(one tile per workgroup, all co-resident)" % (tiles, MI355X_COMPUTE_UNITS))
+                if why:
+                    raise ValueError("cfg.dim=%d: code dimensions above %d run on the single-launch forward only: %s"
+                                     % (dim, MAX_CODE_DIM_ANY_PATH, "; ".join(why)))
         for p in self.contrastive_corr_loss_fn.parameters():
             p.requires_grad = False
         self.automatic_optimization = False
@@ -167,7 +184,8 @@ class LitUnsupervisedSegmenter(nn.Module):
         loss.backward()
         if self._reducer is not None:
             self._reducer.reattach()
-            self._grad_work = self._reducer.allreduce_mean(async_op=True)
+            # (force_collective: run the collective on a process group of ONE - the single-GPU dress rehearsal of the N > 1 path)
+            self._grad_work = self._reducer.allreduce_mean(async_op=True, single_rank_ok=getattr(self, "force_collective", False))
 
     def wait_gradients(self):
         work, self._grad_work = getattr(self, "_grad_work", None), None
@@ -379,11 +397,21 @@ class Trainer:
         if self.world <= 1 or getattr(ds, "per_rank", False) or \
                 isinstance(getattr(loader, "sampler", None), torch.utils.data.distributed.DistributedSampler):
             return loader
+        if isinstance(ds, torch.utils.data.IterableDataset):
+            raise ValueError("data-parallel training over an IterableDataset: shard it per rank yourself (set dataset.per_rank = True)")
+        if loader.batch_size is None:                  # built with batch_sampler=...: batching is not ours to redo
+            raise ValueError("data-parallel training needs a loader built with batch_size (not batch_sampler), a DistributedSampler, "
+                             "or a dataset with per_rank = True")
         shuffle = isinstance(getattr(loader, "sampler", None), torch.utils.data.RandomSampler)
-        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle, seed=0,
-                                                                 drop_last=loader.drop_last)
-        return torch.utils.data.DataLoader(ds, batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
-                                           collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last)
+        # DistributedSampler's default drop_last=False pads the last rank(s) by repeating samples - what Lightning's
+        # replace_sampler_ddp gives the reference; whether incomplete BATCHES are dropped stays the loader's own drop_last
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle, seed=0)
+        kw = dict(batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+                  pin_memory=loader.pin_memory, drop_last=loader.drop_last, timeout=loader.timeout,
+                  worker_init_fn=loader.worker_init_fn, generator=loader.generator)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
+        return torch.utils.data.DataLoader(ds, **kw)
 
     def _validate(self, model):
         model.eval()

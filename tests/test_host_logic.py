@@ -187,7 +187,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libstego_corr.so does not export %s" % n
         assert n in capi.SIGNATURES, "capi.py has no signature for %s" % n
-    assert lib.stego_abi_version() == 2
+    assert lib.stego_abi_version() == 3
 
 
 def test_library_validates_before_enqueueing():
@@ -209,15 +209,37 @@ def test_library_validates_before_enqueueing():
     assert lib.stego_error_string(0) == b"ok"
 
 
-def test_deployment_and_measurement_knobs_are_host_side():
-    """stego_debug_set: knobs 0-5 are measurement switches, knob 6 (STEGO_SHARED_DEVICE) is the deployment setting that
-    ddp.FlatGradReducer / bench.py flip when a collective shares the device; all of it is host state (no GPU needed), an index
-    outside the table is refused."""
+def test_deployment_flag_is_per_call_and_measurement_knobs_are_host_side():
+    """ABI 3: "other kernels share the device" is a flag of the DESCRIPTOR (per call), set from cfg.shared_device, an explicit
+    argument or the process default of capi.set_shared_device - never a side effect of a collective; stego_debug_set knobs are
+    measurement switches (atomics, host state, no GPU needed), an index outside the table is refused; unknown flags are refused."""
     lib = capi.load()
-    assert sorted(capi.KNOBS.values()) == list(range(7)) and capi.KNOBS["STEGO_SHARED_DEVICE"] == 6
+    cfg = O.CorrCfg()
+    mk = lambda **kw: capi.make_desc(4, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46), **kw)
+    assert mk().flags == 0 and mk(shared_device=True).flags == capi.FLAG_SHARED_DEVICE
     capi.set_shared_device(True)
-    capi.set_shared_device(False)
+    try:
+        assert mk().flags == capi.FLAG_SHARED_DEVICE and mk(shared_device=False).flags == 0
+        cfg.shared_device = False                      # the cfg key wins over the process default
+        assert mk().flags == 0
+    finally:
+        capi.set_shared_device(False)
+        del cfg.shared_device
+    assert ctypes.sizeof(capi.StegoCorrDesc) == 15 * 4
+    bad = mk()
+    bad.flags = 2
+    assert lib.stego_corr_workspace_bytes(ctypes.byref(bad)) == 0                     # unknown flag: unsupported descriptor
+    assert sorted(capi.KNOBS.values()) == list(range(7)) and capi.KNOBS["STEGO_SHARED_DEVICE"] == 6
     assert lib.stego_debug_set(99, 1) == 2 and lib.stego_debug_set(-1, 1) == 2        # STEGO_ERR_SHAPE
+    assert lib.stego_debug_occupy(0, 65536, 10, None) == 2                            # (argument check only: nothing is launched)
+
+
+def test_allreduce_does_not_touch_the_library_state():
+    """FlatGradReducer.allreduce_mean used to flip the process-wide shared-device knob on its first call (and never
+    back).  The reducer no longer imports the binding at all."""
+    import inspect
+    from stego_amd import ddp
+    assert "set_shared_device(" not in inspect.getsource(ddp.FlatGradReducer) and "import capi" not in inspect.getsource(ddp)
 
 
 # ------------------------------------------------------------------ salience-guided coordinates (cfg.use_salience)

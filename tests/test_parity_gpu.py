@@ -56,7 +56,7 @@ def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None, preci
 def test_library_loaded_is_the_in_tree_hip_extension():
     lib = capi.load()
     assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
-    assert lib.stego_abi_version() == 2
+    assert lib.stego_abi_version() == 3
     assert torch.cuda.is_available()
 
 
@@ -885,8 +885,75 @@ def test_randomised_shapes_against_the_oracle():
     assert out.stdout.strip().splitlines()[-1] == "failures: 0", out.stdout[-3000:]
 
 
+def _cfg2_capi_run(desc, d, debug=0, before=None):
+    """One forward of BASELINE config 2 through the C ABI with the library's debug knob set; every output + the saved w / means."""
+    capi.debug_set("STEGO_DEBUG", debug)
+    try:
+        if before is not None:
+            before()
+        o = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+        torch.cuda.synchronize()
+    finally:
+        capi.debug_set("STEGO_DEBUG", 0)
+    return [t.clone() for t in (o[0],) + tuple(o[1:5]) + (o[5][0], o[5][1])]
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_fused_give_up_and_repair_paths_are_bitwise_the_normal_launch(precision):
+    """The two fallback paths of the single-launch forward - what a shared or partitioned device takes - forced by the library's debug
+    bits at BASELINE config 2's full size: bit 64 = no workgroup samples in phase 1, every tile gives up waiting for its anchor (after
+    1 us) and samples it itself; bit 32 = no tile applies old_mean in its rendezvous, the last workgroup of the launch repairs all 160
+    negative tiles.  Both must give the bytes of the normal launch (same arithmetic, other schedule), and those match the fp64 oracle."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5
+    cfg = bench.Cfg()
+    prec = capi.PREC_F16X3 if precision == "f16x3" else capi.PREC_F32
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), prec)
+    for seed in (4101, 4102):                      # rotating inputs: stale bytes of the previous launch are not the right bytes
+        d = bench.make_inputs(B, C, H, W, K, S, n_neg, seed, dev)
+        assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
+        normal = _cfg2_capi_run(desc, d)
+        for bits in (64, 32, 96):
+            alt = _cfg2_capi_run(desc, d, debug=bits)
+            for x, y in zip(normal, alt):
+                assert not torch.isnan(y).any()
+                assert torch.equal(x, y), (bits, float((x - y).abs().max()))
+    ref = O.corr_loss_forward(*[d[k].cpu().numpy() for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2", "perms")],
+                              O.CorrCfg(neg_samples=n_neg))
+    alt = _cfg2_capi_run(desc, d, debug=96)
+    assert_close(alt[1].cpu().numpy().reshape(-1), ref.pos_intra_cd.reshape(-1), what="intra cd (fallback paths)")
+    assert_close(alt[3].cpu().numpy().reshape(-1), ref.neg_inter_loss.reshape(-1), atol_frac=5e-4, what="neg loss (fallback paths)")
+    assert abs(float(alt[0][2]) - float(ref.neg_inter_loss.mean())) < 1e-3 * abs(float(ref.neg_inter_loss.mean()))
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_fused_forward_beside_a_foreign_kernel_that_holds_compute_units(shared):
+    """A stand-in collective (stego_debug_occupy: 40 workgroups with 64 KB of LDS each spinning 120 us on another stream) owns compute
+    units when the forward is launched.  With the per-call flag STEGO_FLAG_SHARED_DEVICE the forward needs only its tiles' workgroups;
+    without it the workgroups that cannot be placed come late - the tiles whose anchors they own give up after their bounded spin and
+    sample themselves.  Either way: the bytes of the undisturbed launch, no NaN, no hang."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5
+    cfg = bench.Cfg()
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3, shared_device=shared)
+    side = torch.cuda.Stream()
+    for seed in (4201, 4202, 4203):
+        d = bench.make_inputs(B, C, H, W, K, S, n_neg, seed, dev)
+        quiet = _cfg2_capi_run(desc, d)
+
+        def hold():
+            capi.occupy(40, 64 * 1024, 120, stream=side)
+            torch.cuda._sleep(30000)               # let the stand-in get onto its compute units first
+        busy = _cfg2_capi_run(desc, d, before=hold)
+        for x, y in zip(quiet, busy):
+            assert not torch.isnan(y).any()
+            assert torch.equal(x, y), float((x - y).abs().max())
+
+
 def test_fused_forward_shared_device_mode_matches():
-    """STEGO_SHARED_DEVICE (set by ddp.FlatGradReducer / bench.py when a collective overlaps the step): the fused forward launches one
+    """STEGO_FLAG_SHARED_DEVICE (per call; cfg.shared_device / capi.set_shared_device): the fused forward launches one
     workgroup per tile instead of one per compute unit, a third of them take a second phase-1 pass.  Same bytes out."""
     c = GoldenCase("cfg1_B4_vits8_dinolike")
     base = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]
@@ -915,7 +982,7 @@ def test_fused_forward_at_the_largest_batch_of_a_launch(shared):
     B, C, H, W, K, S, n_neg = 36, 384, 14, 14, 70, 11, 5
     cfg = bench.Cfg()
     d = bench.make_inputs(B, C, H, W, K, S, n_neg, 5151, dev)
-    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3, shared_device=shared)
 
     def run():
         o = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
@@ -926,7 +993,6 @@ def test_fused_forward_at_the_largest_batch_of_a_launch(shared):
         capi.debug_set("STEGO_FWD_VARIANT", 1)
         ref = run()
         capi.debug_set("STEGO_FWD_VARIANT", 0)
-        capi.set_shared_device(shared)
         assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
         for rep in range(5):
             for g, r in zip(run(), ref):
@@ -934,5 +1000,34 @@ def test_fused_forward_at_the_largest_batch_of_a_launch(shared):
                 assert float((g - r).abs().max()) < 2e-6
     finally:
         capi.debug_set("STEGO_FWD_VARIANT", 0)
-        capi.set_shared_device(False)
 
+
+
+def test_nccl_world_size_one_dress_rehearsal_of_the_data_parallel_step():
+    """RCCL has never run this code with more than one rank where the builder can see it (1-GPU boxes): at least the whole N > 1 path -
+    process group on backend "nccl", flat gradient bucket, asynchronous ReduceOp.AVG launched by manual_backward, wait_gradients as a
+    stream dependency, the all-reduce captured in bench.py's step graphs - runs here on a group of ONE, and must give exactly the
+    numbers of the run without a collective (the mean over one rank is the identity)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_world1_worker.py")], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    last_json = lambda text: json.loads([l for l in text.strip().splitlines() if l.startswith("{")][-1])     # (RCCL prints its banner to stdout)
+    rec = last_json(out.stdout)
+    # (not bitwise: the torch ops of the probes' backward are not run-to-run deterministic; the collective itself is the identity)
+    assert np.allclose(rec["loss_collective"], rec["loss_plain"], rtol=1e-6, atol=0) and rec["head_equal"], rec
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "nccl_world1.json"), "w") as f:
+        json.dump(rec, f)
+    # the bench's own N > 1 protocol with the all-reduce captured in the step graphs, on a group of one
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10", "--force-collective",
+           "--launch", "graph", "--no-cpu-baseline", "--no-alt"]
+    env2 = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env2, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    b = last_json(out.stdout)
+    assert b["config"]["collective"] and b["config"]["launch"].startswith("graph") and b["value"] > 0, b["config"]
+    with open(os.path.join(root, "gpurun_out", "nccl_world1_bench.json"), "w") as f:
+        json.dump(b, f)
