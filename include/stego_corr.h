@@ -180,6 +180,19 @@ int stego_corr_fwd(const StegoCorrDesc* desc,
 int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const int64_t* const* raw_perms, int32_t n_neg,
                        int32_t B, float* coords1, float* coords2, int64_t* perms, stego_stream_t stream);
 
+/* The SAME draws from ONE launch: torch.rand(n_coord) x 2 (* 2 - 1) and torch.randperm(B) x n_neg (+ the super_perm fix-up) exactly
+ * as PyTorch-ROCm's device generator produces them from the state (seed, offset) - Philox-4x32-10 with ATen's counter layout,
+ * random_ keys, stable sort on the low key bits, reshuffle of duplicate-key islands (csrc/draws.hip restates
+ * aten/src/ATen/native/cuda/{DistributionTemplates.h, Randperm.cu, Randperm.cuh}).  The caller reads (seed, offset) from the torch
+ * generator (initial_seed(), get_offset()) and afterwards sets its offset to offset + stego_ref_draws_advance(...): the random stream of
+ * a training run is the reference's, call for call.  `variant`: bit 0 = the distribution kernels' grid is sized per `unroll` elements,
+ * bit 1 = the uniform conversion is an fma, bit 2 = randperm's keys come from the 32-bit flavour of random_ - properties of the
+ * installed torch build; stego_amd/modules.py picks the variant that
+ * reproduces the real torch calls (checked once per process) and keeps the torch calls if none does.  offset % 4 == 0, B <= 2048. */
+int stego_ref_draws(uint64_t seed, uint64_t offset, int32_t variant, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1,
+                    float* coords2, int64_t* perms, stego_stream_t stream);
+uint64_t stego_ref_draws_advance(int64_t n_coord, int32_t n_neg, int32_t B, int32_t variant);
+
 /* OPT-IN alternative to the torch draws (cfg.fast_draws): the same DISTRIBUTIONS as modules.py:366-367, 382-385 - coords
  * uniform on torch.rand's 2^-24 lattice, times 2 minus 1; one uniformly random permutation of [0, B) per negative followed by
  * the super_perm fix-up - from one kernel with its own counter-based generator (Philox-4x32-10) keyed by the 64 random bits at

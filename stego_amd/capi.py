@@ -64,6 +64,8 @@ SIGNATURES = {
     "stego_corr_fwd_prepared": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
+    "stego_ref_draws": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
+    "stego_ref_draws_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32, c_int32]),
     "stego_fast_draws": (c_int32, [_P, ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_finish_draws": (c_int32, [_P, _P, ctypes.c_int64, POINTER(ctypes.c_void_p), c_int32, c_int32, _P, _P, _P, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
@@ -256,6 +258,21 @@ def finish_draws(u1, u2, raw_perms, B):
     arr = (ctypes.c_void_p * max(n_neg, 1))(*[r.data_ptr() for r in raw_perms])
     with torch.cuda.device(dev):
         _check(lib.stego_finish_draws(_ptr(u1), _ptr(u2), u1.numel(), arr, n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+    return c1, c2, perms
+
+
+def ref_draws(gen, shape, n_neg, B, variant, dev):
+    """(coords1, coords2, perms) = the reference's torch.rand x 2 / torch.randperm x n_neg draws from ONE launch (stego_ref_draws),
+    bit for bit, advancing `gen` (the device's torch.Generator) exactly as the torch calls would."""
+    lib = load()
+    c1 = torch.empty(shape, dtype=torch.float32, device=dev)
+    c2 = torch.empty(shape, dtype=torch.float32, device=dev)
+    perms = torch.empty(n_neg, B, dtype=torch.int64, device=dev)
+    seed, off = gen.initial_seed(), gen.get_offset()
+    with torch.cuda.device(dev):
+        adv = int(lib.stego_ref_draws_advance(c1.numel(), n_neg, B, variant))
+        _check(lib.stego_ref_draws(seed & (2 ** 64 - 1), off, variant, c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+    gen.set_offset(off + adv)
     return c1, c2, perms
 
 

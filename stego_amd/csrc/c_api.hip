@@ -18,6 +18,9 @@ hipError_t launch_fast_draws(const long long* seed, long long n_coord, int n_neg
                              hipStream_t stream);
 hipError_t launch_finish_draws(const float* u1, const float* u2, long long n_coord, const long long* const* raw, int n_neg,
                                int B, float* c1, float* c2, long long* perms, hipStream_t stream);
+hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, int variant, long long n_coord, int n_neg, int B,
+                            int cus, int threads_per_cu, float* c1, float* c2, long long* perms, hipStream_t stream);
+unsigned long long ref_draws_advance(long long n_coord, int n_neg, int B, int variant, int cus, int threads_per_cu);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
@@ -350,6 +353,30 @@ int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const 
         if (!raw_perms[i]) return STEGO_ERR_NULL;
     return hip_rc(launch_finish_draws(u1, u2, n_coord, reinterpret_cast<const long long* const*>(raw_perms), n_neg, B, coords1,
                                       coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+}
+
+static int device_threads_per_cu()
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2048;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxThreadsPerMultiProcessor, dev) != hipSuccess || n <= 0) n = 2048;
+    return n;
+}
+
+int stego_ref_draws(uint64_t seed, uint64_t offset, int32_t variant, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1,
+                    float* coords2, int64_t* perms, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_coord < 0 || n_neg < 0 || B < 1 || B > 2048 || variant < 0 || variant > 7 || (offset & 3)) return STEGO_ERR_SHAPE;
+    if ((n_coord > 0 && (!coords1 || !coords2)) || (n_neg > 0 && !perms)) return STEGO_ERR_NULL;
+    return hip_rc(launch_ref_draws(seed, offset, variant, n_coord, n_neg, B, device_cu_count(), device_threads_per_cu(), coords1,
+                                   coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+}
+
+uint64_t stego_ref_draws_advance(int64_t n_coord, int32_t n_neg, int32_t B, int32_t variant)
+{
+    if (n_coord < 0 || n_neg < 0 || B < 1) return 0;
+    return ref_draws_advance(n_coord, n_neg, B, variant, device_cu_count(), device_threads_per_cu());
 }
 
 int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2,

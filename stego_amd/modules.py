@@ -120,6 +120,57 @@ def sample_nonzero_locations(t, target_size):
 # ----------------------------------------------------------------------- autograd glue
 _backend = capi      # tests may swap this for an oracle-backed double to exercise host logic on CPU
 
+# (device index, numel of a coords tensor, n_neg, B) -> variant of stego_ref_draws that reproduces the installed torch, or -1
+_REF_DRAW_VARIANTS = {}
+
+
+def _device_generator(dev):
+    if not torch.cuda.default_generators:            # (filled by the lazy CUDA / HIP initialisation)
+        torch.cuda.init()
+    return torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+
+
+def _torch_draws(shape, n, B, dev):
+    """The reference's draws as the reference makes them (modules.py:366-367, :383): seven torch calls on the device generator."""
+    out = [torch.rand(shape, device=dev), torch.rand(shape, device=dev)]
+    out += [torch.randperm(B, device=dev, dtype=torch.long) for _ in range(n)]
+    return out
+
+
+def ref_draw_variant(shape, n, B, dev):
+    """Which variant of the one-launch draws (stego_ref_draws) is bit-identical to THIS torch build's rand / randperm for these sizes -
+    found by running both from the same generator state once (the generator is left where it was); -1 = none (the torch calls stay).
+    The kernel restates ATen internals; this check is what makes relying on them safe across torch versions."""
+    numel = 1
+    for s_ in shape:
+        numel *= int(s_)
+    key = (dev.index, numel, int(n), int(B))
+    v = _REF_DRAW_VARIANTS.get(key)
+    if v is not None:
+        return v
+    v = -1
+    gen = _device_generator(dev)
+    try:
+        state = gen.get_state()
+        try:
+            ref = _torch_draws(shape, n, B, dev)
+            off_ref = gen.get_offset()
+            want1, want2 = ref[0] * 2 - 1, ref[1] * 2 - 1
+            want_p = _unfix(torch.stack(ref[2:])) if n else None
+            for cand in range(8):
+                gen.set_state(state)
+                c1, c2, perms = _backend.ref_draws(gen, shape, n, B, cand, dev)
+                if gen.get_offset() == off_ref and torch.equal(c1, want1) and torch.equal(c2, want2) and \
+                        (n == 0 or torch.equal(perms, want_p)):
+                    v = cand
+                    break
+        finally:
+            gen.set_state(state)
+    except (RuntimeError, AttributeError):
+        v = -1
+    _REF_DRAW_VARIANTS[key] = v
+    return v
+
 
 def _precision_of(cfg):
     name = getattr(cfg, "corr_precision", "f16x3")
@@ -367,6 +418,18 @@ class ContrastiveCorrelationLoss(nn.Module):
             coords1, coords2, perms = _backend.fast_draws(seed, shape, cfg.neg_samples, B)
             if cfg.neg_samples == 0:
                 perms = None
+        elif dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "ref_draws") and B <= 2048 and \
+                getattr(cfg, "one_launch_draws", True) and not torch.cuda.is_current_stream_capturing() and \
+                ref_draw_variant([B, cfg.feature_samples, cfg.feature_samples, 2], cfg.neg_samples, B, dev) >= 0:
+            # DEFAULT on a HIP device: the reference's draws - the same numbers torch.rand x 2 and torch.randperm x neg_samples give
+            # from this generator state, the generator advanced by the same amount - from ONE launch (stego_ref_draws) instead of
+            # ~30 tiny kernels.  Checked against the real torch calls once per process and size (ref_draw_variant); under stream
+            # capture the generator's state lives on the device where Python cannot read it: the torch calls below are captured.
+            shape = [B, cfg.feature_samples, cfg.feature_samples, 2]
+            gen = _device_generator(dev)
+            coords1, coords2, perms = _backend.ref_draws(gen, shape, cfg.neg_samples, B, ref_draw_variant(shape, cfg.neg_samples, B, dev), dev)
+            if cfg.neg_samples == 0:
+                perms = None
         elif dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "finish_draws"):
             # The reference's draws in the reference's order on the device generator (:366, :367, :383): torch.rand x2, then
             # one torch.randperm per negative; "* 2 - 1" and the super_perm fix-up run in ONE kernel (stego_finish_draws)
@@ -374,8 +437,7 @@ class ContrastiveCorrelationLoss(nn.Module):
             # measured SLOWER: 352 vs 268 us per replay - cross-branch edges cost more than the kernels they overlap.)
             shape = [B, cfg.feature_samples, cfg.feature_samples, 2]
             n = cfg.neg_samples
-            out = [torch.rand(shape, device=dev), torch.rand(shape, device=dev)]
-            out += [torch.randperm(B, device=dev, dtype=torch.long) for _ in range(n)]
+            out = _torch_draws(shape, n, B, dev)
             coords1, coords2, perms = _backend.finish_draws(out[0], out[1], out[2:], B)
             if n == 0:
                 perms = None

@@ -1028,6 +1028,51 @@ def test_nccl_world_size_one_dress_rehearsal_of_the_data_parallel_step():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env2, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     b = last_json(out.stdout)
-    assert b["config"]["collective"] and b["config"]["launch"].startswith("graph") and b["value"] > 0, b["config"]
+    assert b["config"]["collective"] and b["config"]["launch"].startswith("hipgraph") and "all-reduce captured" in b["config"]["launch"] and b["value"] > 0, b["config"]
     with open(os.path.join(root, "gpurun_out", "nccl_world1_bench.json"), "w") as f:
         json.dump(b, f)
+
+
+@pytest.mark.parametrize("B,S,n_neg", [(4, 11, 5), (16, 11, 5), (32, 11, 5), (36, 11, 5), (32, 7, 3), (300, 5, 2)])
+def test_one_launch_draws_are_the_torch_generator_s_rand_and_randperm(B, S, n_neg):
+    """stego_ref_draws against the seven torch calls of the reference (modules.py:366-367 torch.rand x 2, :383 super_perm = torch.randperm
+    x neg_samples) from the same generator state, over hundreds of seeds per size: every float and every index equal, the generator left
+    at the same offset.  13 key bits at B = 32 make ~6 % of the permutations hit the duplicate-key reshuffle; B = 300 (18 bits of 300
+    keys) exercises the sort."""
+    dev = torch.device("cuda:0")
+    shape = [B, S, S, 2]
+    v = M.ref_draw_variant(shape, n_neg, B, dev)
+    assert v >= 0, "no variant of stego_ref_draws reproduces this torch build: the product would fall back to the torch calls"
+    gen = M._device_generator(dev)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    dup = 0
+    n_seeds = 400 if B <= 36 else 60
+    for seed in range(n_seeds):
+        torch.manual_seed(1000 + seed)
+        if seed % 3 == 1:
+            torch.rand(5, device=dev)                       # (an offset that is not 0)
+        st = gen.get_state()
+        ref = M._torch_draws(shape, n_neg, B, dev)
+        off = gen.get_offset()
+        gen.set_state(st)
+        c1, c2, perms = capi.ref_draws(gen, shape, n_neg, B, v, dev)
+        assert gen.get_offset() == off
+        bad += (c1 != ref[0] * 2 - 1).sum() + (c2 != ref[1] * 2 - 1).sum() + (perms != M._unfix(torch.stack(ref[2:]))).sum()
+    assert int(bad) == 0
+
+
+def test_forward_with_one_launch_draws_equals_forward_with_the_torch_calls():
+    """The product path: ContrastiveCorrelationLoss.forward seeded alike with cfg.one_launch_draws on (default) and off."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 99, dev)
+    outs = []
+    for one in (True, False):
+        cfg = bench.Cfg()
+        cfg.one_launch_draws = one
+        torch.manual_seed(7)
+        o = M.ContrastiveCorrelationLoss(cfg)(d["feats"], d["feats_pos"], None, None, d["code"], d["code_pos"])
+        outs.append([t.detach().clone() for t in o] + [torch.rand(3, device=dev)])          # + the generator's next numbers
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
