@@ -147,6 +147,7 @@ struct FusedParams {
     int KQ, LDK;
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int n_owner;                               // workgroups [0, n_owner) share phase 1
+    int ps_round;                              // pair-sets per round of tiles (all of them unless there are more tiles than CUs)
     int pointwise;
     int debug;                                 // 32 never rendezvous (always repair), 64 owners skip phase 1 (always help),
                                                // 256 phase stamps

@@ -83,9 +83,9 @@ __device__ __forceinline__ unsigned long long lanes_below(int lane) { return lan
 
 // ------------------------------------------------------------------------------------------ tile placement
 // XCD preference of tile t = (p, b): the image its B side is gathered from, modulo 8.
-__device__ __forceinline__ int tile_pref(const FusedParams& prm, int t, int n_tiles)
+__device__ __forceinline__ int tile_pref(const FusedParams& prm, int t, int t_end)
 {
-    if (t >= n_tiles) return -1;
+    if (t >= t_end) return -1;
     const int B = prm.B;
     const int p = t / B, b = t - p * B;
     int src = b;
@@ -94,40 +94,45 @@ __device__ __forceinline__ int tile_pref(const FusedParams& prm, int t, int n_ti
 }
 
 // Bijection workgroups <-> tiles, computed redundantly by every wave (perms is device data: the host cannot build it
-// without a sync).  Workgroup w sits on XCD w % 8 (slot w / 8).  The r-th tile (in tile order) that prefers XCD x takes
+// without a sync) - per ROUND: the workgroups [w0, w0 + n_tiles) take the tiles [w0, w0 + n_tiles) (whole pair-sets, see the kernel).
+// Workgroup w sits on XCD w % 8 (its slot: its rank among the round's workgroups of that XCD).  The r-th tile (in tile order) that prefers XCD x takes
 // slot r of x while x has slots; tiles beyond that ("overflow") fill the slots other XCDs leave free, in order.
 // Tiles are visited in blocks of 4 x 64 whose perms loads are issued together (one round trip for <= 256 tiles).
 constexpr int ASSIGN_NB = 4;
 
 // the loads of the first block, issued at the top of the kernel so that they fly together with phase 1's
-__device__ __forceinline__ void assign_prefetch(const FusedParams& prm, int lane, int (&pref)[ASSIGN_NB])
+template <bool WINDOW>
+__device__ __forceinline__ void assign_prefetch(const FusedParams& prm, int lane, int w0_, int n_tiles, int (&pref)[ASSIGN_NB])
 {
-    const int n_tiles = prm.n_sets * prm.B;
+    const int w0 = WINDOW ? w0_ : 0;
 #pragma unroll
-    for (int i = 0; i < ASSIGN_NB; ++i) pref[i] = tile_pref(prm, 64 * i + lane, n_tiles);
+    for (int i = 0; i < ASSIGN_NB; ++i) pref[i] = tile_pref(prm, w0 + 64 * i + lane, w0 + n_tiles);
 }
 
-__device__ int assign_tile(const FusedParams& prm, int me, int lane, const int (&pref0)[ASSIGN_NB])
+template <bool WINDOW>                                   // (false: one round, w0 = 0 folded - the common case keeps its old code)
+__device__ int assign_tile(const FusedParams& prm, int me, int lane, int w0_, int n_tiles, const int (&pref0)[ASSIGN_NB])
 {
-    const int n_tiles = prm.n_sets * prm.B;
     constexpr int NB = ASSIGN_NB;
+    const int w0 = WINDOW ? w0_ : 0;
+    const int x0 = w0 & 7;                               // XCD of the round's first workgroup
+    auto nslots = [&](int x) { return (n_tiles - ((x - x0) & 7) + 7) >> 3; };      // workgroups of the round on XCD x
     int cnt[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) cnt[x] = 0;
     int pref[NB];
     for (int c0 = 0; c0 < n_tiles; c0 += 64 * NB) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, c0 + 64 * i + lane, n_tiles);
+        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int x = 0; x < 8; ++x) cnt[x] += __builtin_popcountll(__ballot(pref[i] == x));
     }
-    const int xme = me & 7, rme = me >> 3;
+    const int xme = me & 7, rme = (me - w0) >> 3;        // ((me - w0) - ((xme - x0) & 7)) / 8: the remainder is < 8
     int cnt_me = 0, k = 0;
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-        const int nslot = (n_tiles - x + 7) >> 3;
+        const int nslot = nslots(x);
         if (x == xme) cnt_me = cnt[x];
         if (x < xme) k += max(0, nslot - cnt[x]);
     }
@@ -140,14 +145,14 @@ __device__ int assign_tile(const FusedParams& prm, int me, int lane, const int (
     const unsigned long long below = lanes_below(lane);
     for (int c0 = 0; c0 < n_tiles; c0 += 64 * NB) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, c0 + 64 * i + lane, n_tiles);
+        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int myrank = 0, myslots = 0;
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
                 const unsigned long long m = __ballot(pref[i] == x);
-                if (pref[i] == x) { myrank = base[x] + __builtin_popcountll(m & below); myslots = (n_tiles - x + 7) >> 3; }
+                if (pref[i] == x) { myrank = base[x] + __builtin_popcountll(m & below); myslots = nslots(x); }
                 base[x] += __builtin_popcountll(m);
             }
             const bool ovf = pref[i] >= 0 && myrank >= myslots;
@@ -159,7 +164,7 @@ __device__ int assign_tile(const FusedParams& prm, int me, int lane, const int (
             if (hm) result = c0 + 64 * i + __builtin_ctzll(hm);
         }
     }
-    return __builtin_amdgcn_readfirstlane(result);
+    return w0 + __builtin_amdgcn_readfirstlane(result);
 }
 
 // ------------------------------------------------------------------------------------------ phase 1: anchor sets
@@ -803,9 +808,22 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     // ---- which tile am I: the first gather wave works it out (ballots over perms, ~1.3 us), everybody else picks it up from LDS
     int tile;
     if (wave8 == 4) {
+        // More tiles than compute units (B = 64 with 5 negatives: 448): ROUNDS of whole pair-sets - the old_mean rendezvous of a
+        // pair-set is between workgroups that run at the same time - of ps_round * B tiles each; the workgroups of round r are
+        // the r-th window of the grid and start as the compute units of earlier workgroups become free (every workgroup needs a whole
+        // one: 136 KB of LDS).  Should the hardware start a later window first, its tiles' bounded spins fall back on the repair
+        // path: slower, never wrong.  A later round finds its anchors ready (phase 1 belongs to the first n_owner workgroups).
+        const int per_round = prm.ps_round * B;
         int pref0[ASSIGN_NB];
-        assign_prefetch(prm, lane, pref0);
-        tile = assign_tile(prm, me, lane, pref0);
+        if (per_round >= n_tiles) {              // one round (workgroup-uniform)
+            assign_prefetch<false>(prm, lane, 0, n_tiles, pref0);
+            tile = assign_tile<false>(prm, me, lane, 0, n_tiles, pref0);
+        } else {
+            const int w0 = (me / per_round) * per_round;
+            const int ntr = n_tiles - w0 < per_round ? n_tiles - w0 : per_round;
+            assign_prefetch<true>(prm, lane, w0, ntr, pref0);
+            tile = assign_tile<true>(prm, me, lane, w0, ntr, pref0);
+        }
         if (lane == 0) __hip_atomic_store(tile_slot, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((prm.debug & 256) && lane == 0) ts[6] = __builtin_amdgcn_s_memrealtime();
     } else {
@@ -1380,10 +1398,9 @@ bool fused_supported(const FusedParams& prm, int precision)
         return m.sc == 1 && (m.sn % 2) == 0 && (m.sh % 2) == 0 && (m.sw % 2) == 0 && (reinterpret_cast<uintptr_t>(m.p) % 8) == 0;
     };
     if (!(prm.C == 384 || prm.C == 768)) return false;                         // NJ instantiations below
-    // One workgroup per tile, all of them co-resident (136 KB of LDS: one per CU): the in-launch hand-offs (anchors, old_mean)
-    // are between workgroups that run at the same time.  More tiles than CUs (B = 64 with 5 negatives: 448) would leave
-    // first-round workgroups spinning to their timeout for tiles that cannot start: those batches take the three-launch path.
-    if ((2 + prm.n_neg) * prm.B > device_cu_count()) return false;
+    // One workgroup per compute unit at a time (136 KB of LDS): the in-launch hand-offs (anchors, old_mean) are between workgroups
+    // that run at the same time.  More tiles than CUs run as rounds of whole pair-sets (see the kernel), so a pair-set must fit:
+    if (prm.B > (device_cu_count() & ~7)) return false;                       // (one pair-set = B tiles per round at least)
     if (!cl4(prm.feats) || !cl4(prm.feats_pos) || !cl2(prm.code) || !cl2(prm.code_pos)) return false;
     if (prm.K % 2 != 0 || prm.K > 128) return false;                            // four code K-chunks of <= 32 channels
     if (prm.H > 256 || prm.W > 256) return false;                             // packed tap coordinates (8 bits each)
@@ -1410,6 +1427,8 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     // helper that cannot be placed would hold up its anchors - and their 7 tiles each - for as long as the other kernel runs.
     // Then the tiles' own workgroups share phase 1 (a third of them take a second pass) and the CUs beyond the tiles stay free.
     const int all = (cus & ~7) < 8 ? 8 : (cus & ~7);
+    // rounds of whole pair-sets: as many as fit the compute units at once (all 2 + n_neg of them when n_tiles <= CUs)
+    prm.ps_round = all / prm.B < 1 ? 1 : (all / prm.B > prm.n_sets ? prm.n_sets : all / prm.B);
     const int sd = shared_device ? 1 : knob(KNOB_SHARED_DEVICE);       // (the knob: tools only - a per-call setting is a descriptor flag)
     prm.n_owner = sd == 0 ? all : (n_tiles < all ? n_tiles : all);
     if (sd > 8) {                          // (tools: an explicit number of phase-1 owners between the two, a multiple of 8)

@@ -95,15 +95,14 @@ class LitUnsupervisedSegmenter(nn.Module):
             if dim > MAX_CODE_DIM_ANY_PATH:
                 # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
                 # csrc/corr_fused.hip): the same conditions here, with the cfg keys named
-                tiles = (2 + cfg.neg_samples) * cfg.batch_size
                 why = []
                 if dim % 2:
                     why.append("cfg.dim must be even")
                 if cfg.arch != "dino":
                     why.append("cfg.arch must be 'dino' (channels-last feature maps of width 384 / 768)")
-                if tiles > MI355X_COMPUTE_UNITS:
-                    why.append("(2 + cfg.neg_samples) * cfg.batch_size = %d must not exceed the %d compute units "
-                               "(one tile per workgroup, all co-resident)" % (tiles, MI355X_COMPUTE_UNITS))
+                if cfg.batch_size > MI355X_COMPUTE_UNITS:
+                    why.append("cfg.batch_size = %d must not exceed the %d compute units (the tiles of one pair-set run at the "
+                               "same time)" % (cfg.batch_size, MI355X_COMPUTE_UNITS))
                 if why:
                     raise ValueError("cfg.dim=%d: code dimensions above %d run on the single-launch forward only: %s"
                                      % (dim, MAX_CODE_DIM_ANY_PATH, "; ".join(why)))

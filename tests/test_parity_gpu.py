@@ -738,20 +738,57 @@ def test_fused_path_edge_shapes(shape, precision):
     assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
 
 
-def test_more_tiles_than_compute_units_take_the_three_launch_path():
-    """B = 40 with 5 negatives = 280 tiles > 256 CUs: the fused kernel's workgroups would not all be resident, so its in-launch
-    hand-offs would spin to their timeouts; such batches are routed to the three-launch forward (same results)."""
-    shape = dict(B=40, C=384, H=6, W=6, K=8, S=3, n_neg=5)
-    d = O.synth_inputs(seed=26, **shape)
-    cfg = O.CorrCfg(feature_samples=3, neg_samples=5)
+@pytest.mark.parametrize("B,K,precision", [(40, 8, "f16x3"), (48, 70, "f16x3"), (64, 70, "f32"), (64, 100, "f16x3"), (100, 70, "f16x3")])
+def test_more_tiles_than_compute_units_run_in_rounds_of_whole_pair_sets(B, K, precision):
+    """(2 + 5) * B tiles > 256 compute units (the reference's batch_size is free, train_config.yml:11; B = 64 is an obvious way to use a
+    288 GB GPU): the single-launch forward takes them in ROUNDS of whole pair-sets - 6 + 1 pair-sets at B = 40, 5 + 2 at 48, 4 + 3 at 64,
+    2 + 2 + 2 + 1 at 100 - the later windows of the grid starting as compute units become free.  Forward and backward against the fp64
+    oracle; K = 100 is a code dimension that only exists on this path."""
+    S, n_neg, H, W = 5, 5, 9, 7
+    d = O.synth_inputs(B, 384, H, W, K, S, n_neg, seed=260 + B, dino_like=True)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
     inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
     cl = {k: _channels_last(_dev(d[k])) for k in ("feats", "feats_pos", "code", "code_pos")}
-    desc = capi.make_desc(40, 384, 8, 6, 6, 3, 5, cfg, (.18, .12, .46))
-    assert capi.corr_fwd_launches(desc, cl["feats"], cl["feats_pos"], cl["code"], cl["code_pos"]) == 3
-    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3", grad=False)
+    desc = capi.make_desc(B, 384, K, H, W, S, n_neg, cfg, (.18, .12, .46))
+    assert capi.corr_fwd_launches(desc, cl["feats"], cl["feats_pos"], cl["code"], cl["code_pos"]) == 1
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
     ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=5e-4, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=5e-4, what="inter_cd")
     assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
     assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=5e-4, what="neg_cd")
+    scale = float(np.mean(np.abs(ref.neg_inter_loss)))
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_intra_loss))
+    assert abs(float(r["out"][2]) - float(ref.pos_inter_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_inter_loss))
+    numel = B * S ** 4
+    g_nl = np.full((n_neg * B,) + (S,) * 4, 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=2e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=2e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_batch_64_at_full_size_single_launch_against_the_three_launch_path():
+    """B = 64 at BASELINE config 2's map size: 448 tiles in two rounds (4 + 3 pair-sets), every output against the three-launch forward
+    of the same library, on rotating inputs."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 64, 384, 28, 28, 70, 11, 5
+    cfg = bench.Cfg()
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+    try:
+        for seed in (6401, 6402):
+            d = bench.make_inputs(B, C, H, W, K, S, n_neg, seed, dev)
+            capi.debug_set("STEGO_FWD_VARIANT", 1)
+            ref = _cfg2_capi_run(desc, d)
+            capi.debug_set("STEGO_FWD_VARIANT", 0)
+            assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
+            for rep in range(2):
+                got = _cfg2_capi_run(desc, d)
+                for g, r in zip(got, ref):
+                    assert not torch.isnan(g).any()
+                    assert float((g - r).abs().max()) < 3e-6
+    finally:
+        capi.debug_set("STEGO_FWD_VARIANT", 0)
 
 
 def test_split_fp16_backward_error_stays_in_the_fp32_class():
