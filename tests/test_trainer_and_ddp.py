@@ -439,3 +439,69 @@ def test_trainer_shards_a_plain_loader_across_ranks(monkeypatch):
     syn = torch.utils.data.DataLoader(T.SyntheticContrastiveDataset(8, 32, 5, seed=0), batch_size=4)
     assert tr._shard_loader(syn) is syn
 
+
+
+# ------------------------------------------------------------------ on-disk formats against artefacts the REFERENCE's code produced
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("crop_type", ["five", "random"])
+def test_cropped_tree_written_by_the_reference_is_read_and_reproduced(crop_type, tmp_path):
+    """tests/golden/cropped_ref/ was written by the unmodified RandomCropComputer.__getitem__ / random_crops / five_crops of the
+    reference (oracle/make_format_golden.py drives /root/reference/src/crop_datasets.py:14-123).  stego_amd.data.CroppedDataset reads
+    it with the reference reader's semantics (data.py:370-400: target - 1, mask = target == -1), and stego_amd.data.write_cropped
+    writes the same files from the same source items (same boxes, same uint8 conversions; labels bit for bit, JPEGs pixel for pixel)."""
+    from PIL import Image
+    from stego_amd import data as D
+    root = os.path.join(GOLD, "cropped_ref")
+    src = np.load(os.path.join(root, "source_items.npz"))
+    items = [(torch.from_numpy(src["img%d" % i]), torch.from_numpy(src["label%d" % i])) for i in range(2)]
+    ds = D.CroppedDataset(root, "toyset", crop_type, 0.5, "train")
+    assert len(ds) == 10
+    n = D.write_cropped(str(tmp_path), "toyset", crop_type, 0.5, "train", items)
+    assert n == 10
+    mine = D.crop_dir(str(tmp_path), "toyset", crop_type, 0.5)
+    for idx in range(10):
+        image, target, mask = ds[idx]
+        item, crop_num = divmod(idx, 5)
+        img, label = items[item]
+        H, W = label.shape
+        ch, cw = int(H * 0.5), int(W * 0.5)
+        boxes = D.five_crop_boxes(H, W, ch, cw) if crop_type == "five" else D.random_crop_boxes(H, W, ch, cw, item)
+        t, l = boxes[crop_num]
+        assert torch.equal(target, label[t:t + ch, l:l + cw])                       # labels survive the + 1 / - 1 round trip exactly
+        assert torch.equal(mask.squeeze(0), label[t:t + ch, l:l + cw] == -1)
+        assert image.shape == (3, ch, cw) and float((image - img[:, t:t + ch, l:l + cw]).abs().mean()) < 0.3    # (JPEG of white noise)
+        for sub, ext in (("img", "jpg"), ("label", "png")):
+            a = np.asarray(Image.open(os.path.join(ds.root, sub, "train", "%d.%s" % (idx, ext))))
+            b = np.asarray(Image.open(os.path.join(mine, sub, "train", "%d.%s" % (idx, ext))))
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("arch", ["vit_small", "vit_base"])
+def test_state_dict_is_key_for_key_the_reference_lightning_checkpoint(arch, tmp_path):
+    """tests/golden/ref_ckpt_manifest.json lists the state_dict of the reference's LitUnsupervisedSegmenter (keys, shapes, dtypes taken
+    from the reference's own DinoFeaturizer / ClusterLookup classes, train_segmentation.py:53-106).  This build's module tree must have
+    exactly those entries, and a checkpoint in Lightning 1.2's layout holding them loads with strict=True."""
+    import json
+    with open(os.path.join(GOLD, "ref_ckpt_manifest.json")) as f:
+        man = json.load(f)
+    m = man[arch]
+    cfg = load_config(overrides=["model_type=%s" % arch, "dino_patch_size=8", "dim=%d" % m["dim"], "extra_clusters=%d" % m["extra_clusters"],
+                                 "native_backbone=False"])
+    model = LitUnsupervisedSegmenter(m["n_classes"], cfg).cpu()
+    mine = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
+    assert mine == m["state_dict"]
+    g = torch.Generator().manual_seed(3)
+    sd = {k: torch.randn(shape, generator=g).to(getattr(torch, dt.split(".")[1])) for k, (shape, dt) in m["state_dict"].items()}
+    ck = {k: None for k in man["lightning_1_2_top_level_keys"]}
+    ck.update({"epoch": 2, "global_step": 1234, "pytorch-lightning_version": "1.2.10", "callbacks": {}, "optimizer_states": [],
+               "lr_schedulers": [], "state_dict": sd, "hparams_name": "kwargs",
+               "hyper_parameters": {"n_classes": m["n_classes"], "cfg": {k: v for k, v in vars(cfg).items()}}})
+    assert sorted(ck["hyper_parameters"]) == sorted(man["hyper_parameters_keys"])
+    path = str(tmp_path / "ref_layout.ckpt")
+    torch.save(ck, path)
+    loaded = LitUnsupervisedSegmenter.load_from_checkpoint(path, strict=True)
+    assert loaded.global_step == 1234 and loaded.n_classes == m["n_classes"]
+    for k, v in loaded.state_dict().items():
+        assert torch.equal(v, sd[k]), k
