@@ -38,6 +38,13 @@ class StegoVitDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("B", "H", "W", "patch", "D", "depth", "heads", "hidden")]
 
 
+class StegoHeadDesc(Structure):
+    """include/stego_head.h"""
+    _fields_ = [("B", c_int32), ("HW", c_int32), ("C", c_int32), ("K", c_int32), ("nonlinear", c_int32),
+                ("tok_stride", c_int64), ("img_stride", c_int64)]
+
+
+_H = POINTER(StegoHeadDesc)
 _D = POINTER(StegoCorrDesc)
 _M = POINTER(StegoMap)
 _V = POINTER(StegoVitDesc)
@@ -47,6 +54,10 @@ SIGNATURES = {
     "stego_vit_workspace_bytes": (c_size_t, [_V]),
     "stego_vit_pack_weights": (c_int32, [_V, POINTER(ctypes.c_void_p), c_int32, _P, c_size_t, _P]),
     "stego_vit_forward": (c_int32, [_V, _P, _P, _P, _P, c_size_t, _P]),
+    "stego_head_fwd_workspace_bytes": (c_size_t, [_H]),
+    "stego_head_bwd_workspace_bytes": (c_size_t, [_H]),
+    "stego_head_fwd": (c_int32, [_H] + [_P] * 10 + [_P] * 3 + [_P, c_size_t, _P]),
+    "stego_head_bwd": (c_int32, [_H] + [_P] * 6 + [_P] * 6 + [_P, c_size_t, _P]),
     "stego_abi_version": (c_int32, []),
     "stego_debug_set": (c_int32, [c_int32, c_int32]),
     "stego_debug_occupy": (c_int32, [c_int32, c_int32, c_int32, _P]),
@@ -460,3 +471,58 @@ def dense_corr(a, b, normalize=False):
         _check(lib.stego_dense_corr(byref(ma), byref(mb), B, C, H1, W1, H2, W2, 1 if normalize else 0, _ptr(out), _ptr(ws),
                                     ws.numel(), _stream()))
     return out
+
+
+# ------------------------------------------------------------------ segmentation head (include/stego_head.h)
+def head_desc(tokens, K, nonlinear):
+    """tokens: fp32 [B, HW, C] view with a dense channel axis (e.g. feat[:, 1:, :] of the backbone: the class token is skipped by
+    the view's offset, the image stride stays (1 + HW) * C)."""
+    if tokens.dim() != 3 or tokens.dtype != torch.float32 or tokens.stride(2) != 1:
+        raise RuntimeError("head: expected a float32 [B, HW, C] token tensor with contiguous channels")
+    B, HW, C = tokens.shape
+    return StegoHeadDesc(B, HW, C, int(K), 1 if nonlinear else 0, tokens.stride(1), tokens.stride(0) if B > 1 else HW * tokens.stride(1))
+
+
+def head_fwd(tokens, masks, w1, b1, w21, b21, w22, b22, need_grad, want_feats):
+    """stego_head_fwd.  masks = (m1, m2, m3) fp32 [B, C] each or None.  Returns (code [B, HW, K], feats_out [B, HW, C] or None,
+    saved_h or None)."""
+    _require_dev(tokens, w1, b1)
+    lib = load()
+    dev = tokens.device
+    nonlinear = w21 is not None
+    d = head_desc(tokens, w1.shape[0], nonlinear)
+    B, HW, C, K = d.B, d.HW, d.C, d.K
+    code = torch.empty(B, HW, K, dtype=torch.float32, device=dev)
+    feats = torch.empty(B, HW, C, dtype=torch.float32, device=dev) if want_feats else None
+    saved_h = torch.empty(B * HW * C + 8, dtype=torch.float32, device=dev) if (nonlinear and need_grad) else None
+    nws = int(lib.stego_head_fwd_workspace_bytes(byref(d)))
+    if nws == 0:
+        raise RuntimeError("stego_head_fwd: unsupported shape (C a multiple of 32, K <= 128, 16-byte token rows)")
+    ws = _empty_bytes(nws if (nonlinear and saved_h is None) else 256, dev)
+    m1, m2, m3 = masks if masks is not None else (None, None, None)
+    with _on_device(dev):
+        _check(lib.stego_head_fwd(byref(d), _ptr(tokens), _ptr(m1), _ptr(m2), _ptr(m3), _ptr(w1), _ptr(b1), _ptr(w21), _ptr(b21),
+                                  _ptr(w22), _ptr(b22), _ptr(code), _ptr(feats), _ptr(saved_h), _ptr(ws), ws.numel(), _stream()))
+    return code, feats, saved_h
+
+
+def head_bwd(tokens, masks, saved_h, w22, d_code, K):
+    """stego_head_bwd -> (dw1, db1, dw21, db21, dw22, db22) (the cluster2 entries None for a linear head)."""
+    _require_dev(tokens, d_code)
+    lib = load()
+    dev = tokens.device
+    nonlinear = saved_h is not None
+    d = head_desc(tokens, K, nonlinear)
+    C = d.C
+    f32 = dict(dtype=torch.float32, device=dev)
+    dw1, db1 = torch.empty(K, C, **f32), torch.empty(K, **f32)
+    dw21 = db21 = dw22 = db22 = None
+    if nonlinear:
+        dw21, db21, dw22, db22 = torch.empty(C, C, **f32), torch.empty(C, **f32), torch.empty(K, C, **f32), torch.empty(K, **f32)
+    d_code = _dense(d_code, torch.float32)
+    ws = _empty_bytes(lib.stego_head_bwd_workspace_bytes(byref(d)), dev)
+    m1, m2 = (masks[0], masks[1]) if masks is not None else (None, None)
+    with _on_device(dev):
+        _check(lib.stego_head_bwd(byref(d), _ptr(tokens), _ptr(m1), _ptr(m2), _ptr(saved_h), _ptr(w22), _ptr(d_code),
+                                  _ptr(dw1), _ptr(db1), _ptr(dw21), _ptr(db21), _ptr(dw22), _ptr(db22), _ptr(ws), ws.numel(), _stream()))
+    return dw1, db1, dw21, db21, dw22, db22

@@ -86,6 +86,41 @@ class _TokenLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _NativeHeadFunction(torch.autograd.Function):
+    """The segmentation head on the hand-written kernels of include/stego_head.h (modules.py:108-116): the three 1x1 convolutions as
+    split-fp16 GEMMs over the token matrix with the Dropout2d masks applied while the tokens are staged, the dropped-out feature
+    map written on the way; backward = the six parameter gradients (the backbone is frozen: the tokens get none)."""
+
+    @staticmethod
+    def forward(ctx, tokens, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats):
+        from . import capi
+        need_grad = any(t is not None and t.requires_grad for t in (w1, b1, w21, b21, w22, b22))
+        masks = (m1, m2, m3) if m1 is not None else None
+        det = lambda t: None if t is None else t.detach()
+        code, feats, saved_h = capi.head_fwd(tokens.detach(), masks, det(w1), det(b1), det(w21), det(b21), det(w22), det(b22),
+                                             need_grad, want_feats)
+        ctx.set_materialize_grads(False)
+        ctx.K = w1.shape[0]
+        ctx.nonlinear = w21 is not None
+        if need_grad:
+            ctx.save_for_backward(tokens, m1, m2, saved_h, w22)
+        if feats is not None:
+            ctx.mark_non_differentiable(feats)
+        return code, feats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_code, _g_feats):
+        from . import capi
+        if g_code is None:
+            return (None,) * 11
+        tokens, m1, m2, saved_h, w22 = ctx.saved_tensors
+        masks = (m1, m2, None) if m1 is not None else None
+        dw1, db1, dw21, db21, dw22, db22 = capi.head_bwd(tokens, masks, saved_h if ctx.nonlinear else None,
+                                                          w22.detach() if w22 is not None else None, g_code, ctx.K)
+        return None, None, None, None, dw1, db1, dw21, db21, dw22, db22, None
+
+
 class DinoFeaturizer(nn.Module):
     """Frozen DINO ViT + trainable 1x1-conv segmentation head.  forward(img) -> (feats, code) with
     feats a channels-last strided VIEW [B,C,h,w] of the tokens - the layout the loss kernels want."""
@@ -193,10 +228,52 @@ class DinoFeaturizer(nn.Module):
                 raise ValueError("Unknown feat type:{}".format(self.feat_type))
 
         if self.proj_type is not None:
+            if self._native_head_ok(image_feat):
+                return self._head_native(image_feat)
             code = self._head(image_feat)
         else:
             code = image_feat
         return (self.dropout(image_feat) if self.cfg.dropout else image_feat), code
+
+    def _native_head_ok(self, image_feat):
+        """The hand-written head kernels (include/stego_head.h) take channels-last fp32 token maps on a HIP device; cfg.native_head
+        (default True) turns them off."""
+        return (image_feat.is_cuda and image_feat.dtype == torch.float32 and image_feat.stride(1) == 1 and image_feat.dim() == 4
+                and getattr(self.cfg, "native_head", True) and image_feat.shape[1] % 32 == 0 and self.dim <= 128
+                and image_feat.stride(3) % 4 == 0 and image_feat.stride(0) % 4 == 0
+                and image_feat.stride(2) == image_feat.shape[3] * image_feat.stride(3))
+
+    def _head_native(self, image_feat):
+        """forward()'s tail on the native head: (feats, code) exactly as modules.py:108-116 returns them.  The three Dropout2d draws are
+        made with the torch calls F.dropout2d makes, in the reference's order (cluster1's input :109, cluster2's :111, the returned
+        map :114), so a seeded run consumes the generator like the reference; the masks go to the kernel as [B, C] scale vectors."""
+        B, C, fh, fw = image_feat.shape
+        tok = image_feat.permute(0, 2, 3, 1).reshape(B, fh * fw, C) if image_feat.is_contiguous(memory_format=torch.channels_last) \
+            else image_feat.permute(0, 2, 3, 1).flatten(1, 2)          # a VIEW [B, hw, C] (the class token stays skipped by strides)
+        nonlinear = self.proj_type == "nonlinear"
+        m1 = m2 = m3 = None
+        if self.training:
+            m1 = self._feature_noise(image_feat).view(B, C)
+            if nonlinear:
+                m2 = self._feature_noise(image_feat).view(B, C)
+            if self.cfg.dropout:
+                m3 = self._feature_noise(image_feat).view(B, C)
+            if m2 is None:
+                m2 = m1                                                 # (unused by a linear head; keeps the argument list dense)
+            if m3 is None:
+                m3 = torch.ones_like(m1) if self.cfg.dropout else m1
+        want_feats = bool(self.cfg.dropout and self.training)
+        c1 = self.cluster1[0]
+        w1, b1 = c1.weight.view(c1.out_channels, c1.in_channels), c1.bias
+        w21 = b21 = w22 = b22 = None
+        if nonlinear:
+            c20, c22 = self.cluster2[0], self.cluster2[2]
+            w21, b21 = c20.weight.view(c20.out_channels, c20.in_channels), c20.bias
+            w22, b22 = c22.weight.view(c22.out_channels, c22.in_channels), c22.bias
+        code, feats = _NativeHeadFunction.apply(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats)
+        code = code.view(B, fh, fw, self.dim).permute(0, 3, 1, 2)
+        feats = feats.view(B, fh, fw, C).permute(0, 3, 1, 2) if feats is not None else image_feat
+        return feats, code
 
     def _feature_noise(self, x):
         """The channel mask of nn.Dropout2d, drawn exactly as ATen's feature dropout draws it (a [B,C,1,1] tensor filled

@@ -79,8 +79,25 @@ def step_cached():
     loss.backward()
 
 
+cfg.native_head = False                 # the torch head (F.linear / bmm over the token matrix), round 2
+res["cached_tokens_torch_head"] = {"step_ms": timed(step_cached, 30)}
+cfg.native_head = True                  # the hand-written head (include/stego_head.h), round 3: the default
 res["cached_tokens"] = {"step_ms": timed(step_cached, 30), "misses": cache.misses,
                         "table_MB": cache.tokens.numel() * 2 / 1e6}
+tok = cache.tokens[idx].float()
+image_feat = tok[:, 1:, :].reshape(2 * B, 28, 28, -1).permute(0, 3, 1, 2)
+up = torch.randn(2 * B, 70, 28, 28, device=dev) / 784
+
+
+def head_only(native):
+    cfg.native_head = native
+    f, c = net._head_native(image_feat) if native else (net.dropout(image_feat), net._head(image_feat))
+    for p in params: p.grad = None
+    (c * up).sum().backward()
+
+
+res["head_fwd_bwd_ms"] = {"native": timed(lambda: head_only(True), 30), "torch": timed(lambda: head_only(False), 30)}
+cfg.native_head = True
 print(json.dumps({"metric": "training step, B=%d pairs, ViT-S/8 224^2 (backbone on 2B images + head + correspondence loss fwd+bwd + head bwd)" % B,
                   "unit": "ms", **res,
                   "pairs_per_s_native": B / res["native_backbone"]["step_ms"] * 1e3,
