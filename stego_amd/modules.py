@@ -331,6 +331,8 @@ class ContrastiveCorrelationLoss(nn.Module):
         """(loss, cd) for already-sampled f1,f2 [N,C,S1,S2] / c1,c2 [N,K,S1,S2] (modules.py:325-347)."""
         N, C, S1, S2 = f1.shape
         K = c1.shape[1]
+        if f1.is_cuda and (S1 * S2 > 128 or K > 72):               # limits of stego_corr_helper_fwd (include/stego_corr.h)
+            return self.generic_helper(f1, f2, c1, c2, shift)
         desc = capi.make_desc(N, C, K, S1, S2, S2, 0, self.cfg, (shift, shift, shift), _precision_of(self.cfg))
         return _HelperFunction.apply(f1, f2, c1, c2, desc)
 
@@ -352,12 +354,65 @@ class ContrastiveCorrelationLoss(nn.Module):
             coords2 = torch.rand(coord_shape, device=dev) * 2 - 1
         return coords1, coords2
 
+    @staticmethod
+    def fused_kernels_cover(B, C, K, H, W, S):
+        """Does the hand-written loss path (stego_corr_fwd / _bwd, include/stego_corr.h "Limits of this build") take this shape?
+        S * S <= 128 sample points per image; K <= 72 on any layout; 72 < K <= 128 on the single-launch forward (K even, ViT widths,
+        B and the map within its bounds).  Everything else - e.g. cfg.feature_samples = 16 - is computed by generic_forward()."""
+        if S * S > 128 or K > 128 or H > 32767 or W > 32767:
+            return False
+        if K > 72:
+            return K % 2 == 0 and C in (384, 768) and B <= 256 and H <= 256 and W <= 256
+        return True
+
+    def generic_helper(self, f1, f2, c1, c2, shift):
+        """modules.py:325-347 with its einsums on the native dense-correspondence kernel (tensor_correlation -> stego_dense_corr,
+        forward and both adjoints) and the elementwise work in torch: the path of shapes the fused kernels do not cover."""
+        cfg = self.cfg
+        with torch.no_grad():
+            fd = tensor_correlation(norm(f1), norm(f2))
+            if cfg.pointwise:
+                old_mean = fd.mean()
+                fd -= fd.mean([3, 4], keepdim=True)
+                fd = fd - fd.mean() + old_mean
+        cd = tensor_correlation(norm(c1), norm(c2))
+        min_val = 0.0 if cfg.zero_clamp else -9999.0
+        if cfg.stabalize:
+            loss = -cd.clamp(min_val, .8) * (fd - shift)
+        else:
+            loss = -cd.clamp(min_val) * (fd - shift)
+        return loss, cd
+
+    def generic_forward(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
+        """modules.py:369-398 for any shape (any cfg.feature_samples, any cfg.dim): sample() with torch's grid_sample, the two
+        correlation tensors of every pair-set on the native dense kernel, the rest elementwise.  Same six return values."""
+        cfg = self.cfg
+        feats, code = sample(orig_feats, coords1), sample(orig_code, coords1)
+        feats_pos, code_pos = sample(orig_feats_pos, coords2), sample(orig_code_pos, coords2)
+        pos_intra_loss, pos_intra_cd = self.generic_helper(feats, feats, code, code, cfg.pos_intra_shift)
+        pos_inter_loss, pos_inter_cd = self.generic_helper(feats, feats_pos, code, code_pos, cfg.pos_inter_shift)
+        neg_losses, neg_cds = [], []
+        for i in range(int(perms.shape[0]) if perms is not None else 0):
+            perm_neg = perms[i]
+            feats_neg, code_neg = sample(orig_feats[perm_neg], coords2), sample(orig_code[perm_neg], coords2)
+            neg_inter_loss, neg_inter_cd = self.generic_helper(feats, feats_neg, code, code_neg, cfg.neg_inter_shift)
+            neg_losses.append(neg_inter_loss)
+            neg_cds.append(neg_inter_cd)
+        if neg_losses:
+            neg_inter_loss, neg_inter_cd = torch.cat(neg_losses, dim=0), torch.cat(neg_cds, dim=0)
+        else:
+            S = cfg.feature_samples
+            neg_inter_loss = neg_inter_cd = pos_intra_cd.new_zeros(0, S, S, S, S)
+        return pos_intra_loss.mean(), pos_intra_cd, pos_inter_loss.mean(), pos_inter_cd, neg_inter_loss, neg_inter_cd
+
     def forward_explicit(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
         """forward() with the RNG draws supplied by the caller (perms: int64 [neg_samples, B])."""
         cfg = self.cfg
         B, C, H, W = orig_feats.shape
         K = orig_code.shape[1]
         S = cfg.feature_samples
+        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, K, H, W, S):
+            return self.generic_forward(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
         n_neg = int(perms.shape[0]) if perms is not None else 0
         if perms is None:
             perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
@@ -385,6 +440,10 @@ class ContrastiveCorrelationLoss(nn.Module):
         coords1, coords2, perms = self.draw(orig_feats, orig_salience, orig_salience_pos)
         cfg = self.cfg
         B, C, H, W = orig_feats.shape
+        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, orig_code.shape[1], H, W, cfg.feature_samples):
+            o = self.generic_forward(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
+            neg_mean = o[4].mean() if o[4].numel() else o[0].new_zeros(())
+            return torch.stack([o[0], o[2], neg_mean]), o[1], o[3], o[5]
         n_neg = int(perms.shape[0]) if perms is not None else 0
         if perms is None:
             perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)

@@ -87,12 +87,17 @@ class LitUnsupervisedSegmenter(nn.Module):
         # STEGO_ERR_UNSUPPORTED inside the first training_step
         if cfg.correspondence_weight > 0:
             if dim > MAX_CODE_DIM:
-                raise ValueError("cfg.dim=%d: this build of the correspondence-loss kernels supports code dimensions up to %d "
-                                 "(train_config.yml:39 ships 70); see include/stego_corr.h" % (dim, MAX_CODE_DIM))
+                import warnings
+                warnings.warn("cfg.dim=%d: the fused loss kernels cover code dimensions up to %d (train_config.yml:39 ships 70; "
+                              "include/stego_corr.h); this configuration runs on ContrastiveCorrelationLoss.generic_forward: same "
+                              "results, several times slower" % (dim, MAX_CODE_DIM))
             if cfg.feature_samples > MAX_FEATURE_SAMPLES:
-                raise ValueError("cfg.feature_samples=%d: this build supports up to %d (S*S <= 128 sample points per image; "
-                                 "train_config.yml:51 ships 11)" % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
-            if dim > MAX_CODE_DIM_ANY_PATH:
+                import warnings
+                warnings.warn("cfg.feature_samples=%d: the fused loss kernels cover S*S <= 128 sample points per image (S <= %d; "
+                              "train_config.yml:51 ships 11); this configuration runs on ContrastiveCorrelationLoss.generic_forward "
+                              "(torch sampling + the native dense-correlation kernel): same results, several times slower"
+                              % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
+            if MAX_CODE_DIM_ANY_PATH < dim <= MAX_CODE_DIM:
                 # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
                 # csrc/corr_fused.hip): the same conditions here, with the cfg keys named
                 why = []

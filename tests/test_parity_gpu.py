@@ -459,12 +459,30 @@ def test_salience_path_on_device_matches_oracle():
     assert_close(out[5].cpu().numpy(), ref.neg_inter_cd, what="neg_inter_cd")
 
 
-def test_unsupported_configs_fail_loudly():
-    cfg = O.CorrCfg(feature_samples=12, neg_samples=1)      # 144 sample points > 128
-    f = torch.randn(2, 16, 8, 8, device=DEV)
-    c = torch.randn(2, 4, 8, 8, device=DEV)
-    with pytest.raises(RuntimeError, match="unsupported"):
-        M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+@pytest.mark.parametrize("S,K,C", [(12, 70, 384), (16, 70, 384), (16, 24, 64), (5, 130, 384)])
+def test_feature_samples_above_11_and_wide_codes_run_on_the_generic_path(S, K, C):
+    """cfg.feature_samples and cfg.dim are free in the reference (train_config.yml:39,51).  Beyond the fused kernels' S * S <= 128 /
+    K <= 128 the loss is computed by generic_forward (torch grid_sample + the native dense-correlation kernel for every einsum,
+    forward and adjoints): forward and gradients against the fp64 oracle."""
+    B, H, W, n_neg = 3, 10, 9, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=900 + S + K, dino_like=True)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    assert not M.ContrastiveCorrelationLoss.fused_kernels_cover(B, C, K, H, W, S)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3")
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=5e-4, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=5e-4, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=5e-4, what="neg_cd")
+    scale = float(np.mean(np.abs(ref.neg_inter_loss)))
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_intra_loss))
+    assert abs(float(r["out"][2]) - float(ref.pos_inter_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_inter_loss))
+    numel = B * S ** 4
+    g_nl = np.full((n_neg * B,) + (S,) * 4, 0.63 / (n_neg * numel))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=2e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=2e-3, atol_frac=1e-3, what="d_code_pos")
 
 
 @pytest.mark.parametrize("native_backbone", [False, True])

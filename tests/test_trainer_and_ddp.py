@@ -323,11 +323,17 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
     assert rec["config"]["collective"].startswith("all_reduce(")
 
 
-def test_unsupported_code_dim_and_sample_count_fail_at_construction_with_the_cfg_key_named():
+def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():
+    """cfg.dim > 128 / cfg.feature_samples > 11 are valid in the reference (train_config.yml:39,51 are free): they run on the generic
+    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; 72 < dim <= 128 with an odd dim (a
+    shape only the single-launch kernel could take, and cannot) still fails early."""
     for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=12"], "cfg.feature_samples=12")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
-        with pytest.raises(ValueError, match=key):
+        with pytest.warns(UserWarning, match=key):
             LitUnsupervisedSegmenter(5, cfg)
+    cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "dim=99"])
+    with pytest.raises(ValueError, match="cfg.dim=99"):
+        LitUnsupervisedSegmenter(5, cfg)
 
 
 def test_feature_pyramid_arch_builds_through_the_segmenter():
