@@ -127,9 +127,10 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
  * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws made by the
  * caller in the reference's order (coords1 :366, coords2 :367, super_perm x n_neg :383).
  *
- * Channels-last maps of the ViT widths (C = 384 / 768, K even) with at most one tile per compute unit ((2 + n_neg) * B <= 256)
- * take the FUSED path: ONE kernel launch
- * (corr_fused_kernel) in which every workgroup owns one (pair-set, image) tile:
+ * Channels-last maps of the ViT widths (C = 384 / 768, K even) with B <= the device's compute units (256) take the FUSED path:
+ * ONE kernel launch (corr_fused_kernel) in which every workgroup owns one (pair-set, image) tile; when there are more tiles
+ * ((2 + n_neg) * B) than compute units, the grid is a sequence of windows of whole pair-sets (floor(CUs / B) pair-sets each: the
+ * rendezvous of a pair-set never spans two windows, so a window that is resident never waits for one that is not):
  *   - the anchor sets (@coords1) are sampled (sample, :287-288: border, align_corners) and L2-normalised
  *     (norm, :275-276) once, by the workgroups of the XCD that caches their image, and handed to the tiles that
  *     need them through write-through stores + a counter (no kernel boundary);
