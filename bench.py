@@ -154,10 +154,10 @@ def _product_path(sets, cfg, args, kernel_step_s, total=False):
         (cfg.pos_intra_weight * pil + cfg.pos_inter_weight * pel + cfg.neg_inter_weight * nl.mean()).backward()
 
     n = len(sets)
-    for i in range(n):
-        step(i)
+    for k in range(3 * n + 40):            # warm-up: allocator pools, the draws' self-check, the autograd engine's device thread
+        step(k % n)
     torch.cuda.synchronize()
-    steps = max(40, args.steps // 2)
+    steps = max(200, args.steps // 2)
     t0 = time.perf_counter()
     for k in range(steps):
         step(k % n)

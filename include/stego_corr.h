@@ -193,6 +193,15 @@ int stego_finish_draws(const float* u1, const float* u2, int64_t n_coord, const 
 int stego_ref_draws(uint64_t seed, uint64_t offset, int32_t variant, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1,
                     float* coords2, int64_t* perms, stego_stream_t stream);
 uint64_t stego_ref_draws_advance(int64_t n_coord, int32_t n_neg, int32_t B, int32_t variant);
+/* The same launch with the generator state read ON THE DEVICE when the kernel runs: seed = *seed_ptr, offset = *offset_ptr +
+ * offset_intragraph - ATen's graph-safe form (at::PhiloxCudaState as CUDAGeneratorImpl::philox_cuda_state(increment) returns it while a
+ * stream is being captured: CUDAGraph::replay refreshes the two words before every replay, so every replay of a captured step draws the
+ * generator's next numbers, as the captured torch calls would).  The caller obtains the triple from torch and registers the increment
+ * stego_ref_draws_advance(...) with the generator in the same call (stego_amd/csrc/torch_glue_ext.cpp: the only torch C++ in the
+ * tree, plumbing like the stream handle). */
+int stego_ref_draws_indirect(const int64_t* seed_ptr, const int64_t* offset_ptr, uint64_t offset_intragraph, int32_t variant,
+                             int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2, int64_t* perms,
+                             stego_stream_t stream);
 
 /* OPT-IN alternative to the torch draws (cfg.fast_draws): the same DISTRIBUTIONS as modules.py:366-367, 382-385 - coords
  * uniform on torch.rand's 2^-24 lattice, times 2 minus 1; one uniformly random permutation of [0, B) per negative followed by
@@ -206,6 +215,13 @@ int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_
 int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
                             const StegoMap* code, const StegoMap* code_pos);
 int stego_corr_workspace_prepare(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes, stego_stream_t stream);
+/* The same on a stream of the library's own, returning when the workspace IS prepared - without calling any HIP synchronisation API
+ * (it watches a pinned flag word that a one-thread kernel sets behind the memset), so it is legal while the calling thread captures
+ * a graph on another stream: there stego_corr_workspace_prepare(capture stream) would become a memset node that every replay repeats in
+ * front of the forward.  The side stream and the flag are created by the first call on a device, which must not happen during a
+ * capture: a host that captures calls stego_corr_workspace_prepare_now(NULL, NULL, 0) once at start-up (stego_amd does when it loads
+ * the library).  This is the one entry point that allocates (once per device) and blocks. */
+int stego_corr_workspace_prepare_now(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes);
 int stego_corr_fwd_prepared(const StegoCorrDesc* desc,
                    const StegoMap* feats, const StegoMap* feats_pos,
                    const StegoMap* code, const StegoMap* code_pos,

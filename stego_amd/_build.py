@@ -22,6 +22,9 @@ HEADERS = ["corr_common.h", "corr_tile.h", "host_util.h", os.path.join("..", "..
            os.path.join("..", "..", "include", "stego_head.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
+# the one torch C++ extension (host only, g++): the autograd function of the loss and the generator's graph-safe Philox state, over the C ABI
+TORCHGLUE_SRC = os.path.join(CSRC, "torch_glue_ext.cpp")
+TORCHGLUE_PATH = os.path.join(LIB_DIR, "_stego_torchglue.so")
 
 
 def _hipcc():
@@ -97,5 +100,31 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return out
 
 
+def build_torchglue(force=False, verbose=False):
+    """Compile csrc/torch_glue_ext.cpp against the installed torch (pybind11 module, no device code) -> lib/_stego_torchglue.so."""
+    deps = [TORCHGLUE_SRC, os.path.join(CSRC, "..", "..", "include", "stego_corr.h")]
+    if not force and os.path.exists(TORCHGLUE_PATH) and all(os.path.getmtime(TORCHGLUE_PATH) >= os.path.getmtime(d) for d in deps):
+        return TORCHGLUE_PATH
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_stego_torchglue", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + d for d in cpp_extension.include_paths() + [os.path.join(rocm, "include"), sysconfig.get_paths()["include"]]]
+    cmd += [TORCHGLUE_SRC, "-L" + tlib, "-Wl,-rpath," + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl",
+            "-o", TORCHGLUE_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed on %s:\n%s%s" % (TORCHGLUE_SRC, res.stdout, res.stderr))
+    os.replace(TORCHGLUE_PATH + ".tmp", TORCHGLUE_PATH)
+    return TORCHGLUE_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_torchglue(force=True, verbose=True))

@@ -74,9 +74,11 @@ SIGNATURES = {
     "stego_corr_fwd": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_fwd_prepared": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]),
     "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
+    "stego_corr_workspace_prepare_now": (c_int32, [_D, _P, c_size_t]),
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
     "stego_ref_draws": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_ref_draws_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32, c_int32]),
+    "stego_ref_draws_indirect": (c_int32, [_P, _P, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_fast_draws": (c_int32, [_P, ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_finish_draws": (c_int32, [_P, _P, ctypes.c_int64, POINTER(ctypes.c_void_p), c_int32, c_int32, _P, _P, _P, _P]),
     "stego_corr_fwd_profile": (c_int32, [_D] + [_M] * 4 + [_P] * 3 + [_P] * 8 + [_P, c_size_t, _P]
@@ -224,12 +226,15 @@ def _empty_bytes(n, dev):
 # a few counters in the workspace that must be zero when a launch starts and that every launch leaves zero again.  A kept
 # workspace is prepared once (stego_corr_workspace_prepare) and then costs neither an allocation nor a memset per call.
 _WS_CACHE = {}
+_SIDE_READY = set()
 _WS_CACHE_MAX = 16
 
 
 def reset_workspaces():
     """Forget the kept forward workspaces (call after a launch that failed: its counters may be dirty)."""
     _WS_CACHE.clear()
+    if _torchglue_mod:
+        _torchglue_mod.reset_workspaces()
 
 
 def _prepared_ws(lib, desc, dev):
@@ -242,7 +247,16 @@ def _prepared_ws(lib, desc, dev):
             _WS_CACHE.pop(next(iter(_WS_CACHE)))
         ws = _empty_bytes(n, dev)
         with _on_device(dev):
-            _check(lib.stego_corr_workspace_prepare(byref(desc), _ptr(ws), ws.numel(), stream))
+            if torch.cuda.is_current_stream_capturing():
+                # a workspace first met while a graph is being captured (the capture stream is a stream of its own): prepared NOW on
+                # the library's side stream, not as a memset node that every replay would repeat in front of the forward (launches
+                # leave their counters zero, so once is enough)
+                _check(lib.stego_corr_workspace_prepare_now(byref(desc), _ptr(ws), ws.numel()))
+            else:
+                _check(lib.stego_corr_workspace_prepare(byref(desc), _ptr(ws), ws.numel(), stream))
+                if dev.index not in _SIDE_READY:       # the library's side stream for this device: created outside any capture
+                    _check(lib.stego_corr_workspace_prepare_now(None, None, 0))
+                    _SIDE_READY.add(dev.index)
         _WS_CACHE[key] = ws
     return ws
 
@@ -298,16 +312,53 @@ def finish_draws(u1, u2, raw_perms, B):
     return c1, c2, perms
 
 
+_torchglue_mod = None
+
+
+def torchglue():
+    """The in-tree torch extension (csrc/torch_glue_ext.cpp): the loss as a C++ autograd function over the C ABI and the device
+    generator's graph-safe Philox state - or None when it has not been built (then the Python autograd.Function runs, and draws under
+    stream capture stay the torch calls)."""
+    global _torchglue_mod
+    if _torchglue_mod is None:
+        path = _build.TORCHGLUE_PATH
+        if not os.path.exists(path):
+            _torchglue_mod = False
+        else:
+            import importlib.util
+            load()
+            spec = importlib.util.spec_from_file_location("_stego_torchglue", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.bind(_build.LIB_PATH)
+            _torchglue_mod = mod
+    return _torchglue_mod or None
+
+
+_ADVANCE = {}
+
+
 def ref_draws(gen, shape, n_neg, B, variant, dev):
     """(coords1, coords2, perms) = the reference's torch.rand x 2 / torch.randperm x n_neg draws from ONE launch (stego_ref_draws),
-    bit for bit, advancing `gen` (the device's torch.Generator) exactly as the torch calls would."""
+    bit for bit, advancing `gen` (the device's torch.Generator) exactly as the torch calls would.  While the current stream is being
+    captured the kernel reads the generator's state where CUDAGraph.replay puts it (stego_ref_draws_indirect; needs torchglue())."""
+    ext = torchglue()
+    if ext is not None and len(shape) == 4 and shape[1] == shape[2] and shape[3] == 2 and shape[0] == B:
+        return ext.ref_draws(gen, B, shape[1], n_neg, variant, dev)
     lib = load()
     c1 = torch.empty(shape, dtype=torch.float32, device=dev)
     c2 = torch.empty(shape, dtype=torch.float32, device=dev)
     perms = torch.empty(n_neg, B, dtype=torch.int64, device=dev)
-    seed, off = gen.initial_seed(), gen.get_offset()
     with _on_device(dev):
         adv = int(lib.stego_ref_draws_advance(c1.numel(), n_neg, B, variant))
+        if ext is not None:
+            captured, seed, off, intra = ext.philox_state(gen, adv)
+            if captured:
+                _check(lib.stego_ref_draws_indirect(seed, off, intra, variant, c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+            else:
+                _check(lib.stego_ref_draws(seed, off, variant, c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
+            return c1, c2, perms
+        seed, off = gen.initial_seed(), gen.get_offset()
         _check(lib.stego_ref_draws(seed & (2 ** 64 - 1), off, variant, c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
     gen.set_offset(off + adv)
     return c1, c2, perms

@@ -18,7 +18,8 @@ hipError_t launch_fast_draws(const long long* seed, long long n_coord, int n_neg
                              hipStream_t stream);
 hipError_t launch_finish_draws(const float* u1, const float* u2, long long n_coord, const long long* const* raw, int n_neg,
                                int B, float* c1, float* c2, long long* perms, hipStream_t stream);
-hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, int variant, long long n_coord, int n_neg, int B,
+hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, const long long* seed_ptr, const long long* offset_ptr,
+                            int variant, long long n_coord, int n_neg, int B,
                             int cus, int threads_per_cu, float* c1, float* c2, long long* perms, hipStream_t stream);
 unsigned long long ref_draws_advance(long long n_coord, int n_neg, int B, int variant, int cus, int threads_per_cu);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
@@ -369,8 +370,21 @@ int stego_ref_draws(uint64_t seed, uint64_t offset, int32_t variant, int64_t n_c
     (void)hipGetLastError();
     if (n_coord < 0 || n_neg < 0 || B < 1 || B > 2048 || variant < 0 || variant > 7 || (offset & 3)) return STEGO_ERR_SHAPE;
     if ((n_coord > 0 && (!coords1 || !coords2)) || (n_neg > 0 && !perms)) return STEGO_ERR_NULL;
-    return hip_rc(launch_ref_draws(seed, offset, variant, n_coord, n_neg, B, device_cu_count(), device_threads_per_cu(), coords1,
-                                   coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+    return hip_rc(launch_ref_draws(seed, offset, nullptr, nullptr, variant, n_coord, n_neg, B, device_cu_count(), device_threads_per_cu(),
+                                   coords1, coords2, reinterpret_cast<long long*>(perms), static_cast<hipStream_t>(stream)));
+}
+
+int stego_ref_draws_indirect(const int64_t* seed_ptr, const int64_t* offset_ptr, uint64_t offset_intragraph, int32_t variant,
+                             int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2, int64_t* perms,
+                             stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_coord < 0 || n_neg < 0 || B < 1 || B > 2048 || variant < 0 || variant > 7 || (offset_intragraph & 3)) return STEGO_ERR_SHAPE;
+    if (!seed_ptr || !offset_ptr || (n_coord > 0 && (!coords1 || !coords2)) || (n_neg > 0 && !perms)) return STEGO_ERR_NULL;
+    return hip_rc(launch_ref_draws(0, offset_intragraph, reinterpret_cast<const long long*>(seed_ptr),
+                                   reinterpret_cast<const long long*>(offset_ptr), variant, n_coord, n_neg, B, device_cu_count(),
+                                   device_threads_per_cu(), coords1, coords2, reinterpret_cast<long long*>(perms),
+                                   static_cast<hipStream_t>(stream)));
 }
 
 uint64_t stego_ref_draws_advance(int64_t n_coord, int32_t n_neg, int32_t B, int32_t variant)
@@ -417,6 +431,18 @@ int stego_corr_workspace_prepare(const StegoCorrDesc* d, void* workspace, size_t
     // the hand-off words sit right behind the per-tile sums (plan_fwd carves the same way)
     return hip_rc(hipMemsetAsync(static_cast<unsigned char*>(workspace) + g.stats_bytes, 0, g.sync_bytes,
                                  static_cast<hipStream_t>(stream)));
+}
+
+int stego_corr_workspace_prepare_now(const StegoCorrDesc* d, void* workspace, size_t workspace_bytes)
+{
+    (void)hipGetLastError();
+    hipStream_t side = nullptr;
+    hipError_t e = side_begin(&side);
+    if (e != hipSuccess) return hip_rc(e);
+    if (!d && !workspace) return STEGO_OK;                 // first call of a host: creates the side stream outside any capture
+    const int rc = stego_corr_workspace_prepare(d, workspace, workspace_bytes, static_cast<stego_stream_t>(side));
+    if (rc) return rc;
+    return hip_rc(side_finish());
 }
 
 int stego_corr_fwd_prepared(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code,

@@ -155,7 +155,9 @@ struct RefDrawParams {
     float* c2;
     long long n_coord;                 // floats per coords tensor
     long long* perms;                  // [n_neg][B]
-    unsigned long long seed, offset;   // generator state before the first draw
+    unsigned long long seed, offset;   // generator state before the first draw ...
+    const long long* seed_ptr;         // ... or (stream capture) where it will be when the graph replays: *seed_ptr,
+    const long long* offset_ptr;       //     *offset_ptr + offset  (ATen's PhiloxCudaState, unpacked like at::cuda::philox::unpack)
     int n_neg, B;
     int grid_coord;                    // blocks of a torch.rand call of n_coord elements
     int grid_keys;                     // blocks of the key draw of randperm(B)
@@ -220,8 +222,13 @@ __device__ __forceinline__ float torch_uniform(unsigned x, int fma)
 constexpr int REF_MAX_B = 2048;
 
 // blocks [0, nb_coord): one element of each coords tensor per thread; block nb_coord + n: permutation n
-__global__ void __launch_bounds__(256) ref_draws_kernel(const RefDrawParams prm, const int nb_coord)
+__global__ void __launch_bounds__(256) ref_draws_kernel(const RefDrawParams prm_in, const int nb_coord)
 {
+    RefDrawParams prm = prm_in;
+    if (prm.seed_ptr) {                 // graph-safe state: read where CUDAGraph::replay puts it
+        prm.seed = (unsigned long long)*prm.seed_ptr;
+        prm.offset += (unsigned long long)*prm.offset_ptr;
+    }
     if ((int)blockIdx.x < nb_coord) {
         const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
         if (i >= prm.n_coord) return;
@@ -301,11 +308,13 @@ unsigned long long ref_draws_advance(long long n_coord, int n_neg, int B, int va
     return 2 * a_rand + (unsigned long long)n_neg * (a_keys + a_dup);
 }
 
-hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, int variant, long long n_coord, int n_neg, int B,
+hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, const long long* seed_ptr, const long long* offset_ptr,
+                            int variant, long long n_coord, int n_neg, int B,
                             int cus, int threads_per_cu, float* c1, float* c2, long long* perms, hipStream_t stream)
 {
     RefDrawParams prm{};
     prm.c1 = c1; prm.c2 = c2; prm.n_coord = n_coord; prm.perms = perms; prm.seed = seed; prm.offset = offset;
+    prm.seed_ptr = seed_ptr; prm.offset_ptr = offset_ptr;
     prm.n_neg = n_neg; prm.B = B; prm.fma = (variant >> 1) & 1; prm.keys32 = (variant >> 2) & 1;
     prm.grid_coord = 1;
     if (n_coord > 0) torch_dist_policy(n_coord, variant, 4, cus, threads_per_cu, &prm.grid_coord, &prm.off_rand);

@@ -24,5 +24,10 @@ void set_knob(int which, int value);
 
 // test hook (stego_debug_occupy): n_wg workgroups of 256 threads with lds_bytes of LDS each spin for `micros`
 hipError_t launch_occupy(int n_wg, int lds_bytes, int micros, hipStream_t stream);
+// A stream of the library's own per device + a pinned flag word: side_begin() returns the stream (creating both on the first call for a
+// device - NOT while a capture is under way), side_finish() returns when everything enqueued on it has run, by watching the flag a
+// one-thread kernel sets: no HIP synchronisation API is called, so both are legal while the calling thread captures another stream.
+hipError_t side_begin(hipStream_t* stream);
+hipError_t side_finish();
 
 }  // namespace stego

@@ -1,5 +1,7 @@
 // Per-device caches and measurement knobs (see host_util.h).
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -85,6 +87,64 @@ hipError_t launch_occupy(int n_wg, int lds_bytes, int micros, hipStream_t stream
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(256), lds_bytes, stream, (long long)micros * 100, (int*)nullptr);
     return hipGetLastError();
+}
+
+// ---- the library's side stream (stego_corr_workspace_prepare_now)
+struct SideChannel {
+    hipStream_t stream = nullptr;
+    int* flag_host = nullptr;
+    int* flag_dev = nullptr;
+    int seq = 0;
+};
+static std::mutex side_mutex;
+static std::map<int, SideChannel> side_channels;
+
+__global__ void side_publish_kernel(int* flag, int value)
+{
+    *reinterpret_cast<volatile int*>(flag) = value;
+    __threadfence_system();
+}
+
+static hipError_t side_channel(SideChannel** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    SideChannel& ch = side_channels[dev];
+    if (!ch.stream) {
+        if ((e = hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&ch.flag_host), 64, hipHostMallocDefault)) != hipSuccess) return e;
+        ch.flag_host[0] = 0;
+        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&ch.flag_dev), ch.flag_host, 0)) != hipSuccess) return e;
+    }
+    *out = &ch;
+    return hipSuccess;
+}
+
+hipError_t side_begin(hipStream_t* stream)
+{
+    std::lock_guard<std::mutex> lock(side_mutex);
+    SideChannel* ch = nullptr;
+    hipError_t e = side_channel(&ch);
+    if (e == hipSuccess) *stream = ch->stream;
+    return e;
+}
+
+hipError_t side_finish()
+{
+    std::lock_guard<std::mutex> lock(side_mutex);
+    SideChannel* ch = nullptr;
+    hipError_t e = side_channel(&ch);
+    if (e != hipSuccess) return e;
+    const int want = ++ch->seq;
+    hipLaunchKernelGGL(side_publish_kernel, dim3(1), dim3(1), 0, ch->stream, ch->flag_dev, want);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*reinterpret_cast<volatile int*>(ch->flag_host) != want) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return hipErrorNotReady;
+        std::this_thread::yield();
+    }
+    return hipSuccess;
 }
 
 }  // namespace stego

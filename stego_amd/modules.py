@@ -172,6 +172,27 @@ def ref_draw_variant(shape, n, B, dev):
     return v
 
 
+def _usable_ref_draw_variant(shape, n, B, dev):
+    """ref_draw_variant(), or - while the current stream is being captured, where the self-check cannot run - its cached answer, provided
+    the generator's graph-safe state is reachable (capi.torchglue())."""
+    if not torch.cuda.is_current_stream_capturing():
+        return ref_draw_variant(shape, n, B, dev)
+    numel = 1
+    for s_ in shape:
+        numel *= int(s_)
+    if getattr(_backend, "torchglue", lambda: None)() is None:
+        return -1
+    return _REF_DRAW_VARIANTS.get((dev.index, numel, int(n), int(B)), -1)
+
+
+def _native_autograd(cfg):
+    """The C++ autograd function of the loss (capi.torchglue()) unless cfg.native_autograd is False, the module has not been built, or a
+    test has swapped the backend: then the Python autograd.Function classes below run - same C ABI calls, same results."""
+    if _backend is not capi or not getattr(cfg, "native_autograd", True):
+        return None
+    return capi.torchglue()
+
+
 def _precision_of(cfg):
     name = getattr(cfg, "corr_precision", "f16x3")
     if name in ("f32", "fp32", 0):
@@ -418,7 +439,13 @@ class ContrastiveCorrelationLoss(nn.Module):
             perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg,
                               (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), _precision_of(cfg))
-        out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
+        ext = _native_autograd(cfg)
+        if ext is not None:            # the same op as a C++ autograd function (csrc/torch_glue_ext.cpp): a third of the host time
+            mn = _relayout_threshold(orig_code)
+            out = ext.corr_loss(as_channels_last(orig_feats, mn), as_channels_last(orig_feats_pos, mn), as_channels_last(orig_code, mn),
+                                as_channels_last(orig_code_pos, mn), coords1, coords2, perms, bytes(desc), 0)
+        else:
+            out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
         neg_loss = out[4]
         if n_neg > 0:
             neg_loss = neg_loss.as_subclass(_NegLossMap)          # (an alias: same storage, same autograd node)
@@ -449,6 +476,12 @@ class ContrastiveCorrelationLoss(nn.Module):
             perms = torch.zeros(0, B, dtype=torch.long, device=orig_feats.device)
         desc = capi.make_desc(B, C, orig_code.shape[1], H, W, cfg.feature_samples, n_neg, cfg,
                               (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), _precision_of(cfg))
+        ext = _native_autograd(cfg)
+        if ext is not None:
+            mn = _relayout_threshold(orig_code)
+            return tuple(ext.corr_loss(as_channels_last(orig_feats, mn), as_channels_last(orig_feats_pos, mn),
+                                       as_channels_last(orig_code, mn), as_channels_last(orig_code_pos, mn), coords1, coords2, perms,
+                                       bytes(desc), 1))
         return _CorrLossMeansFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
 
     def total(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos, weights):
@@ -478,15 +511,16 @@ class ContrastiveCorrelationLoss(nn.Module):
             if cfg.neg_samples == 0:
                 perms = None
         elif dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "ref_draws") and B <= 2048 and \
-                getattr(cfg, "one_launch_draws", True) and not torch.cuda.is_current_stream_capturing() and \
-                ref_draw_variant([B, cfg.feature_samples, cfg.feature_samples, 2], cfg.neg_samples, B, dev) >= 0:
+                getattr(cfg, "one_launch_draws", True) and \
+                (variant := _usable_ref_draw_variant([B, cfg.feature_samples, cfg.feature_samples, 2], cfg.neg_samples, B, dev)) >= 0:
             # DEFAULT on a HIP device: the reference's draws - the same numbers torch.rand x 2 and torch.randperm x neg_samples give
             # from this generator state, the generator advanced by the same amount - from ONE launch (stego_ref_draws) instead of
-            # ~30 tiny kernels.  Checked against the real torch calls once per process and size (ref_draw_variant); under stream
-            # capture the generator's state lives on the device where Python cannot read it: the torch calls below are captured.
+            # ~30 tiny kernels.  Checked against the real torch calls once per process and size (ref_draw_variant).  Under stream
+            # capture the generator's state lives on the device: the kernel reads it there (stego_ref_draws_indirect, through the
+            # in-tree torch extension); a size that was never drawn eagerly before the capture keeps the torch calls below.
             shape = [B, cfg.feature_samples, cfg.feature_samples, 2]
             gen = _device_generator(dev)
-            coords1, coords2, perms = _backend.ref_draws(gen, shape, cfg.neg_samples, B, ref_draw_variant(shape, cfg.neg_samples, B, dev), dev)
+            coords1, coords2, perms = _backend.ref_draws(gen, shape, cfg.neg_samples, B, variant, dev)
             if cfg.neg_samples == 0:
                 perms = None
         elif dev.type == "cuda" and not cfg.use_salience and hasattr(_backend, "finish_draws"):

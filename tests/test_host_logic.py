@@ -313,3 +313,19 @@ def test_means_and_total_api_equal_the_reference_composition(oracle_backed):
     total.backward()
     assert_close(code.grad.numpy(), g1.numpy(), rtol=1e-4, atol_frac=1e-5, what="d_code via total()")
     assert_close(code_pos.grad.numpy(), g2.numpy(), rtol=1e-4, atol_frac=1e-5, what="d_code_pos via total()")
+
+
+def test_torch_glue_extension_is_built_and_bound_to_the_library():
+    """stego_amd/lib/_stego_torchglue.so (csrc/torch_glue_ext.cpp, built by __graft_entry__.build()): loads next to the C-ABI library,
+    resolves the entry points it calls (bind() checks the ABI version), and refuses host tensors like every other entry of the product."""
+    import torch
+    from stego_amd import capi, _build
+    _build.build_torchglue()
+    ext = capi.torchglue()
+    assert ext is not None
+    for name in ("bind", "philox_state", "ref_draws", "corr_loss", "reset_workspaces"):
+        assert hasattr(ext, name)
+    x = torch.zeros(2, 8, 4, 4)
+    desc = capi.make_desc(2, 8, 4, 4, 4, 2, 0, type("C", (), dict(pointwise=True, zero_clamp=True, stabalize=False))(), (0.1, 0.2, 0.3))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        ext.corr_loss(x, x, x[:, :4], x[:, :4], torch.zeros(2, 2, 2, 2), torch.zeros(2, 2, 2, 2), torch.zeros(0, 2, dtype=torch.long), bytes(desc), 0)

@@ -459,7 +459,7 @@ def test_salience_path_on_device_matches_oracle():
     assert_close(out[5].cpu().numpy(), ref.neg_inter_cd, what="neg_inter_cd")
 
 
-@pytest.mark.parametrize("S,K,C", [(12, 70, 384), (16, 70, 384), (16, 24, 64), (5, 130, 384)])
+@pytest.mark.parametrize("S,K,C", [(12, 70, 384), (16, 70, 384), (16, 24, 64), (5, 130, 384), (3, 96, 16)])
 def test_feature_samples_above_11_and_wide_codes_run_on_the_generic_path(S, K, C):
     """cfg.feature_samples and cfg.dim are free in the reference (train_config.yml:39,51).  Beyond the fused kernels' S * S <= 128 /
     K <= 128 the loss is computed by generic_forward (torch grid_sample + the native dense-correlation kernel for every einsum,
@@ -674,11 +674,19 @@ def test_code_dimensions_above_72_forward_and_backward_against_fp64_oracle(K, pr
 
 
 def test_code_dimensions_above_72_need_the_fused_layout():
+    """72 < K <= 128 exists on the fused kernel only (channels-last ViT widths): the C ABI refuses other maps with STEGO_ERR_UNSUPPORTED,
+    the Python surface routes them to generic_forward (parity: test_feature_samples_above_11_and_wide_codes_run_on_the_generic_path)."""
     cfg = O.CorrCfg(feature_samples=3, neg_samples=1)
     f = torch.randn(2, 16, 8, 8, device=DEV)                # not a ViT width: three-launch path, K <= 72 only
     c = torch.randn(2, 96, 8, 8, device=DEV)
+    assert not M.ContrastiveCorrelationLoss.fused_kernels_cover(2, 16, 96, 8, 8, 3)
+    desc = capi.make_desc(2, 16, 96, 8, 8, 3, 1, cfg, (.18, .12, .46), capi.PREC_F16X3)
+    co = torch.rand(2, 3, 3, 2, device=DEV) * 2 - 1
+    perms = torch.tensor([[1, 0]], device=DEV)
     with pytest.raises(RuntimeError, match="unsupported"):
-        M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+        capi.corr_fwd(desc, f, f, c, c, co, co, perms, False)
+    out = M.ContrastiveCorrelationLoss(cfg)(f, f, None, None, c, c)
+    assert all(torch.isfinite(t).all() for t in out)
 
 
 def test_unprepared_entry_point_accepts_any_workspace_and_prepared_one_stays_clean():
@@ -1101,7 +1109,7 @@ def test_one_launch_draws_are_the_torch_generator_s_rand_and_randperm(B, S, n_ne
     gen = M._device_generator(dev)
     bad = torch.zeros((), dtype=torch.int64, device=dev)
     dup = 0
-    n_seeds = 400 if B <= 36 else 60
+    n_seeds = 2000 if B <= 36 else 60
     for seed in range(n_seeds):
         torch.manual_seed(1000 + seed)
         if seed % 3 == 1:
@@ -1114,6 +1122,68 @@ def test_one_launch_draws_are_the_torch_generator_s_rand_and_randperm(B, S, n_ne
         assert gen.get_offset() == off
         bad += (c1 != ref[0] * 2 - 1).sum() + (c2 != ref[1] * 2 - 1).sum() + (perms != M._unfix(torch.stack(ref[2:]))).sum()
     assert int(bad) == 0
+
+
+@pytest.mark.parametrize("B", [4, 32])
+def test_one_launch_draws_captured_in_a_hip_graph_follow_the_generator_replay_after_replay(B):
+    """stego_ref_draws_indirect: the launch captured ONCE reads the generator's state where CUDAGraph.replay refreshes it
+    (at::PhiloxCudaState in its captured form, handed over by the in-tree torch extension), so replay k draws what the seven torch
+    calls would draw k-th from the generator's state at the first replay - whatever was seeded or consumed in between - and every
+    replay advances the generator by the seven calls' amount."""
+    dev = torch.device("cuda:0")
+    S, n_neg = 11, 5
+    shape = [B, S, S, 2]
+    assert capi.torchglue() is not None, "stego_amd/lib/_stego_torchglue.so not built (__graft_entry__.build())"
+    v = M.ref_draw_variant(shape, n_neg, B, dev)
+    assert v >= 0
+    gen = M._device_generator(dev)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        c1, c2, perms = capi.ref_draws(gen, shape, n_neg, B, v, dev)
+        c1b, c2b, permsb = capi.ref_draws(gen, shape, n_neg, B, v, dev)          # a second forward inside the same graph
+    for seed in range(40):
+        torch.manual_seed(500 + seed)
+        if seed % 2:
+            torch.rand(7, device=dev)
+        st = gen.get_state()
+        ref = [M._torch_draws(shape, n_neg, B, dev) for _ in range(4)]
+        off = gen.get_offset()
+        gen.set_state(st)
+        for k in range(2):
+            g.replay()
+            for got, want in (((c1, c2, perms), ref[2 * k]), ((c1b, c2b, permsb), ref[2 * k + 1])):
+                assert torch.equal(got[0], want[0] * 2 - 1) and torch.equal(got[1], want[1] * 2 - 1)
+                assert torch.equal(got[2], M._unfix(torch.stack(want[2:])))
+        assert gen.get_offset() == off
+
+
+def test_captured_product_step_draws_like_the_eager_one():
+    """ContrastiveCorrelationLoss.forward captured in a HIP graph (after one eager call, which runs the draws' self-check) = the eager
+    forward from the same generator state, replay after replay; the capture holds ONE draw kernel instead of the ~30 of the torch calls."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 98, dev)
+    cfg = bench.Cfg()
+    loss_fn = M.ContrastiveCorrelationLoss(cfg)
+    args = (d["feats"], d["feats_pos"], None, None, d["code"], d["code_pos"])
+    with torch.no_grad():
+        loss_fn(*args)                                                            # eager warm-up: workspaces, self-check
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = loss_fn(*args)
+        assert M._usable_ref_draw_variant([B, S, S, 2], n_neg, B, dev) >= 0
+        torch.manual_seed(11)
+        want = [[t.clone() for t in loss_fn(*args)] for _ in range(3)]
+        nxt = torch.rand(3, device=dev)
+        torch.manual_seed(11)
+        for k in range(3):
+            g.replay()
+            for a, b in zip(out, want[k]):
+                assert torch.equal(a, b)
+        assert torch.equal(torch.rand(3, device=dev), nxt)
 
 
 def test_forward_with_one_launch_draws_equals_forward_with_the_torch_calls():
@@ -1131,3 +1201,56 @@ def test_forward_with_one_launch_draws_equals_forward_with_the_torch_calls():
         outs.append([t.detach().clone() for t in o] + [torch.rand(3, device=dev)])          # + the generator's next numbers
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_cpp_autograd_function_is_the_python_one_bit_for_bit():
+    """csrc/torch_glue_ext.cpp::CorrLoss (the default on a HIP device) against modules._CorrLossFunction / _CorrLossMeansFunction
+    (cfg.native_autograd = False): the same C ABI calls, so every output and every gradient is bitwise equal - with the training
+    upstream (three scalars), with dense upstreams on every output, with an expanded-scalar upstream on the negative loss map, and
+    through means() / total(); a second differentiation is refused."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 97, dev)
+    assert capi.torchglue() is not None, "stego_amd/lib/_stego_torchglue.so not built (__graft_entry__.build())"
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    ups = None
+    res = {}
+    for native in (True, False):
+        cfg = bench.Cfg()
+        cfg.native_autograd = native
+        loss_fn = M.ContrastiveCorrelationLoss(cfg)
+        assert (M._native_autograd(cfg) is not None) == native
+        rec = []
+        for case in ("train", "dense", "expanded", "total"):
+            c = d["code"].detach().clone().requires_grad_(True)
+            cp = d["code_pos"].detach().clone().requires_grad_(True)
+            if case == "total":
+                torch.manual_seed(3)                                   # (total() makes its own draws)
+                out = loss_fn.total(d["feats"], d["feats_pos"], None, None, c, cp, (0.67, 0.25, 0.63))
+                out[0].backward()
+                rec += [t.detach().clone() for t in out] + [c.grad.clone(), cp.grad.clone()]
+                continue
+            o = loss_fn.forward_explicit(d["feats"], d["feats_pos"], c, cp, d["coords1"], d["coords2"], d["perms"])
+            rec += [t.detach().clone() for t in o]
+            if case == "train":
+                (0.67 * o[0] + 0.25 * o[2] + 0.63 * o[4].mean()).backward()
+            elif case == "dense":
+                if ups is None:
+                    ups = [torch.randn(t.shape, device=dev, generator=gen) for t in o]
+                torch.autograd.backward(list(o), ups)
+            else:
+                (o[0] * 2 + o[4].sum() * 0.5 + o[4].mean()).backward()
+            rec += [c.grad.clone(), cp.grad.clone()]
+        res[native] = rec
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # once differentiable
+    cfg = bench.Cfg()
+    c = d["code"].detach().clone().requires_grad_(True)
+    o = M.ContrastiveCorrelationLoss(cfg).forward_explicit(d["feats"], d["feats_pos"], c, d["code_pos"], d["coords1"], d["coords2"], d["perms"])
+    up = torch.ones((), device=dev, requires_grad=True)
+    with pytest.raises(RuntimeError, match="differentiable once"):
+        torch.autograd.grad(o[0], c, grad_outputs=up, create_graph=True)
