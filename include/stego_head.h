@@ -50,7 +50,8 @@ typedef struct StegoHeadDesc {
  *                       8 words of operand scales (the largest magnitudes of x, the weights and H: every fp32 operand is multiplied
  *                       by a power of two before it is split into fp16 halves, so that small values keep 22 bits); NULL when no
  *                       backward follows (with desc->nonlinear H then lives in `workspace`)
- *   workspace         : stego_head_fwd_workspace_bytes() */
+ *   workspace         : stego_head_fwd_workspace_bytes() (scale words, the weights as fp16 hi / lo planes, H; with saved_h given the
+ *                       H part - B * HW * C floats rounded up to 256 bytes, the last - may be left out) */
 size_t stego_head_fwd_workspace_bytes(const StegoHeadDesc* desc);
 int stego_head_fwd(const StegoHeadDesc* desc, const float* tokens, const float* mask1, const float* mask2, const float* mask3,
                    const float* w1, const float* b1, const float* w21, const float* b21, const float* w22, const float* b22,

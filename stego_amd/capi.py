@@ -549,7 +549,9 @@ def head_fwd(tokens, masks, w1, b1, w21, b21, w22, b22, need_grad, want_feats):
     nws = int(lib.stego_head_fwd_workspace_bytes(byref(d)))
     if nws == 0:
         raise RuntimeError("stego_head_fwd: unsupported shape (C a multiple of 32, K <= 128, 16-byte token rows)")
-    ws = _empty_bytes(nws if (nonlinear and saved_h is None) else 256, dev)
+    if nonlinear and saved_h is not None:       # H lives in saved_h: the workspace only holds the scale words and the split weights
+        nws -= (B * HW * C * 4 + 255) // 256 * 256
+    ws = _empty_bytes(nws, dev)
     m1, m2, m3 = masks if masks is not None else (None, None, None)
     with _on_device(dev):
         _check(lib.stego_head_fwd(byref(d), _ptr(tokens), _ptr(m1), _ptr(m2), _ptr(m3), _ptr(w1), _ptr(b1), _ptr(w21), _ptr(b21),

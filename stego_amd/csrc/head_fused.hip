@@ -16,9 +16,12 @@
 // Forward: 3 launches (cluster1; cluster2[0] + ReLU -> H; cluster2[2] accumulated into code).  Backward: dHpre = (G W22) * 1[H > 0],
 // three weight-gradient GEMMs, one reduction.
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <algorithm>
 
 #include "../../include/stego_head.h"
 #include "corr_common.h"
+#include "host_util.h"
 
 namespace stego {
 
@@ -27,10 +30,17 @@ typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
 constexpr int HT = 128;                          // tile rows / cols
 constexpr int HKS = 32;                          // channels (or tokens) per stage
 constexpr int HSIDE = 16384;                     // one operand stage: [hi 128 x 64 B][lo 128 x 64 B]
+constexpr int HS_WORDS = 8;                      // operand-scale words of a call (enum HS_* below)
 
 __device__ __forceinline__ int hswz(int r, int u) { return r * 64 + ((u ^ ((r >> 2) & 3)) << 4); }
 
-// one 32-deep stage: a.b ~= ah.bh + ah.bl + al.bh   (rows of As = output rows, rows of Bs = output columns)
+// one 32-deep stage: a.b ~= ah.bh + ah.bl + al.bh   (rows of As = output rows, rows of Bs = output columns).  ALO / BLO: byte offset
+// of the lo plane behind the hi plane (64 B per row: 8192 for a 128-row operand stage, 24576 for a 384-row one).
+// The MFMA is issued with the operands SWAPPED (it computes the transposed 32 x 32 block): a lane then holds, for ONE output row
+// (lane & 31), the columns 8 j + 4 (lane >> 5) + 0..3, j = 0..3 - four runs of four consecutive columns, i.e. 16-byte global accesses in
+// the epilogues (4 x fewer store / load instructions than the natural layout's one dword per lane and register: the epilogue of a
+// 128 x 384 tile was 768 store instructions per workgroup and store-issue-bound).
+template <int ALO, int BLO>
 __device__ __forceinline__ void head_mma_stage(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
                                                f32x16 (&acc)[2][2], int lane, int wr, int wc)
 {
@@ -39,22 +49,22 @@ __device__ __forceinline__ void head_mma_stage(const unsigned char* __restrict__
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int u = 2 * ks + half;
-        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(As + hswz(ra0, u)), al0 = *reinterpret_cast<const f16x8*>(As + 8192 + hswz(ra0, u));
-        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(As + hswz(ra1, u)), al1 = *reinterpret_cast<const f16x8*>(As + 8192 + hswz(ra1, u));
-        const f16x8 bh0 = *reinterpret_cast<const f16x8*>(Bs + hswz(rb0, u)), bl0 = *reinterpret_cast<const f16x8*>(Bs + 8192 + hswz(rb0, u));
-        const f16x8 bh1 = *reinterpret_cast<const f16x8*>(Bs + hswz(rb1, u)), bl1 = *reinterpret_cast<const f16x8*>(Bs + 8192 + hswz(rb1, u));
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(As + hswz(ra0, u)), al0 = *reinterpret_cast<const f16x8*>(As + ALO + hswz(ra0, u));
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(As + hswz(ra1, u)), al1 = *reinterpret_cast<const f16x8*>(As + ALO + hswz(ra1, u));
+        const f16x8 bh0 = *reinterpret_cast<const f16x8*>(Bs + hswz(rb0, u)), bl0 = *reinterpret_cast<const f16x8*>(Bs + BLO + hswz(rb0, u));
+        const f16x8 bh1 = *reinterpret_cast<const f16x8*>(Bs + hswz(rb1, u)), bl1 = *reinterpret_cast<const f16x8*>(Bs + BLO + hswz(rb1, u));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, al0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, al0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, al1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, al1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, ah0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, ah0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, ah1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, ah1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, ah0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, ah0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, ah1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, ah1, acc[1][1], 0, 0, 0);
     }
 }
 
@@ -146,49 +156,117 @@ struct HeadGemmParams {
     const float* A;            // row m = (image b, token t): A + b * a_img + t * a_tok, K contiguous
     long long a_img, a_tok;
     int HW;                    // rows per image
-    const float* maskA;        // [B, K] or null: A'[m][k] = A[m][k] * maskA[b][k]
-    const float* B;            // weights [N, K] row-major (ldb), or [K, N] when b_transposed
-    int ldb, b_transposed;
+    const float* maskA;        // A'[m][k] = A[m][k] * maskA[b * mask_ld + k]: [B, K] (mask_ld = K) or ONE row of ones (mask_ld = 0); never null
+    int mask_ld, mask3_ld;
+    int n_slot, n_img;         // images a 128-row tile can touch ((HT - 1) / HW + 2, at most B); B
+    const half_t* Bh;          // weights, pre-split by head_prep_weights_kernel: [Npad][ldb] fp16 hi / lo planes of B[n][k] * scale,
+    const half_t* Bl;          // zero beyond N / K (Npad a multiple of the workgroup's columns, ldb a multiple of 32)
+    int ldb;
     float* C;                  // [M, N] row-major (ldc)
     int ldc;
-    const float* bias;         // [N] or null
-    const float* bias2;        // [N] or null
+    const float* bias;         // [N]; never null in the bias epilogues (a row of zeros when absent)
+    const float* bias2;        // [N], likewise
     const float* aux;          // EPI_MASK_POS: [M, N] (ldaux)
     int ldaux;
     float* feats_out;          // [M, K] dense or null: = A * mask3 (written by the N tile 0)
-    const float* mask3;        // [B, K] or null (null with feats_out: plain copy)
+    const float* mask3;        // like maskA, for feats_out (EPI_BIAS only)
     const unsigned* amax_a;    // largest |A| / |B| (device words, see head_scale) or null
     const unsigned* amax_b;
     unsigned* amax_out;        // or null: atomicMax of |C| (the operand scale of whoever consumes C)
     int M, N, K, epi;
 };
 
-// KVEC: K % 32 == 0 and 16-byte aligned rows -> float4 staging; otherwise scalar staging with bounds (the K = cfg.dim GEMM)
-template <bool KVEC, int EPI>
-__global__ void __launch_bounds__(256) head_gemm_kernel(const HeadGemmParams prm)
+// Weights -> the B operand's fp16 hi / lo planes, once per call, two small launches over all weights of the call: the largest |w| of
+// each (its bits go to *amax: the GEMMs undo the scale from the same word), then B[n][k] = w * 2^s split into hi + lo.
+struct HeadPrepJob {
+    const float* src;          // [rows][cols] row-major (ld); transposed: B[n][k] = src[k * ld + n]
+    int N, K, ld, transposed;
+    half_t* hi;
+    half_t* lo;
+    int Npad, Kpad;
+    unsigned* amax;
+};
+struct HeadPrepParams { HeadPrepJob job[4]; };
+
+// One launch for the small constants of a call (three memset / copy nodes cost ~5 us each on the stream): the scale words (zeroed, or
+// the first n_copy of them copied from the forward's), a row of zeros (may be null) and a row of ones.
+__global__ void __launch_bounds__(256) head_consts_kernel(unsigned* words, const unsigned* copy_from, int n_copy, float* zeros, float* ones, int C)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HSIDE];
-    unsigned char* As = lds;
-    unsigned char* Bs = lds + HSIDE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * HT, n0 = blockIdx.y * HT;
-    const int row = tid >> 1, h = tid & 1;
-    // my A row (rows / columns beyond the matrix are read from the last valid one and zeroed: every load below is unconditional -
-    // a load inside a branch gets its own s_waitcnt and the staging becomes a chain of dependent round trips)
-    const int m = m0 + row;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < HS_WORDS) words[i] = (copy_from && i < n_copy) ? copy_from[i] : 0u;
+    if (i < C) {
+        if (zeros) zeros[i] = 0.f;
+        ones[i] = 1.f;
+    }
+}
+
+constexpr int PREP_WG = 32;                      // workgroups per job (grid.y)
+
+// pass 1: the largest |w| of every job -> its amax word (zeroed by the caller)
+__global__ void __launch_bounds__(256) head_prep_absmax_kernel(const HeadPrepParams prm)
+{
+    __shared__ float red[4];
+    const HeadPrepJob jb = prm.job[blockIdx.x];
+    const int rows = jb.transposed ? jb.K : jb.N, cols = jb.transposed ? jb.N : jb.K;
+    float mx = 0.f;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < rows * cols; i += PREP_WG * 256) {
+        const int r = i / cols, c = i - r * cols;
+        mx = fmaxf(mx, fabsf(jb.src[(size_t)r * jb.ld + c]));
+    }
+    head_publish_max(mx, jb.amax, red);
+}
+
+// pass 2: B[n][k] = w * 2^s split into hi + lo, zero-padded to [Npad][Kpad]
+__global__ void __launch_bounds__(256) head_prep_split_kernel(const HeadPrepParams prm)
+{
+    const HeadPrepJob jb = prm.job[blockIdx.x];
+    const float sc = head_scale(jb.amax);
+    const int kp2 = jb.Kpad / 2;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < jb.Npad * kp2; i += PREP_WG * 256) {
+        const int n = i / kp2, k = 2 * (i - n * kp2);
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = n < jb.N && k + e < jb.K;
+            const int nn = ok ? n : 0, kk = ok ? k + e : 0;
+            const float w = jb.src[jb.transposed ? (size_t)kk * jb.ld + nn : (size_t)nn * jb.ld + kk];
+            v[e] = w * (ok ? sc : 0.f);
+        }
+        unsigned h, l;
+        split_f16_pair(v[0], v[1], h, l);
+        *reinterpret_cast<unsigned*>(jb.hi + (size_t)n * jb.Kpad + k) = h;
+        *reinterpret_cast<unsigned*>(jb.lo + (size_t)n * jb.Kpad + k) = l;
+    }
+}
+
+// KVEC: K % 32 == 0 and 16-byte aligned A rows -> float4 staging; otherwise scalar staging with bounds (the K = cfg.dim GEMM).
+// NW: 128-column blocks per workgroup (4 NW waves: a 128 x 128 NW tile).  NW = 3 covers the C = 384 outputs of a ViT-S head with ONE
+// staging of the token operand (the activation side is what costs: 16 values to scale and split per thread and stage; the weights
+// arrive split).
+template <bool KVEC, int EPI, int NW>
+__global__ void __launch_bounds__(256 * NW) head_gemm_kernel(const HeadGemmParams prm)
+{
+    constexpr int BLO = NW * 8192;               // the B stage: [hi 128 NW rows x 64 B][lo ...]
+    constexpr int STAGE = HSIDE + 2 * BLO;       // one stage: A, then B; two of them (double buffer: one barrier per stage)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 1, wc = wave >> 1;
+    const int m0 = blockIdx.x * HT, n0 = blockIdx.y * HT * NW;
+    const int row = tid >> 1, h = tid & 1;       // B row (an output column of this workgroup), which 16 channels of the stage
+    const bool stage_a = NW == 1 || tid < 256;   // (wave-uniform) the first 256 threads also stage the A rows
+    // my A row (rows beyond the matrix are read from the last valid one and zeroed: every load below is unconditional - a load inside
+    // a branch gets its own s_waitcnt and the staging becomes a chain of dependent round trips)
+    const int arow_i = row & (HT - 1);
+    const int m = m0 + arow_i;
     const bool m_ok = m < prm.M;
     const int mc = m_ok ? m : prm.M - 1;
     const int b = mc / prm.HW, t = mc - b * prm.HW;
     const float* arow = prm.A + (long long)b * prm.a_img + (long long)t * prm.a_tok;
-    const float* mrow = prm.maskA ? prm.maskA + (size_t)b * prm.K : nullptr;
-    const float* m3row = prm.mask3 ? prm.mask3 + (size_t)b * prm.K : nullptr;
-    float* frow = (prm.feats_out && blockIdx.y == 0 && m_ok) ? prm.feats_out + (size_t)m * prm.K : nullptr;
-    // my B row (an output column)
-    const int n = n0 + row;
-    const bool n_ok = n < prm.N;
-    const int nc = n_ok ? n : prm.N - 1;
-    const float a_keep = m_ok ? 1.f : 0.f, b_keep = n_ok ? 1.f : 0.f;
-    const size_t b_kstride = prm.b_transposed ? (size_t)prm.ldb : 1, b_nstride = prm.b_transposed ? 1 : (size_t)prm.ldb;
+    // (maskA / mask3 always point at [B, K] floats - a vector of ones when there is no dropout: a load that happens only when a pointer is
+    // set becomes a branch with its own s_waitcnt, and a wait in front of the MFMAs is a stage that no longer overlaps its loads)
+    float* frow = (EPI == EPI_BIAS && prm.feats_out && blockIdx.y == 0 && m_ok && stage_a) ? prm.feats_out + (size_t)m * prm.K : nullptr;
+    const float a_keep = m_ok ? 1.f : 0.f;
+    const half_t* bh_row = prm.Bh + (size_t)(n0 + row) * prm.ldb + 16 * h;
+    const half_t* bl_row = prm.Bl + (size_t)(n0 + row) * prm.ldb + 16 * h;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -200,106 +278,191 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const HeadGemmParams prm
 
     const float sa = head_scale(prm.amax_a), sb = head_scale(prm.amax_b);
     const float unscale = 1.f / (sa * sb);
-    float va[16], vb[16];
-    auto load_stage = [&](int k0) {
+    // The dropout masks of the images this tile touches live in LDS (a few KB, copied once): the commit reads them from there instead of
+    // holding 16 + 16 more registers of prefetched mask values per thread.
+    float* mlds = reinterpret_cast<float*>(lds + 2 * STAGE);                 // [n_slot][K] (maskA), then [n_slot][K] (mask3, EPI_BIAS)
+    const int b_first = m0 / prm.HW;
+    if constexpr (KVEC) {
+        const int nm = prm.n_slot * prm.K;
+        for (int i = tid; i < nm; i += 256 * NW) {
+            const int slot = i / prm.K, k = i - slot * prm.K;
+            const int bs = min(b_first + slot, prm.n_img - 1);
+            mlds[i] = prm.maskA[(size_t)bs * prm.mask_ld + k];
+            if constexpr (EPI == EPI_BIAS) mlds[nm + i] = prm.mask3[(size_t)bs * prm.mask3_ld + k];
+        }
+    }
+    const float* ml_row = mlds + (b - b_first) * prm.K;
+    const float* ml3_row = ml_row + prm.n_slot * prm.K;
+
+    // load_a / load_b: nothing but loads into registers (no arithmetic, no stores: whatever uses a loaded value makes the compiler wait
+    // for it, and this runs right before the MFMAs of the stage in LDS); commit_stage turns them into a stage's operands.  The token
+    // operand streams from HBM (latency ~3 us under load, measured as the stage time with a one-stage look-ahead): it is fetched TWO
+    // stages ahead (xa[2]); the weight planes come from L2 and are fetched one stage ahead.
+    f32x4 xa[2][4];
+    hu32x4 vbh[2], vbl[2];
+    auto load_b = [&](int k0) {
+        vbh[0] = *reinterpret_cast<const hu32x4*>(bh_row + k0);
+        vbh[1] = *reinterpret_cast<const hu32x4*>(bh_row + k0 + 8);
+        vbl[0] = *reinterpret_cast<const hu32x4*>(bl_row + k0);
+        vbl[1] = *reinterpret_cast<const hu32x4*>(bl_row + k0 + 8);
+    };
+    auto load_a = [&](int k0, f32x4 (&x)[4]) {
         const int kk = k0 + 16 * h;
         if constexpr (KVEC) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 x = *reinterpret_cast<const f32x4*>(arow + kk + 4 * q);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(prm.B + (size_t)nc * prm.ldb + kk + 4 * q);
-                if (frow) {                      // (uniform per thread over the whole K loop)
-                    f32x4 y = x;
-                    if (m3row) y = y * *reinterpret_cast<const f32x4*>(m3row + kk + 4 * q);
-                    *reinterpret_cast<f32x4*>(frow + kk + 4 * q) = y;
-                }
-                if (mrow) x = x * *reinterpret_cast<const f32x4*>(mrow + kk + 4 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { va[4 * q + e] = x[e] * (sa * a_keep); vb[4 * q + e] = w[e] * (sb * b_keep); }
-            }
+            for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(arow + kk + 4 * q);
         } else {
-            float xa[16];
+            // (the K = cfg.dim operand: no mask on this path; clamped addresses, zeroed by a 0 / 1 factor at commit)
             if ((prm.K & 1) == 0 && ((prm.a_img | prm.a_tok) & 1) == 0) {           // 8-byte aligned rows: pairs
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const int kc = kk + e < prm.K ? kk + e : prm.K - 2;
                     const f32x2 v = *reinterpret_cast<const f32x2*>(arow + kc);
-                    xa[e] = v[0];
-                    xa[e + 1] = v[1];
+                    x[e >> 2][e & 3] = v[0];
+                    x[e >> 2][(e & 3) + 1] = v[1];
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) xa[e] = arow[kk + e < prm.K ? kk + e : prm.K - 1];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = kk + e;
-                const bool k_ok = k < prm.K;
-                const int kc = k_ok ? k : prm.K - 1;
-                float x = xa[e];
-                if (mrow) x *= mrow[kc];
-                const float w = prm.B[(size_t)kc * b_kstride + (size_t)nc * b_nstride];      // (one load: no select between two)
-                const float kf = k_ok ? 1.f : 0.f;
-                va[e] = x * (sa * a_keep * kf);
-                vb[e] = w * (sb * b_keep * kf);
+                for (int e = 0; e < 16; ++e) x[e >> 2][e & 3] = arow[kk + e < prm.K ? kk + e : prm.K - 1];
             }
         }
     };
 
-    load_stage(0);
-    for (int k0 = 0; k0 < prm.K; k0 += HKS) {
-        __syncthreads();                         // the previous stage's MFMAs are done with the LDS
-        head_commit16(As, row, h, va);
-        head_commit16(Bs, row, h, vb);
+    auto commit_stage = [&](unsigned char* st, int k0, const f32x4 (&x)[4], auto with_a) {
+        if constexpr (decltype(with_a)::value) {
+            const int kk = k0 + 16 * h;
+            float va[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 f = f32x4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (KVEC) f = *reinterpret_cast<const f32x4*>(ml_row + kk + 4 * q);
+                if constexpr (EPI == EPI_BIAS) {
+                    if (frow) *reinterpret_cast<f32x4*>(frow + kk + 4 * q) = x[q] * *reinterpret_cast<const f32x4*>(ml3_row + kk + 4 * q);   // feats_out = x * m3 (modules.py:116)
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = f[e] * (sa * a_keep);
+                    if constexpr (!KVEC) g *= (kk + 4 * q + e < prm.K) ? 1.f : 0.f;
+                    va[4 * q + e] = x[q][e] * g;
+                }
+            }
+            head_commit16(st, arow_i, h, va);
+        }
+        unsigned char* Bs = st + HSIDE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<hu32x4*>(Bs + hswz(row, 2 * h + u)) = vbh[u];
+            *reinterpret_cast<hu32x4*>(Bs + BLO + hswz(row, 2 * h + u)) = vbl[u];
+        }
+    };
+    // stage k's MFMAs read buffer k & 1 while stage k + 1 is committed to the other buffer: ONE barrier per stage, and the waves drift
+    // apart - one wave's split / LDS writes run under the other waves' MFMAs.  The loop exists twice - for the waves that also stage
+    // the token operand and for those that only copy weight units - so that each copy issues a fixed number of loads per iteration: with
+    // the A loads inside a branch the compiler has to wait for ALL loads (vmcnt(0)) before the commit, look-ahead included.
+    // Every workgroup walks the K stages in the same cyclic order but starts at its own stage (blockIdx.x mod stages): at any time the
+    // tiles of the launch read different 128-byte columns of the token rows.  In step, they all hit the same residues of the
+    // 1536-byte row pitch - a fraction of the memory channels at a time.
+    const int k_end = (prm.K + HKS - 1) / HKS * HKS;
+    const int n_st = k_end / HKS;
+    const int st0 = (int)(blockIdx.x % (unsigned)n_st);
+    auto stage_k = [&](int i) { const int j = st0 + min(i, n_st - 1); return (j >= n_st ? j - n_st : j) * HKS; };      // i-th stage of my order (clamped)
+    auto run = [&](auto with_a) {
+        constexpr bool WITH_A = decltype(with_a)::value;
+        load_b(stage_k(0));
+        if constexpr (WITH_A) {
+            load_a(stage_k(0), xa[0]);
+            load_a(stage_k(1), xa[1]);
+        }
+        __syncthreads();                             // the masks are in LDS
+        commit_stage(lds, stage_k(0), xa[0], with_a);
         __syncthreads();
-        if (k0 + HKS < prm.K) load_stage(k0 + HKS);          // in flight under the MFMAs
-        head_mma_stage(As, Bs, acc, lane, wr, wc);
-    }
+        // iteration i (its stage is in LDS buffer CUR): fetch B of stage i + 1 and A of stage i + 2, run the MFMAs, commit stage i + 1
+        auto iteration = [&](int i, auto cur_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            const bool more = i + 1 < n_st;
+            // (unconditional, from clamped stage numbers: a load inside a branch makes the number of loads in flight path-dependent,
+            // and the compiler then waits for all of them before the commit)
+            load_b(stage_k(i + 1));
+            __builtin_amdgcn_sched_barrier(0);       // B's loads first: the commit waits for them with the look-ahead A loads still in flight
+            if constexpr (WITH_A) load_a(stage_k(i + 2), xa[CUR]);                      // (xa[CUR] held stage i: committed one iteration ago)
+            __builtin_amdgcn_sched_barrier(0);
+            head_mma_stage<8192, BLO>(lds + CUR * STAGE, lds + CUR * STAGE + HSIDE, acc, lane, wr, wc);
+            if (more) commit_stage(lds + (CUR ^ 1) * STAGE, stage_k(i + 1), xa[CUR ^ 1], with_a);
+            __syncthreads();
+        };
+        for (int i = 0; i < n_st; i += 2) {
+            iteration(i, std::integral_constant<int, 0>{});
+            if (i + 1 < n_st) iteration(i + 1, std::integral_constant<int, 1>{});
+        }
+    };
+    if (NW == 1 || stage_a) run(std::true_type{});
+    else run(std::false_type{});
 
-    // epilogue straight from the accumulators: for a fixed register the lanes 0-31 hold 32 consecutive columns of one row.
-    // Loads (accumulate / mask modes) are unconditional from clamped addresses, only the store is predicated.
+    // epilogue straight from the accumulators (transposed blocks, see head_mma_stage): lane & 31 is the row, register 4 j + e the column
+    // 8 j + 4 (lane >> 5) + e of a 32 x 32 block.  Loads (accumulate / mask modes) are unconditional from clamped addresses, issued for
+    // a whole block pair before their first use; 16-byte accesses wherever the four columns exist (rows of C need not be 16-byte aligned:
+    // the K = 70 code rows are not; global accesses only need dword alignment), scalar ones at the ragged edge.
     float omax = 0.f;
-    // (accumulate / mask modes: all 64 old values first, in one round trip - a load per element right before its use is 64 round trips)
-    f32x16 old[2][2];
-    if (EPI == EPI_ACCUM || EPI == EPI_MASK_POS) {
+    const int rloc = lane & 31, hsel = lane >> 5;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + 64 * wc + 32 * ni + (lane & 31);
-            const int colc = col < prm.N ? col : prm.N - 1;
+    for (int mi = 0; mi < 2; ++mi) {
+        const int rr = m0 + 64 * wr + 32 * mi + rloc;
+        const bool r_ok = rr < prm.M;
+        const unsigned rrc = (unsigned)(r_ok ? rr : prm.M - 1);
+        // (32-bit element offsets from a uniform base: one address register per access instead of two; host-checked range)
+        f32x4 old[2][4];
+        if (EPI == EPI_ACCUM || EPI == EPI_MASK_POS) {
+            const float* src = EPI == EPI_ACCUM ? prm.C : prm.aux;
+            const unsigned ld = EPI == EPI_ACCUM ? (unsigned)prm.ldc : (unsigned)prm.ldaux;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = m0 + 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int rrc = rr < prm.M ? rr : prm.M - 1;
-                    old[mi][ni][r] = EPI == EPI_ACCUM ? *reinterpret_cast<const volatile float*>(prm.C + (size_t)rrc * prm.ldc + colc)
-                                                      : *reinterpret_cast<const volatile float*>(prm.aux + (size_t)rrc * prm.ldaux + colc);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int col = n0 + 64 * wc + 32 * ni + 8 * jj + 4 * hsel;
+                    if (col + 3 < prm.N) {
+                        // (one 16-byte load, alignment 4; it cannot sink below the first store to C, which may alias it)
+                        __builtin_memcpy(&old[ni][jj], src + (rrc * ld + (unsigned)col), 16);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) old[ni][jj][e] = *reinterpret_cast<const volatile float*>(src + (rrc * ld + (unsigned)min(col + e, prm.N - 1)));
+                    }
                 }
         }
-    }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + 64 * wc + 32 * ni + (lane & 31);
-        const bool c_ok = col < prm.N;
-        const int colc = c_ok ? col : prm.N - 1;
-        float bs = 0.f;
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
-            if (prm.bias) bs += prm.bias[colc];
-            if (prm.bias2) bs += prm.bias2[colc];
-        }
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int col = n0 + 64 * wc + 32 * ni + 8 * jj + 4 * hsel;
+                f32x4 v, bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+                    // (bias / bias2 always point at >= N floats, a row of zeros when absent; the host pads nothing: clamp at the edge)
+                    if (col + 3 < prm.N) {
+                        f32x4 t;
+                        __builtin_memcpy(&t, prm.bias + col, 16); bs4 = t;
+                        __builtin_memcpy(&t, prm.bias2 + col, 16); bs4 += t;
+                    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = m0 + 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[mi][ni][r] * unscale;
-                if (EPI == EPI_BIAS) v += bs;
-                else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bs, 0.f);
-                else if (EPI == EPI_ACCUM) v += old[mi][ni][r];
-                else v *= old[mi][ni][r] > 0.f ? 1.f : 0.f;
-                if (c_ok && rr < prm.M) {
-                    prm.C[(size_t)rr * prm.ldc + col] = v;
-                    omax = fmaxf(omax, fabsf(v));
+                        for (int e = 0; e < 4; ++e) bs4[e] = prm.bias[min(col + e, prm.N - 1)] + prm.bias2[min(col + e, prm.N - 1)];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[mi][ni][4 * jj + e] * unscale;
+                    if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+                        x += bs4[e];
+                        if (EPI == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+                    } else if (EPI == EPI_ACCUM) x += old[ni][jj][e];
+                    else x *= old[ni][jj][e] > 0.f ? 1.f : 0.f;
+                    v[e] = x;
+                }
+                float* dst = prm.C + (rrc * (unsigned)prm.ldc + (unsigned)col);
+                if (r_ok && col + 3 < prm.N) {
+                    __builtin_memcpy(dst, &v, 16);                 // (alignment 4: one global_store_dwordx4)
+                    omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                } else if (r_ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < prm.N) { dst[e] = v[e]; omax = fmaxf(omax, fabsf(v[e])); }
                 }
             }
     }
@@ -316,7 +479,8 @@ struct HeadWgradParams {
     const float* X;            // token operand: (b, t) at X + b * x_img + t * x_tok, Kc contiguous
     long long x_img, x_tok;
     int HW;
-    const float* maskX;        // [B, Kc] or null
+    const float* maskX;        // X'[t][c] = X[t][c] * maskX[b * mask_ld + c]: [B, Kc] (mask_ld = Kc) or one row of ones (mask_ld = 0); never null
+    int mask_ld;
     float* part;               // [splits][N][Kc] partial sums
     float* part_bias;          // [splits][N] partial column sums of G (written by channel tile 0) or null
     const unsigned* amax_g;    // largest |G| / |X| (see head_scale) or null
@@ -326,10 +490,8 @@ struct HeadWgradParams {
 
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams prm)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HSIDE];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // two stages of [G 16 KB][X 16 KB] (double buffer)
     __shared__ float colsum[2][HT];
-    unsigned char* Gs = lds;
-    unsigned char* Xs = lds + HSIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * HT, c0 = blockIdx.y * HT, split = blockIdx.z;
     // token range of this split: whole stages of 32 tokens
@@ -353,7 +515,9 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams p
     const int ncl = n_ok ? n : prm.N - 1, ccl = c_ok ? c : prm.Kc - 1;     // (clamped: every load below is unconditional, see the GEMM)
     const float n_keep = n_ok ? 1.f : 0.f, c_keep = c_ok ? 1.f : 0.f;
     const int Bimg = (prm.M + prm.HW - 1) / prm.HW;
-    float vg[16], vx[16];
+    // load_stage: loads only, into raw registers (anything computed from a loaded value here would make the compiler wait for the load
+    // before the MFMAs that follow); commit_stage scales, masks, sums the bias column and splits
+    float rg[16], rx[16], rk0, rk1;
     auto load_stage = [&](int st) {
         const int t0 = st * HKS + 16 * g;
         // my 16 tokens lie in at most two images (HW >= 16 is checked by the host): their bases and mask values once per stage
@@ -361,46 +525,68 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams p
         const int first1 = (b0 + 1) * prm.HW;                 // first token of the next image
         const float* x0 = prm.X + (long long)b0 * prm.x_img + ccl - (long long)b0 * prm.HW * prm.x_tok;
         const float* x1 = prm.X + (long long)b1 * prm.x_img + ccl - (long long)b1 * prm.HW * prm.x_tok;
-        const float k0 = prm.maskX ? prm.maskX[(size_t)b0 * prm.Kc + ccl] : 1.f, k1 = prm.maskX ? prm.maskX[(size_t)b1 * prm.Kc + ccl] : 1.f;
+        rk0 = prm.maskX[(size_t)b0 * prm.mask_ld + ccl];      // (maskX is never null: a row of ones with mask_ld = 0 when there is no mask)
+        rk1 = prm.maskX[(size_t)b1 * prm.mask_ld + ccl];
         const float* gp = prm.G + ncl;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = t0 + e;
             const int mcl = m < prm.M ? m : prm.M - 1;
-            const bool second = mcl >= first1;
-            const float gv = gp[(size_t)mcl * prm.ldg];
-            const float xv = (second ? x1 : x0)[(long long)mcl * prm.x_tok];
-            // (zeroing by a 0 / 1 factor, not by a select: a value that is only used conditionally has its load sunk into a branch)
-            const float okf = m < prm.M ? 1.f : 0.f;
-            vg[e] = gv * (okf * n_keep);
-            vx[e] = xv * ((second ? k1 : k0) * (sx * okf * c_keep));
+            rg[e] = gp[(size_t)mcl * prm.ldg];
+            rx[e] = (mcl >= first1 ? x1 : x0)[(long long)mcl * prm.x_tok];
         }
     };
-    if (s_beg < s_end) load_stage(s_beg);
-    for (int st = s_beg; st < s_end; ++st) {
-        __syncthreads();
-        if (blockIdx.y == 0) {
+    auto commit_stage = [&](unsigned char* stg, int st) {
+        const int t0 = st * HKS + 16 * g;
+        const int first1 = (min(t0 / prm.HW, Bimg - 1) + 1) * prm.HW;
+        float vg[16], vx[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) bsum += vg[e];
+        for (int e = 0; e < 16; ++e) {
+            const int m = t0 + e;
+            const int mcl = m < prm.M ? m : prm.M - 1;
+            // (zeroing by a 0 / 1 factor, not by a select: a value that is only used conditionally has its load sunk into a branch)
+            const float okf = m < prm.M ? 1.f : 0.f;
+            const float gq = rg[e] * (okf * n_keep);
+            if (blockIdx.y == 0) bsum += gq;
+            vg[e] = gq * sg;
+            vx[e] = rx[e] * ((mcl >= first1 ? rk1 : rk0) * (sx * okf * c_keep));
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) vg[e] *= sg;
-        head_commit16(Gs, col, g, vg);           // row = my column, the 32 tokens of the stage are its "channels"
-        head_commit16(Xs, col, g, vx);
-        __syncthreads();
-        if (st + 1 < s_end) load_stage(st + 1);
-        head_mma_stage(Gs, Xs, acc, lane, wr, wc);
+        head_commit16(stg, col, g, vg);           // row = my column, the 32 tokens of the stage are its "channels"
+        head_commit16(stg + HSIDE, col, g, vx);
+    };
+    // double-buffered like the GEMM: one barrier per stage; loads unconditional from a clamped stage number
+    if (s_beg < s_end) {
+        load_stage(s_beg);
+        commit_stage(lds, s_beg);
     }
+    __syncthreads();
+    int cur = 0;
+    for (int st = s_beg; st < s_end; ++st) {
+        const bool more = st + 1 < s_end;
+        load_stage(min(st + 1, s_end - 1));
+        __builtin_amdgcn_sched_barrier(0);       // the loads go out BEFORE the MFMAs (left alone, the scheduler puts them behind)
+        head_mma_stage<8192, 8192>(lds + cur * 2 * HSIDE, lds + cur * 2 * HSIDE + HSIDE, acc, lane, wr, wc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) commit_stage(lds + (cur ^ 1) * 2 * HSIDE, st + 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // (transposed blocks, see head_mma_stage: lane & 31 is the row n, registers hold runs of four consecutive channels)
     float* out = prm.part + (size_t)split * prm.N * prm.Kc;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int cc = c0 + 64 * wc + 32 * ni + (lane & 31);
+    for (int mi = 0; mi < 2; ++mi) {
+        const int nn = n0 + 64 * wr + 32 * mi + (lane & 31);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nn = n0 + 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (nn < prm.N && cc < prm.Kc) out[(size_t)nn * prm.Kc + cc] = acc[mi][ni][r] * unscale;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int cc = c0 + 64 * wc + 32 * ni + 8 * jj + 4 * (lane >> 5);
+                if (nn < prm.N && cc < prm.Kc) {                   // (Kc is a multiple of 32: a run of four is inside or outside)
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * jj + e] * unscale;
+                    *reinterpret_cast<f32x4*>(out + (size_t)nn * prm.Kc + cc) = v;
+                }
             }
     }
     if (blockIdx.y == 0 && prm.part_bias) {
@@ -410,29 +596,31 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams p
     }
 }
 
-// dW[i] = sum_s part[s][i]  (fixed order);  db[n] = sum_s part_bias[s][n] (optionally into two outputs: b1 and b22 share their gradient)
+// dW[i] = sum_s part[s][i]  (fixed order);  db[n] = sum_s part_bias[s][n] (optionally into two outputs: b1 and b22 share their gradient).
+// numel is a multiple of 4 (Kc is a multiple of 32): a thread sums four consecutive outputs, 16 partial tiles in flight.
 __global__ void __launch_bounds__(256) head_reduce_kernel(const float* part, int splits, long long numel, float* dW,
                                                           const float* part_bias, int N, float* db, float* db_b)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i < numel) {
-        float s = 0.f;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
         int k = 0;
-        for (; k + 8 <= splits; k += 8) {            // eight loads in flight, summed in order
-            float v[8];
+        for (; k + 16 <= splits; k += 16) {
+            f32x4 v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + j) * numel + i];
+            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(part + (size_t)(k + j) * numel + i);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
+            for (int j = 0; j < 16; ++j) s += v[j];
         }
-        for (; k < splits; ++k) s += part[(size_t)k * numel + i];
-        dW[i] = s;
+        for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * numel + i);
+        *reinterpret_cast<f32x4*>(dW + i) = s;
     }
-    if (part_bias && i < N) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (part_bias && t < N) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part_bias[(size_t)k * N + i];
-        if (db) db[i] = s;
-        if (db_b) db_b[i] = s;
+        for (int k = 0; k < splits; ++k) s += part_bias[(size_t)k * N + t];
+        if (db) db[t] = s;
+        if (db_b) db_b[t] = s;
     }
 }
 
@@ -444,7 +632,7 @@ static int head_check(const StegoHeadDesc* d)
     if (d->C % 32 != 0 || d->K > 128 || d->tok_stride < d->C || d->img_stride < (int64_t)d->HW * d->tok_stride) return STEGO_ERR_UNSUPPORTED;
     if (d->HW < 16) return STEGO_ERR_UNSUPPORTED;                                                   // (a stage of the weight gradient spans <= 2 images)
     if (d->tok_stride % 4 != 0 || d->img_stride % 4 != 0) return STEGO_ERR_UNSUPPORTED;            // 16-byte token rows
-    if ((int64_t)d->B * d->HW >= (1ll << 31) / 2) return STEGO_ERR_UNSUPPORTED;
+    if ((int64_t)d->B * d->HW >= (1ll << 31) / 2 || (int64_t)d->B * d->HW * d->C >= (1ll << 30)) return STEGO_ERR_UNSUPPORTED;   // 32-bit byte offsets
     return STEGO_OK;
 }
 
@@ -454,21 +642,53 @@ static int wgrad_splits(const StegoHeadDesc* d, int N)
 {
     const int tiles = ((N + HT - 1) / HT) * ((d->C + HT - 1) / HT);
     const long long stages = ((long long)d->B * d->HW + HKS - 1) / HKS;
-    long long s = (2 * 256 + tiles - 1) / tiles;                     // ~two workgroups per compute unit
+    long long s = (2 * 256 + tiles - 1) / tiles;                     // ~two workgroups per compute unit (one per CU: partial tiles 50 -> 25 MB, reduction 28 -> 16 us, but the GEMMs 81 -> 100 us: measured, not kept)
     if (s > stages) s = stages;
     return s < 1 ? 1 : (int)s;
 }
 
-static hipError_t launch_gemm(const HeadGemmParams& p, bool kvec, hipStream_t s)
+// columns of a C-wide output handled per workgroup: 384 (one staging of the token operand) when C is a multiple of it
+static int wide_blocks(int N) { return N % (3 * HT) == 0 ? 3 : 1; }
+static size_t plane_halves(int N, int K, int nw) { return (size_t)((N + HT * nw - 1) / (HT * nw) * (HT * nw)) * (size_t)((K + HKS - 1) / HKS * HKS); }
+
+template <bool KVEC, int EPI, int NW>
+static hipError_t launch_gemm_t(const HeadGemmParams& p, hipStream_t s)
 {
-    const dim3 grid((p.M + HT - 1) / HT, (p.N + HT - 1) / HT), block(256);
-    if (kvec && p.epi == EPI_BIAS) hipLaunchKernelGGL((head_gemm_kernel<true, EPI_BIAS>), grid, block, 0, s, p);
-    else if (kvec && p.epi == EPI_BIAS_RELU) hipLaunchKernelGGL((head_gemm_kernel<true, EPI_BIAS_RELU>), grid, block, 0, s, p);
-    else if (kvec && p.epi == EPI_ACCUM) hipLaunchKernelGGL((head_gemm_kernel<true, EPI_ACCUM>), grid, block, 0, s, p);
-    else if (!kvec && p.epi == EPI_MASK_POS) hipLaunchKernelGGL((head_gemm_kernel<false, EPI_MASK_POS>), grid, block, 0, s, p);
-    else return hipErrorInvalidValue;
+    const int lds_bytes = 2 * (HSIDE + 2 * NW * 8192) + (KVEC ? (EPI == EPI_BIAS ? 2 : 1) * p.n_slot * p.K * (int)sizeof(float) : 0);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&head_gemm_kernel<KVEC, EPI, NW>), lds_bytes);
+    if (e != hipSuccess) return e;
+    const dim3 grid((p.M + HT - 1) / HT, (p.N + HT * NW - 1) / (HT * NW)), block(256 * NW);
+    hipLaunchKernelGGL((head_gemm_kernel<KVEC, EPI, NW>), grid, block, lds_bytes, s, p);
     return hipGetLastError();
 }
+
+static hipError_t launch_gemm(const HeadGemmParams& p, bool kvec, int nw, hipStream_t s)
+{
+    if (kvec && p.epi == EPI_BIAS && nw == 1) return launch_gemm_t<true, EPI_BIAS, 1>(p, s);
+    if (kvec && p.epi == EPI_BIAS_RELU && nw == 1) return launch_gemm_t<true, EPI_BIAS_RELU, 1>(p, s);
+    if (kvec && p.epi == EPI_BIAS_RELU && nw == 3) return launch_gemm_t<true, EPI_BIAS_RELU, 3>(p, s);
+    if (kvec && p.epi == EPI_ACCUM && nw == 1) return launch_gemm_t<true, EPI_ACCUM, 1>(p, s);
+    if (!kvec && p.epi == EPI_MASK_POS && nw == 1) return launch_gemm_t<false, EPI_MASK_POS, 1>(p, s);
+    if (!kvec && p.epi == EPI_MASK_POS && nw == 3) return launch_gemm_t<false, EPI_MASK_POS, 3>(p, s);
+    return hipErrorInvalidValue;
+}
+
+// one operand of a GEMM as the planes head_prep_weights_kernel writes: carves them from `ws`, fills the job
+struct HeadPlanes { half_t* hi; half_t* lo; int ld; };
+static HeadPlanes carve_planes(unsigned char*& ws, HeadPrepJob& jb, const float* src, int N, int K, int ld, int transposed, int nw,
+                               unsigned* amax)
+{
+    const size_t n = plane_halves(N, K, nw);
+    HeadPlanes pl;
+    pl.hi = reinterpret_cast<half_t*>(ws); ws += (n * 2 + 255) / 256 * 256;
+    pl.lo = reinterpret_cast<half_t*>(ws); ws += (n * 2 + 255) / 256 * 256;
+    pl.ld = (K + HKS - 1) / HKS * HKS;
+    jb.src = src; jb.N = N; jb.K = K; jb.ld = ld; jb.transposed = transposed; jb.hi = pl.hi; jb.lo = pl.lo;
+    jb.Npad = (N + HT * nw - 1) / (HT * nw) * (HT * nw); jb.Kpad = pl.ld; jb.amax = amax;
+    return pl;
+}
+static size_t planes_bytes(int N, int K, int nw) { return 2 * ((plane_halves(N, K, nw) * 2 + 255) / 256 * 256); }
 
 }  // namespace stego
 
@@ -477,12 +697,15 @@ using namespace stego;
 extern "C" {
 
 // operand-scale words (bits of the largest magnitude, see head_scale): the forward fills 0-4 and hands them to the backward
-enum { HS_X = 0, HS_W1, HS_W21, HS_W22, HS_H, HS_G, HS_DH, HS_COUNT = 8 };
+enum { HS_X = 0, HS_W1, HS_W21, HS_W22, HS_H, HS_G, HS_DH, HS_COUNT = HS_WORDS };
 
 size_t stego_head_fwd_workspace_bytes(const StegoHeadDesc* d)
 {
     if (head_check(d) != STEGO_OK) return 0;
-    return 256 + (d->nonlinear ? round256((size_t)d->B * d->HW * d->C * sizeof(float)) : 0);
+    size_t total = 256 + 2 * round256((size_t)d->C * sizeof(float)) + planes_bytes(d->K, d->C, 1);     // scale words, a row of ones, a row of zeros, W1 planes
+    if (d->nonlinear) total += planes_bytes(d->C, d->C, wide_blocks(d->C)) + planes_bytes(d->K, d->C, 1)     // W21, W22 planes
+                               + round256((size_t)d->B * d->HW * d->C * sizeof(float));                      // H (when saved_h is NULL)
+    return total;
 }
 
 size_t stego_head_bwd_workspace_bytes(const StegoHeadDesc* d)
@@ -490,8 +713,9 @@ size_t stego_head_bwd_workspace_bytes(const StegoHeadDesc* d)
     if (head_check(d) != STEGO_OK) return 0;
     const size_t M = (size_t)d->B * d->HW;
     size_t part = (size_t)wgrad_splits(d, d->K) * d->K * d->C, pbias = (size_t)wgrad_splits(d, d->K) * d->K;
-    size_t total = 256 + round256(part * 4) + round256(pbias * 4);
+    size_t total = 256 + round256((size_t)d->C * 4) + round256(part * 4) + round256(pbias * 4);
     if (d->nonlinear) {
+        total += planes_bytes(d->C, d->K, wide_blocks(d->C));                              // W22^T planes
         total += round256(M * d->C * 4);                                                   // dHpre
         total += round256((size_t)wgrad_splits(d, d->C) * d->C * d->C * 4) + round256((size_t)wgrad_splits(d, d->C) * d->C * 4);
     }
@@ -508,46 +732,65 @@ int stego_head_fwd(const StegoHeadDesc* d, const float* tokens, const float* mas
     if (!tokens || !w1 || !b1 || !code) return STEGO_ERR_NULL;
     if (d->nonlinear && (!w21 || !b21 || !w22 || !b22)) return STEGO_ERR_NULL;
     if (!workspace) return STEGO_ERR_NULL;
-    if (workspace_bytes < (d->nonlinear && !saved_h ? stego_head_fwd_workspace_bytes(d) : 256)) return STEGO_ERR_WORKSPACE;
+    if (workspace_bytes < stego_head_fwd_workspace_bytes(d) - (d->nonlinear && saved_h ? round256((size_t)d->B * d->HW * d->C * sizeof(float)) : 0))
+        return STEGO_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = d->B * d->HW;
     hipError_t e;
     // operand scales: the first 32 bytes of the workspace (or of saved_scales' home: the tail of saved_h, see the header)
-    unsigned* sc = saved_h ? reinterpret_cast<unsigned*>(saved_h + (size_t)M * d->C) : static_cast<unsigned*>(workspace);
-    if ((e = hipMemsetAsync(sc, 0, HS_COUNT * sizeof(unsigned), s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
-    auto absmax = [&](const float* x, long long img, long long rowst, int rpi, long long rows, int cols, int which) -> hipError_t {
-        int blocks = (int)((rows * cols / 4 + 256 * 4 - 1) / (256 * 4));
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    unsigned* sc = saved_h ? reinterpret_cast<unsigned*>(saved_h + (size_t)M * d->C) : reinterpret_cast<unsigned*>(ws);
+    // [scale words 256 B][a row of zeros: the absent second bias; C >= K][a row of ones: the mask operand of whatever has no dropout
+    // mask (kernels never test a mask pointer)], all written by one small launch
+    float* zeros = reinterpret_cast<float*>(ws + 256);
+    const size_t zbytes = round256((size_t)d->C * sizeof(float));
+    ws += 256 + zbytes;
+    float* ones = reinterpret_cast<float*>(ws); ws += zbytes;
+    hipLaunchKernelGGL(head_consts_kernel, dim3((d->C + 255) / 256), dim3(256), 0, s, sc, (const unsigned*)nullptr, 0, zeros, ones, d->C);
+    if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    {
+        int blocks = (int)(((long long)M * d->C / 4 + 256 * 4 - 1) / (256 * 4));
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-        hipLaunchKernelGGL(head_absmax_kernel, dim3(blocks), dim3(256), 0, s, x, img, rowst, rpi, rows, cols, sc + which);
-        return hipGetLastError();
-    };
-    if ((e = absmax(tokens, d->img_stride, d->tok_stride, d->HW, M, d->C, HS_X)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
-    if ((e = absmax(w1, 0, d->C, d->K, d->K, d->C, HS_W1)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
-    if (d->nonlinear) {
-        if ((e = absmax(w21, 0, d->C, d->C, d->C, d->C, HS_W21)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
-        if ((e = absmax(w22, 0, d->C, d->K, d->K, d->C, HS_W22)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+        hipLaunchKernelGGL(head_absmax_kernel, dim3(blocks), dim3(256), 0, s, tokens, (long long)d->img_stride, (long long)d->tok_stride,
+                           d->HW, (long long)M, d->C, sc + HS_X);
+        if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     }
+    // the weights as fp16 hi / lo planes (+ their scale words), two small launches
+    const int nw21 = wide_blocks(d->C);
+    HeadPrepParams prep{};
+    const HeadPlanes pw1 = carve_planes(ws, prep.job[0], w1, d->K, d->C, d->C, 0, 1, sc + HS_W1);
+    HeadPlanes pw21{}, pw22{};
+    if (d->nonlinear) {
+        pw21 = carve_planes(ws, prep.job[1], w21, d->C, d->C, d->C, 0, nw21, sc + HS_W21);
+        pw22 = carve_planes(ws, prep.job[2], w22, d->K, d->C, d->C, 0, 1, sc + HS_W22);
+    }
+    hipLaunchKernelGGL(head_prep_absmax_kernel, dim3(d->nonlinear ? 3 : 1, PREP_WG), dim3(256), 0, s, prep);
+    hipLaunchKernelGGL(head_prep_split_kernel, dim3(d->nonlinear ? 3 : 1, PREP_WG), dim3(256), 0, s, prep);
+    if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     HeadGemmParams p{};
+    p.n_img = d->B; p.n_slot = std::min(d->B, (HT - 1) / d->HW + 2);
     p.amax_a = sc + HS_X; p.amax_b = sc + HS_W1;
     p.A = tokens; p.a_img = d->img_stride; p.a_tok = d->tok_stride; p.HW = d->HW; p.M = M; p.K = d->C;
     // cluster1 (+ both output biases: cluster2[2]'s is added here so that the third GEMM only accumulates) (+ feats_out)
-    p.maskA = mask1; p.B = w1; p.ldb = d->C; p.C = code; p.ldc = d->K; p.N = d->K;
-    p.bias = b1; p.bias2 = d->nonlinear ? b22 : nullptr; p.epi = EPI_BIAS;
-    p.feats_out = feats_out; p.mask3 = mask3;
-    if ((e = launch_gemm(p, true, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    p.maskA = mask1 ? mask1 : ones; p.mask_ld = mask1 ? d->C : 0; p.Bh = pw1.hi; p.Bl = pw1.lo; p.ldb = pw1.ld; p.C = code; p.ldc = d->K; p.N = d->K;
+    p.bias = b1; p.bias2 = d->nonlinear ? b22 : zeros; p.epi = EPI_BIAS;
+    p.feats_out = feats_out; p.mask3 = mask3 ? mask3 : ones; p.mask3_ld = mask3 ? d->C : 0;
+    if ((e = launch_gemm(p, true, 1, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     if (!d->nonlinear) return STEGO_OK;
-    float* H = saved_h ? saved_h : reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + 256);
+    float* H = saved_h ? saved_h : reinterpret_cast<float*>(ws);
     // H = relu(cluster2[0](x * m2))
-    p.maskA = mask2; p.B = w21; p.ldb = d->C; p.C = H; p.ldc = d->C; p.N = d->C;
-    p.bias = b21; p.bias2 = nullptr; p.epi = EPI_BIAS_RELU; p.feats_out = nullptr; p.mask3 = nullptr;
+    p.maskA = mask2 ? mask2 : ones; p.mask_ld = mask2 ? d->C : 0; p.Bh = pw21.hi; p.Bl = pw21.lo; p.ldb = pw21.ld; p.C = H; p.ldc = d->C; p.N = d->C;
+    p.bias = b21; p.bias2 = zeros; p.epi = EPI_BIAS_RELU; p.feats_out = nullptr; p.mask3 = ones; p.mask3_ld = 0;
     p.amax_b = sc + HS_W21; p.amax_out = sc + HS_H;
-    if ((e = launch_gemm(p, true, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    if ((e = launch_gemm(p, true, nw21, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     // code += cluster2[2](H)
     HeadGemmParams q{};
+    q.n_img = p.n_img; q.n_slot = p.n_slot;
     q.A = H; q.a_img = (long long)d->HW * d->C; q.a_tok = d->C; q.HW = d->HW; q.M = M; q.K = d->C;
-    q.B = w22; q.ldb = d->C; q.C = code; q.ldc = d->K; q.N = d->K; q.epi = EPI_ACCUM;
+    q.maskA = ones; q.mask_ld = 0; q.mask3 = ones; q.mask3_ld = 0;
+    q.Bh = pw22.hi; q.Bl = pw22.lo; q.ldb = pw22.ld; q.C = code; q.ldc = d->K; q.N = d->K; q.epi = EPI_ACCUM;
     q.amax_a = sc + HS_H; q.amax_b = sc + HS_W22;
-    if ((e = launch_gemm(q, true, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    if ((e = launch_gemm(q, true, 1, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     return STEGO_OK;
 }
 
@@ -567,12 +810,15 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
     const int sk = wgrad_splits(d, K), sc = wgrad_splits(d, C);
     // operand scales: the forward's (behind saved_h, or - linear head - recomputed here for X) + G's
     unsigned* scl = reinterpret_cast<unsigned*>(ws); ws += 256;
+    float* ones = reinterpret_cast<float*>(ws); ws += round256((size_t)C * 4);       // the mask operand of whatever has no dropout mask
     {
         hipError_t e0;
-        if (d->nonlinear) e0 = hipMemcpyAsync(scl, saved_h + (size_t)M * C, HS_COUNT * sizeof(unsigned), hipMemcpyDeviceToDevice, s);
-        else e0 = hipMemsetAsync(scl, 0, HS_COUNT * sizeof(unsigned), s);
-        if (e0 != hipSuccess) return STEGO_ERR_HIP + (int)e0;
-        if ((e0 = hipMemsetAsync(scl + HS_G, 0, 2 * sizeof(unsigned), s)) != hipSuccess) return STEGO_ERR_HIP + (int)e0;
+        // the forward's words X .. H (HS_G onwards are this call's: zeroed; W22's word holds the maximum of the same matrix the prep
+        // kernel raises it to again), or - linear head - everything zeroed and X recomputed; + the row of ones: one launch
+        hipLaunchKernelGGL(head_consts_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scl,
+                           d->nonlinear ? reinterpret_cast<const unsigned*>(saved_h + (size_t)M * C) : (const unsigned*)nullptr, (int)HS_G,
+                           (float*)nullptr, ones, C);
+        if ((e0 = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e0;
         auto absmax = [&](const float* x, long long img, long long rowst, int rpi, long long rows, int cols, int which) -> hipError_t {
             int blocks = (int)((rows * cols / 4 + 256 * 4 - 1) / (256 * 4));
             blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
@@ -588,15 +834,18 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
     auto wgrad = [&](const float* G, int ldg, int N, const float* X, long long x_img, long long x_tok, const float* maskX,
                      float* part, float* pbias, int splits, float* dW, float* db, float* db_b) -> hipError_t {
         HeadWgradParams w{};
-        w.G = G; w.ldg = ldg; w.X = X; w.x_img = x_img; w.x_tok = x_tok; w.HW = d->HW; w.maskX = maskX;
+        w.G = G; w.ldg = ldg; w.X = X; w.x_img = x_img; w.x_tok = x_tok; w.HW = d->HW;
+        w.maskX = maskX ? maskX : ones; w.mask_ld = maskX ? C : 0;
         w.part = part; w.part_bias = pbias; w.M = M; w.N = N; w.Kc = C; w.splits = splits;
         w.amax_g = G == d_code ? scl + HS_G : scl + HS_DH;
         w.amax_x = X == tokens ? scl + HS_X : scl + HS_H;
-        hipLaunchKernelGGL(head_wgrad_kernel, dim3((N + HT - 1) / HT, (C + HT - 1) / HT, splits), dim3(256), 0, s, w);
-        hipError_t er = hipGetLastError();
+        hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&head_wgrad_kernel), 4 * HSIDE);
+        if (er != hipSuccess) return er;
+        hipLaunchKernelGGL(head_wgrad_kernel, dim3((N + HT - 1) / HT, (C + HT - 1) / HT, splits), dim3(256), 4 * HSIDE, s, w);
+        er = hipGetLastError();
         if (er != hipSuccess) return er;
         const long long numel = (long long)N * C;
-        hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, s, part, splits, numel, dW,
+        hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)std::max<long long>((numel / 4 + 255) / 256, (N + 255) / 256)), dim3(256), 0, s, part, splits, numel, dW,
                            pbias, N, db, db_b);
         return hipGetLastError();
     };
@@ -611,12 +860,21 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
     float* dH = reinterpret_cast<float*>(ws); ws += round256((size_t)M * C * 4);
     float* part_c = reinterpret_cast<float*>(ws); ws += round256((size_t)sc * C * C * 4);
     float* pbias_c = reinterpret_cast<float*>(ws);
+    const int nwb = wide_blocks(C);
+    HeadPrepParams prep{};
+    unsigned char* wsp = reinterpret_cast<unsigned char*>(pbias_c) + round256((size_t)sc * C * 4);
+    const HeadPlanes pwt = carve_planes(wsp, prep.job[0], w22, C, K, C, 1, nwb, scl + HS_W22);      // B[n = channel j][k] = w22[k][j]
+    // (W22's scale word holds the forward's maximum of the same matrix: raising it to the same value again is a no-op, no zeroing)
+    hipLaunchKernelGGL(head_prep_absmax_kernel, dim3(1, PREP_WG), dim3(256), 0, s, prep);
+    hipLaunchKernelGGL(head_prep_split_kernel, dim3(1, PREP_WG), dim3(256), 0, s, prep);
+    if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     HeadGemmParams p{};
+    p.n_img = d->B; p.n_slot = 1;
     p.A = d_code; p.a_img = (long long)d->HW * K; p.a_tok = K; p.HW = d->HW; p.M = M; p.K = K;
-    p.B = w22; p.ldb = C; p.b_transposed = 1;                  // B[n = channel j][k] = w22[k][j]
+    p.Bh = pwt.hi; p.Bl = pwt.lo; p.ldb = pwt.ld;
     p.C = dH; p.ldc = C; p.N = C; p.epi = EPI_MASK_POS; p.aux = saved_h; p.ldaux = C;
     p.amax_a = scl + HS_G; p.amax_b = scl + HS_W22; p.amax_out = scl + HS_DH;
-    if ((e = launch_gemm(p, false, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    if ((e = launch_gemm(p, false, nwb, s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
     // dW21 = dHpre^T (x * m2), db21 = colsum(dHpre)
     if ((e = wgrad(dH, C, C, tokens, d->img_stride, d->tok_stride, mask2, part_c, pbias_c, sc, dw21, db21, nullptr)) != hipSuccess)
         return STEGO_ERR_HIP + (int)e;
