@@ -67,6 +67,18 @@ int stego_head_bwd(const StegoHeadDesc* desc, const float* tokens, const float* 
                    const float* w22, const float* d_code, float* dw1, float* db1, float* dw21, float* db21, float* dw22,
                    float* db22, void* workspace, size_t workspace_bytes, stego_stream_t stream);
 
+/* The dropout masks themselves, as torch draws them: nn.Dropout2d (modules.py:33, :109-114) = F.dropout2d -> ATen feature dropout:
+ *     noise = x.new_empty(B, C, 1, 1).bernoulli_(1 - p).div_(1 - p)
+ * per call.  n_masks consecutive calls from the device generator's state (seed, offset) - or, with seed_ptr / offset_ptr set, from the
+ * graph-safe state read on the device (offset = *offset_ptr + offset; see stego_ref_draws_indirect) - in ONE launch, bit for bit: Philox
+ * counter layout and grid policy of ATen's distribution template, curand_uniform4's conversion, value < (float)(1 - p), times the
+ * float 1 / (1 - p).  masks: [n_masks][numel] floats (numel = B * C).  The caller advances the generator by
+ * stego_ref_dropout_masks_advance().  `variant` bits 0 / 1 as for stego_ref_draws; the host checks the result against the real torch
+ * calls once per process and size and keeps the torch calls if no variant matches. */
+int stego_ref_dropout_masks(uint64_t seed, uint64_t offset, const int64_t* seed_ptr, const int64_t* offset_ptr, int32_t variant,
+                            int32_t n_masks, int64_t numel, float keep_prob, float* masks, stego_stream_t stream);
+uint64_t stego_ref_dropout_masks_advance(int64_t numel, int32_t n_masks, int32_t variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,8 @@ SIGNATURES = {
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
     "stego_ref_draws": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_ref_draws_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32, c_int32]),
+    "stego_ref_dropout_masks": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, _P, _P, c_int32, c_int32, c_int64, c_float, _P, _P]),
+    "stego_ref_dropout_masks_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32]),
     "stego_ref_draws_indirect": (c_int32, [_P, _P, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_fast_draws": (c_int32, [_P, ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_finish_draws": (c_int32, [_P, _P, ctypes.c_int64, POINTER(ctypes.c_void_p), c_int32, c_int32, _P, _P, _P, _P]),
@@ -362,6 +364,24 @@ def ref_draws(gen, shape, n_neg, B, variant, dev):
         _check(lib.stego_ref_draws(seed & (2 ** 64 - 1), off, variant, c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
     gen.set_offset(off + adv)
     return c1, c2, perms
+
+
+def ref_dropout_masks(gen, n_masks, numel, keep_prob, variant, dev):
+    """n_masks x `x.new_empty(B, C, 1, 1).bernoulli_(keep_prob).div_(keep_prob)` (what nn.Dropout2d draws per call) from ONE launch,
+    bit for bit, advancing `gen` like the torch calls -> float32 [n_masks, numel].  Needs torchglue() (the generator's Philox state)."""
+    lib = load()
+    ext = torchglue()
+    if ext is None:
+        raise RuntimeError("ref_dropout_masks needs the torch glue extension")
+    out = torch.empty(n_masks, numel, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        adv = int(lib.stego_ref_dropout_masks_advance(numel, n_masks, variant))
+        captured, seed, off, intra = ext.philox_state(gen, adv)
+        if captured:
+            _check(lib.stego_ref_dropout_masks(0, intra, seed, off, variant, n_masks, numel, float(keep_prob), _ptr(out), _stream()))
+        else:
+            _check(lib.stego_ref_dropout_masks(seed, off, None, None, variant, n_masks, numel, float(keep_prob), _ptr(out), _stream()))
+    return out
 
 
 def fast_draws(seed, shape, n_neg, B):

@@ -6,6 +6,7 @@
 #include "../../include/stego_corr.h"
 #include "corr_common.h"
 #include "host_util.h"
+#include "../../include/stego_head.h"
 
 namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
@@ -22,6 +23,10 @@ hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, 
                             int variant, long long n_coord, int n_neg, int B,
                             int cus, int threads_per_cu, float* c1, float* c2, long long* perms, hipStream_t stream);
 unsigned long long ref_draws_advance(long long n_coord, int n_neg, int B, int variant, int cus, int threads_per_cu);
+unsigned long long ref_masks_advance(long long numel, int n_masks, int variant, int cus, int threads_per_cu);
+hipError_t launch_ref_masks(unsigned long long seed, unsigned long long offset, const long long* seed_ptr, const long long* offset_ptr,
+                            int variant, int n_masks, long long numel, float keep_prob, int cus, int threads_per_cu, float* out,
+                            hipStream_t stream);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
@@ -385,6 +390,24 @@ int stego_ref_draws_indirect(const int64_t* seed_ptr, const int64_t* offset_ptr,
                                    reinterpret_cast<const long long*>(offset_ptr), variant, n_coord, n_neg, B, device_cu_count(),
                                    device_threads_per_cu(), coords1, coords2, reinterpret_cast<long long*>(perms),
                                    static_cast<hipStream_t>(stream)));
+}
+
+int stego_ref_dropout_masks(uint64_t seed, uint64_t offset, const int64_t* seed_ptr, const int64_t* offset_ptr, int32_t variant,
+                            int32_t n_masks, int64_t numel, float keep_prob, float* masks, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_masks < 0 || n_masks > 16 || numel < 0 || variant < 0 || variant > 3 || (offset & 3) || !(keep_prob > 0.f) || keep_prob > 1.f)
+        return STEGO_ERR_SHAPE;
+    if ((n_masks > 0 && numel > 0 && !masks) || ((seed_ptr == nullptr) != (offset_ptr == nullptr))) return STEGO_ERR_NULL;
+    return hip_rc(launch_ref_masks(seed, offset, reinterpret_cast<const long long*>(seed_ptr), reinterpret_cast<const long long*>(offset_ptr),
+                                   variant, n_masks, numel, keep_prob, device_cu_count(), device_threads_per_cu(), masks,
+                                   static_cast<hipStream_t>(stream)));
+}
+
+uint64_t stego_ref_dropout_masks_advance(int64_t numel, int32_t n_masks, int32_t variant)
+{
+    if (numel < 0 || n_masks < 0) return 0;
+    return ref_masks_advance(numel, n_masks, variant, device_cu_count(), device_threads_per_cu());
 }
 
 uint64_t stego_ref_draws_advance(int64_t n_coord, int32_t n_neg, int32_t B, int32_t variant)

@@ -331,4 +331,56 @@ hipError_t launch_ref_draws(unsigned long long seed, unsigned long long offset, 
     return hipGetLastError();
 }
 
+// ---- nn.Dropout2d's channel masks as ATen draws them (feature dropout: noise = x.new_empty(B, C, 1, 1).bernoulli_(1 - p).div_(1 - p)):
+// bernoulli_(q) = (curand_uniform4 value < q) per element through the same distribution template as torch.rand (so the same
+// grid policy / counter layout as above, one Philox block per 4 elements and visit), WITHOUT torch.rand's fold of 1.0 to 0.0;
+// div_(q) multiplies by the float 1 / q.  n_masks consecutive calls, each advancing the generator by the policy's amount.
+struct RefMaskParams {
+    float* out;                        // [n_masks][numel]
+    long long numel;
+    unsigned long long seed, offset;
+    const long long* seed_ptr;
+    const long long* offset_ptr;
+    int n_masks, grid, fma;
+    unsigned long long adv;            // generator advance per mask
+    float q, inv_q;
+};
+
+__global__ void __launch_bounds__(256) ref_masks_kernel(const RefMaskParams prm)
+{
+    unsigned long long seed = prm.seed, offset = prm.offset;
+    if (prm.seed_ptr) {
+        seed = (unsigned long long)*prm.seed_ptr;
+        offset += (unsigned long long)*prm.offset_ptr;
+    }
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= prm.numel) return;
+    const int mk = blockIdx.y;
+    const unsigned x = (unsigned)dist_value<4>(seed, offset + (unsigned long long)mk * prm.adv, i, 256ll * prm.grid);
+    const float c = 2.3283064e-10f;
+    const float u = prm.fma ? __builtin_fmaf((float)x, c, c) : c + __fmul_rn((float)x, c);
+    prm.out[(size_t)mk * prm.numel + i] = u < prm.q ? prm.inv_q : 0.f;
+}
+
+unsigned long long ref_masks_advance(long long numel, int n_masks, int variant, int cus, int threads_per_cu)
+{
+    int g;
+    unsigned long long a = 0;
+    if (numel > 0) torch_dist_policy(numel, variant, 4, cus, threads_per_cu, &g, &a);
+    return a * (unsigned long long)n_masks;
+}
+
+hipError_t launch_ref_masks(unsigned long long seed, unsigned long long offset, const long long* seed_ptr, const long long* offset_ptr,
+                            int variant, int n_masks, long long numel, float keep_prob, int cus, int threads_per_cu, float* out,
+                            hipStream_t stream)
+{
+    if (n_masks <= 0 || numel <= 0) return hipSuccess;
+    RefMaskParams prm{};
+    prm.out = out; prm.numel = numel; prm.seed = seed; prm.offset = offset; prm.seed_ptr = seed_ptr; prm.offset_ptr = offset_ptr;
+    prm.n_masks = n_masks; prm.fma = (variant >> 1) & 1; prm.q = keep_prob; prm.inv_q = 1.0f / keep_prob;
+    torch_dist_policy(numel, variant, 4, cus, threads_per_cu, &prm.grid, &prm.adv);
+    hipLaunchKernelGGL(ref_masks_kernel, dim3((unsigned)((numel + 255) / 256), n_masks), dim3(256), 0, stream, prm);
+    return hipGetLastError();
+}
+
 }  // namespace stego

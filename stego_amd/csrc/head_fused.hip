@@ -488,6 +488,9 @@ struct HeadWgradParams {
     int M, N, Kc, splits;
 };
 
+// (A 128 x 384 variant of this kernel - the G columns of a tile staged once for all channels, 12 waves, 462 -> 308 MB of L2-level
+// traffic for the C x C gradient - was built and measured: 155 us against 142 us for the 3 x 3 tiles of 128 x 128 at two workgroups
+// per CU.  Like the GEMMs, this kernel runs at the ~11 bytes per cycle a CU is delivered under full-chip load, not at its MFMA rate.)
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // two stages of [G 16 KB][X 16 KB] (double buffer)
@@ -597,30 +600,36 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const HeadWgradParams p
 }
 
 // dW[i] = sum_s part[s][i]  (fixed order);  db[n] = sum_s part_bias[s][n] (optionally into two outputs: b1 and b22 share their gradient).
-// numel is a multiple of 4 (Kc is a multiple of 32): a thread sums four consecutive outputs, 16 partial tiles in flight.
+// numel is a multiple of 4 (Kc is a multiple of 32).  A workgroup owns 64 runs of four consecutive outputs; its four waves sum every
+// fourth partial tile each (loads of 16 tiles in flight per lane), then wave 0 adds the four wave sums in wave order: the order of the
+// additions is fixed, the result bitwise repeatable.  (One thread per run summing all tiles alone: 144 workgroups, 50 MB in 52 us.)
 __global__ void __launch_bounds__(256) head_reduce_kernel(const float* part, int splits, long long numel, float* dW,
                                                           const float* part_bias, int N, float* db, float* db_b)
 {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i < numel) {
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 16 <= splits; k += 16) {
-            f32x4 v[16];
+    __shared__ f32x4 wsum[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + lane) * 4;
+    const bool ok = i < numel;
+    const long long ic = ok ? i : 0;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = wave;
+    for (; k + 4 * 15 < splits; k += 4 * 16) {
+        f32x4 v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(part + (size_t)(k + j) * numel + i);
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(part + (size_t)(k + 4 * j) * numel + ic);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s += v[j];
-        }
-        for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * numel + i);
-        *reinterpret_cast<f32x4*>(dW + i) = s;
+        for (int j = 0; j < 16; ++j) s += v[j];
     }
+    for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * numel + ic);
+    wsum[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && ok) *reinterpret_cast<f32x4*>(dW + i) = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (part_bias && t < N) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part_bias[(size_t)k * N + t];
-        if (db) db[t] = s;
-        if (db_b) db_b[t] = s;
+        float sb = 0.f;
+        for (int kk = 0; kk < splits; ++kk) sb += part_bias[(size_t)kk * N + t];
+        if (db) db[t] = sb;
+        if (db_b) db_b[t] = sb;
     }
 }
 
@@ -638,11 +647,14 @@ static int head_check(const StegoHeadDesc* d)
 
 static size_t round256(size_t v) { return (v + 255) / 256 * 256; }
 
+// channel blocks per workgroup of the weight-gradient GEMM of an N-column upstream: the wide tile for the C x C gradient
 static int wgrad_splits(const StegoHeadDesc* d, int N)
 {
     const int tiles = ((N + HT - 1) / HT) * ((d->C + HT - 1) / HT);
     const long long stages = ((long long)d->B * d->HW + HKS - 1) / HKS;
-    long long s = (2 * 256 + tiles - 1) / tiles;                     // ~two workgroups per compute unit (one per CU: partial tiles 50 -> 25 MB, reduction 28 -> 16 us, but the GEMMs 81 -> 100 us: measured, not kept)
+    // ~two workgroups per compute unit (one per CU: partial tiles 50 -> 25 MB, reduction 28 -> 16 us, but the GEMMs 81 -> 100 us:
+    // measured, not kept)
+    long long s = (2 * 256 + tiles - 1) / tiles;
     if (s > stages) s = stages;
     return s < 1 ? 1 : (int)s;
 }
@@ -845,7 +857,7 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
         er = hipGetLastError();
         if (er != hipSuccess) return er;
         const long long numel = (long long)N * C;
-        hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)std::max<long long>((numel / 4 + 255) / 256, (N + 255) / 256)), dim3(256), 0, s, part, splits, numel, dW,
+        hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)std::max<long long>((numel / 4 + 63) / 64, (N + 255) / 256)), dim3(256), 0, s, part, splits, numel, dW,
                            pbias, N, db, db_b);
         return hipGetLastError();
     };

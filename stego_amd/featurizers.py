@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dino_vit, vit_native
+from . import capi, dino_vit, vit_native
 
 
 class LambdaLayer(nn.Module):
@@ -84,6 +84,43 @@ class _TokenLinear(torch.autograd.Function):
         gw = torch.bmm(g3.transpose(1, 2), x.reshape(B, -1, x.shape[-1])).sum(0) if ctx.needs_input_grad[1] else None
         gb = g3.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+# (device index, B * C, n, keep probability) -> variant of stego_ref_dropout_masks that reproduces the installed torch, or -1
+_MASK_VARIANTS = {}
+
+
+def _mask_variant(net, x, n, q):
+    """Which variant of the one-launch Dropout2d masks is bit-identical to THIS torch build's bernoulli_ / div_ for these sizes: found by
+    running both from the same generator state once (the generator is left where it was); -1 = none.  Under stream capture (where the
+    check cannot run) only a cached answer is used."""
+    from .modules import _device_generator
+    dev = x.device
+    key = (dev.index, x.shape[0] * x.shape[1], int(n), float(q))
+    v = _MASK_VARIANTS.get(key)
+    if v is not None:
+        return v
+    if torch.cuda.is_current_stream_capturing():
+        return -1
+    v = -1
+    try:
+        gen = _device_generator(dev)
+        state = gen.get_state()
+        try:
+            want = torch.stack([net._feature_noise(x).view(-1) for _ in range(n)])
+            off = gen.get_offset()
+            for cand in range(4):
+                gen.set_state(state)
+                got = capi.ref_dropout_masks(gen, n, key[1], q, cand, dev)
+                if gen.get_offset() == off and torch.equal(got, want):
+                    v = cand
+                    break
+        finally:
+            gen.set_state(state)
+    except (RuntimeError, AttributeError):
+        v = -1
+    _MASK_VARIANTS[key] = v
+    return v
 
 
 class _NativeHeadFunction(torch.autograd.Function):
@@ -253,11 +290,13 @@ class DinoFeaturizer(nn.Module):
         nonlinear = self.proj_type == "nonlinear"
         m1 = m2 = m3 = None
         if self.training:
-            m1 = self._feature_noise(image_feat).view(B, C)
+            n_draw = 1 + int(nonlinear) + int(bool(self.cfg.dropout))
+            noise = self._feature_noises(image_feat, n_draw)           # the reference's draws, in its order, one launch when possible
+            m1 = noise[0]
             if nonlinear:
-                m2 = self._feature_noise(image_feat).view(B, C)
+                m2 = noise[1]
             if self.cfg.dropout:
-                m3 = self._feature_noise(image_feat).view(B, C)
+                m3 = noise[n_draw - 1]
             if m2 is None:
                 m2 = m1                                                 # (unused by a linear head; keeps the argument list dense)
             if m3 is None:
@@ -274,6 +313,20 @@ class DinoFeaturizer(nn.Module):
         code = code.view(B, fh, fw, self.dim).permute(0, 3, 1, 2)
         feats = feats.view(B, fh, fw, C).permute(0, 3, 1, 2) if feats is not None else image_feat
         return feats, code
+
+    def _feature_noises(self, x, n):
+        """n consecutive Dropout2d channel masks [B, C] for x: the torch calls (_feature_noise), or - on a HIP device with the torch glue
+        extension - the same numbers from ONE launch (stego_ref_dropout_masks: 3 masks are 9 tiny torch kernels otherwise), the generator
+        advanced identically.  Checked against the real torch calls once per process and size (_mask_variant); any mismatch, a missing
+        extension or cfg.one_launch_draws = False keep the torch calls."""
+        B, C = x.shape[0], x.shape[1]
+        q = 1.0 - float(self.dropout.p)
+        if x.is_cuda and 0.0 < q <= 1.0 and getattr(self.cfg, "one_launch_draws", True) and capi.torchglue() is not None:
+            v = _mask_variant(self, x, n, q)
+            if v >= 0:
+                from .modules import _device_generator
+                return capi.ref_dropout_masks(_device_generator(x.device), n, B * C, q, v, x.device)
+        return [self._feature_noise(x).view(B, C) for _ in range(n)]
 
     def _feature_noise(self, x):
         """The channel mask of nn.Dropout2d, drawn exactly as ATen's feature dropout draws it (a [B,C,1,1] tensor filled

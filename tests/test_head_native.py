@@ -122,3 +122,48 @@ def test_head_argument_checks_need_no_launch():
     d = capi.StegoHeadDesc(2, 49, 384, 70, 1, 384, 50 * 384)
     assert lib.stego_head_fwd_workspace_bytes(ctypes.byref(d)) >= 2 * 49 * 384 * 4
     assert lib.stego_head_fwd(ctypes.byref(d), *([None] * 14), 0, None) == 1   # STEGO_ERR_NULL
+
+
+@pytest.mark.parametrize("B,C,n", [(64, 384, 3), (32, 384, 3), (4, 768, 2), (3, 96, 1)])
+def test_one_launch_dropout_masks_are_the_torch_generator_s_bernoulli_draws(B, C, n):
+    """stego_ref_dropout_masks against nn.Dropout2d's own draws (x.new_empty(B, C, 1, 1).bernoulli_(1 - p).div_(1 - p), n calls) from the
+    same generator state over many seeds: every mask value equal, the generator left at the same offset - eagerly and replayed from a
+    HIP graph (the captured launch reads the generator's graph-safe state)."""
+    from stego_amd import capi, featurizers as FZ
+    from stego_amd.modules import _device_generator
+    net, cfg = _featurizer("vit_small", 70, "nonlinear", True)
+    dev = torch.device(DEV)
+    x = torch.zeros(B, C, 2, 2, device=dev)
+    q = 1.0 - float(net.dropout.p)
+    assert capi.torchglue() is not None
+    v = FZ._mask_variant(net, x, n, q)
+    assert v >= 0, "no variant of stego_ref_dropout_masks reproduces this torch build: DinoFeaturizer would keep the torch calls"
+    gen = _device_generator(dev)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for seed in range(300):
+        torch.manual_seed(4000 + seed)
+        if seed % 3 == 1:
+            torch.rand(5, device=dev)
+        st = gen.get_state()
+        want = torch.stack([net._feature_noise(x).view(-1) for _ in range(n)])
+        off = gen.get_offset()
+        gen.set_state(st)
+        got = capi.ref_dropout_masks(gen, n, B * C, q, v, dev)
+        assert gen.get_offset() == off
+        bad += (got != want).sum()
+    assert int(bad) == 0
+    assert 0.05 < float((want == 0).float().mean()) < 0.16          # (p = 0.1 of the channels dropped)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = capi.ref_dropout_masks(gen, n, B * C, q, v, dev)
+    for seed in range(10):
+        torch.manual_seed(7000 + seed)
+        st = gen.get_state()
+        want = [torch.stack([net._feature_noise(x).view(-1) for _ in range(n)]) for _ in range(2)]
+        off = gen.get_offset()
+        gen.set_state(st)
+        for k in range(2):
+            g.replay()
+            assert torch.equal(got, want[k])
+        assert gen.get_offset() == off
