@@ -35,6 +35,9 @@ typedef struct StegoHeadDesc {
     int32_t nonlinear;    /* cfg.projection_type == "nonlinear": cluster2 exists (modules.py:74-78)          */
     int64_t tok_stride;   /* elements between consecutive tokens of an image (C for the backbone's output)   */
     int64_t img_stride;   /* elements between images ((1 + HW) * C: the class token is skipped by the caller) */
+    const uint32_t* tokens_amax;   /* ABI 4, optional: device word holding the float bits of max |tokens| over exactly the elements the
+                           * forward reads (stego_tokens_from_cache writes it while it produces the tokens); NULL = the forward makes its
+                           * own pass over the tokens for it (77 MB at 2B = 64) */
 } StegoHeadDesc;
 
 /* Forward.
@@ -66,6 +69,13 @@ size_t stego_head_bwd_workspace_bytes(const StegoHeadDesc* desc);
 int stego_head_bwd(const StegoHeadDesc* desc, const float* tokens, const float* mask1, const float* mask2, const float* saved_h,
                    const float* w22, const float* d_code, float* dw1, float* db1, float* dw21, float* db21, float* dw22,
                    float* db22, void* workspace, size_t workspace_bytes, stego_stream_t stream);
+
+/* Tokens of a cached backbone (stego_amd TokenCache: the frozen backbone's output for a fixed-crop dataset, kept in HBM as fp16) for
+ * the dataset items `index`: out[i] = float(table[index[i]]), [n][ntok][D] dense, in one pass that also leaves the largest magnitude
+ * of the rows >= skip_rows of every item (skip_rows = 1: the class token, which the head does not read) in *amax_bits - the word
+ * StegoHeadDesc.tokens_amax takes.  D a multiple of 8; amax_bits may be NULL. */
+int stego_tokens_from_cache(const void* table_f16, const int64_t* index, int32_t n, int32_t ntok, int32_t D, int32_t skip_rows,
+                            float* out, uint32_t* amax_bits, stego_stream_t stream);
 
 /* The dropout masks themselves, as torch draws them: nn.Dropout2d (modules.py:33, :109-114) = F.dropout2d -> ATen feature dropout:
  *     noise = x.new_empty(B, C, 1, 1).bernoulli_(1 - p).div_(1 - p)

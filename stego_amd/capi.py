@@ -12,7 +12,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_SHARED_DEVICE = 1          # StegoCorrDesc.flags
 PREC_F32 = 0
 PREC_F16X3 = 1
@@ -41,7 +41,7 @@ class StegoVitDesc(Structure):
 class StegoHeadDesc(Structure):
     """include/stego_head.h"""
     _fields_ = [("B", c_int32), ("HW", c_int32), ("C", c_int32), ("K", c_int32), ("nonlinear", c_int32),
-                ("tok_stride", c_int64), ("img_stride", c_int64)]
+                ("tok_stride", c_int64), ("img_stride", c_int64), ("tokens_amax", c_void_p)]
 
 
 _H = POINTER(StegoHeadDesc)
@@ -78,6 +78,7 @@ SIGNATURES = {
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
     "stego_ref_draws": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_ref_draws_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32, c_int32]),
+    "stego_tokens_from_cache": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "stego_ref_dropout_masks": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, _P, _P, c_int32, c_int32, c_int64, c_float, _P, _P]),
     "stego_ref_dropout_masks_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32]),
     "stego_ref_draws_indirect": (c_int32, [_P, _P, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
@@ -551,10 +552,27 @@ def head_desc(tokens, K, nonlinear):
     if tokens.dim() != 3 or tokens.dtype != torch.float32 or tokens.stride(2) != 1:
         raise RuntimeError("head: expected a float32 [B, HW, C] token tensor with contiguous channels")
     B, HW, C = tokens.shape
-    return StegoHeadDesc(B, HW, C, int(K), 1 if nonlinear else 0, tokens.stride(1), tokens.stride(0) if B > 1 else HW * tokens.stride(1))
+    return StegoHeadDesc(B, HW, C, int(K), 1 if nonlinear else 0, tokens.stride(1), tokens.stride(0) if B > 1 else HW * tokens.stride(1), None)
 
 
-def head_fwd(tokens, masks, w1, b1, w21, b21, w22, b22, need_grad, want_feats):
+def tokens_from_cache(table, index, skip_rows=1):
+    """stego_tokens_from_cache: float32 [n, ntok, D] rows `index` of the fp16 token table + a device word (int32 [1]) with the float bits
+    of the largest magnitude of the rows >= skip_rows (what StegoHeadDesc.tokens_amax takes)."""
+    _require_dev(table, index)
+    if table.dtype != torch.float16 or table.dim() != 3 or not table.is_contiguous():
+        raise RuntimeError("tokens_from_cache: expected a contiguous float16 [items, ntok, D] table")
+    lib = load()
+    dev = table.device
+    index = _dense(index, torch.int64)
+    n, ntok, D = int(index.numel()), table.shape[1], table.shape[2]
+    out = torch.empty(n, ntok, D, dtype=torch.float32, device=dev)
+    amax = torch.empty(1, dtype=torch.int32, device=dev)
+    with _on_device(dev):
+        _check(lib.stego_tokens_from_cache(_ptr(table), _ptr(index), n, ntok, D, int(skip_rows), _ptr(out), _ptr(amax), _stream()))
+    return out, amax
+
+
+def head_fwd(tokens, masks, w1, b1, w21, b21, w22, b22, need_grad, want_feats, tokens_amax=None):
     """stego_head_fwd.  masks = (m1, m2, m3) fp32 [B, C] each or None.  Returns (code [B, HW, K], feats_out [B, HW, C] or None,
     saved_h or None)."""
     _require_dev(tokens, w1, b1)
@@ -562,6 +580,8 @@ def head_fwd(tokens, masks, w1, b1, w21, b21, w22, b22, need_grad, want_feats):
     dev = tokens.device
     nonlinear = w21 is not None
     d = head_desc(tokens, w1.shape[0], nonlinear)
+    if tokens_amax is not None:                  # (the magnitude word of exactly these tokens: tokens_from_cache)
+        d.tokens_amax = tokens_amax.data_ptr()
     B, HW, C, K = d.B, d.HW, d.C, d.K
     code = torch.empty(B, HW, K, dtype=torch.float32, device=dev)
     feats = torch.empty(B, HW, C, dtype=torch.float32, device=dev) if want_feats else None

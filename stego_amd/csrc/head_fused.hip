@@ -193,7 +193,8 @@ struct HeadPrepParams { HeadPrepJob job[4]; };
 __global__ void __launch_bounds__(256) head_consts_kernel(unsigned* words, const unsigned* copy_from, int n_copy, float* zeros, float* ones, int C)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < HS_WORDS) words[i] = (copy_from && i < n_copy) ? copy_from[i] : 0u;
+    // (copy_from with n_copy = -1: only word 0 - the tokens' magnitude, handed in by the caller - is copied)
+    if (i < HS_WORDS) words[i] = (copy_from && (n_copy < 0 ? i == 0 : i < n_copy)) ? copy_from[i] : 0u;
     if (i < C) {
         if (zeros) zeros[i] = 0.f;
         ones[i] = 1.f;
@@ -633,6 +634,45 @@ __global__ void __launch_bounds__(256) head_reduce_kernel(const float* part, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------ cached tokens
+// out[i][t][:] = float(table[index[i]][t][:]); a thread converts 8 halves (16 bytes in, 32 out); the largest magnitude of the rows
+// t >= skip_rows goes to *amax (one conditional atomic per workgroup)
+__global__ void __launch_bounds__(256) head_tokens_from_cache_kernel(const half_t* table, const long long* index, int n, int ntok, int D,
+                                                                     int skip_rows, float* out, unsigned* amax)
+{
+    __shared__ float red[4];
+    const int d8 = D >> 3;
+    const long long per_item = (long long)ntok * d8, total = (long long)n * per_item;
+    const long long step = (long long)gridDim.x * 256;
+    float mx = 0.f;
+    for (long long u0 = (long long)blockIdx.x * 256 + threadIdx.x; u0 < total; u0 += 4 * step) {
+        f16x8 h[4];
+        long long u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // four 16-byte loads in flight per thread (clamped: the tail re-reads the last unit)
+            u[q] = min(u0 + q * step, total - 1);
+            const int i = (int)(u[q] / per_item);
+            h[q] = *reinterpret_cast<const f16x8*>(table + ((size_t)index[i] * per_item + (u[q] - (long long)i * per_item)) * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (u0 + q * step >= total) break;
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = (float)h[q][e]; b[e] = (float)h[q][4 + e]; }
+            float* o = out + (size_t)u[q] * 8;
+            *reinterpret_cast<f32x4*>(o) = a;
+            *reinterpret_cast<f32x4*>(o + 4) = b;
+            const long long r = u[q] % per_item;                     // unit inside the item: row t = r / d8
+            if (r >= (long long)skip_rows * d8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(a[e]), fabsf(b[e])));
+            }
+        }
+    }
+    if (amax) head_publish_max(mx, amax, red);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int head_check(const StegoHeadDesc* d)
 {
@@ -711,6 +751,25 @@ extern "C" {
 // operand-scale words (bits of the largest magnitude, see head_scale): the forward fills 0-4 and hands them to the backward
 enum { HS_X = 0, HS_W1, HS_W21, HS_W22, HS_H, HS_G, HS_DH, HS_COUNT = HS_WORDS };
 
+int stego_tokens_from_cache(const void* table_f16, const int64_t* index, int32_t n, int32_t ntok, int32_t D, int32_t skip_rows,
+                            float* out, uint32_t* amax_bits, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (n < 0 || ntok <= 0 || D <= 0 || (D & 7) || skip_rows < 0) return STEGO_ERR_SHAPE;
+    if (n == 0) return STEGO_OK;
+    if (!table_f16 || !index || !out) return STEGO_ERR_NULL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (amax_bits && (e = hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), s)) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    const long long units = (long long)n * ntok * (D >> 3);
+    long long blocks = (units + 256 * 4 - 1) / (256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(head_tokens_from_cache_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const half_t*>(table_f16),
+                       reinterpret_cast<const long long*>(index), n, ntok, D, skip_rows, out, reinterpret_cast<unsigned*>(amax_bits));
+    if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
+    return STEGO_OK;
+}
+
 size_t stego_head_fwd_workspace_bytes(const StegoHeadDesc* d)
 {
     if (head_check(d) != STEGO_OK) return 0;
@@ -758,9 +817,11 @@ int stego_head_fwd(const StegoHeadDesc* d, const float* tokens, const float* mas
     const size_t zbytes = round256((size_t)d->C * sizeof(float));
     ws += 256 + zbytes;
     float* ones = reinterpret_cast<float*>(ws); ws += zbytes;
-    hipLaunchKernelGGL(head_consts_kernel, dim3((d->C + 255) / 256), dim3(256), 0, s, sc, (const unsigned*)nullptr, 0, zeros, ones, d->C);
+    static_assert(HS_X == 0, "head_consts_kernel copies word 0");
+    hipLaunchKernelGGL(head_consts_kernel, dim3((d->C + 255) / 256), dim3(256), 0, s, sc, reinterpret_cast<const unsigned*>(d->tokens_amax),
+                       -1, zeros, ones, d->C);
     if ((e = hipGetLastError()) != hipSuccess) return STEGO_ERR_HIP + (int)e;
-    {
+    if (!d->tokens_amax) {
         int blocks = (int)(((long long)M * d->C / 4 + 256 * 4 - 1) / (256 * 4));
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
         hipLaunchKernelGGL(head_absmax_kernel, dim3(blocks), dim3(256), 0, s, tokens, (long long)d->img_stride, (long long)d->tok_stride,
@@ -834,6 +895,11 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
         auto absmax = [&](const float* x, long long img, long long rowst, int rpi, long long rows, int cols, int which) -> hipError_t {
             int blocks = (int)((rows * cols / 4 + 256 * 4 - 1) / (256 * 4));
             blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+            if (rowst == cols && img == (long long)rpi * cols && ((rows * cols) & 3) == 0) {
+                // a dense matrix is one flat vector: 16-byte units whatever the row length (the K = 70 upstream took the scalar path)
+                const long long units = rows * cols / 4;
+                rows = units; rpi = (int)std::min<long long>(units, 1ll << 30); cols = 4; rowst = 4; img = (long long)rpi * 4;
+            }
             hipLaunchKernelGGL(head_absmax_kernel, dim3(blocks), dim3(256), 0, s, x, img, rowst, rpi, rows, cols, scl + which);
             return hipGetLastError();
         };

@@ -42,6 +42,7 @@ class TokenCache:
         self.filled = torch.zeros(n_items, dtype=torch.bool, device=device)
         self.complete = False
         self.misses = 0
+        self.last = None              # (tokens fp32, magnitude word) of the latest fetch on a HIP device
 
     def clear(self):
         """Forget everything (the backbone's weights changed)."""
@@ -60,6 +61,12 @@ class TokenCache:
                 self.filled[rows] = True
                 self.misses += int(missing.sum())
             self.complete = bool(self.filled.all())
+        if self.tokens.is_cuda and self.tokens.dtype == torch.float16:
+            # one pass: rows -> fp32 + the largest magnitude of the patch tokens (what the native head prescales by: it would read all
+            # tokens again for it)
+            out, amax = capi.tokens_from_cache(self.tokens, index, skip_rows=1)
+            self.last = (out, amax)
+            return out
         return self.tokens[index].float()
 
 
@@ -129,13 +136,13 @@ class _NativeHeadFunction(torch.autograd.Function):
     map written on the way; backward = the six parameter gradients (the backbone is frozen: the tokens get none)."""
 
     @staticmethod
-    def forward(ctx, tokens, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats):
+    def forward(ctx, tokens, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax=None):
         from . import capi
         need_grad = any(t is not None and t.requires_grad for t in (w1, b1, w21, b21, w22, b22))
         masks = (m1, m2, m3) if m1 is not None else None
         det = lambda t: None if t is None else t.detach()
         code, feats, saved_h = capi.head_fwd(tokens.detach(), masks, det(w1), det(b1), det(w21), det(b21), det(w22), det(b22),
-                                             need_grad, want_feats)
+                                             need_grad, want_feats, tokens_amax)
         ctx.set_materialize_grads(False)
         ctx.K = w1.shape[0]
         ctx.nonlinear = w21 is not None
@@ -150,12 +157,12 @@ class _NativeHeadFunction(torch.autograd.Function):
     def backward(ctx, g_code, _g_feats):
         from . import capi
         if g_code is None:
-            return (None,) * 11
+            return (None,) * 12
         tokens, m1, m2, saved_h, w22 = ctx.saved_tensors
         masks = (m1, m2, None) if m1 is not None else None
         dw1, db1, dw21, db21, dw22, db22 = capi.head_bwd(tokens, masks, saved_h if ctx.nonlinear else None,
                                                           w22.detach() if w22 is not None else None, g_code, ctx.K)
-        return None, None, None, None, dw1, db1, dw21, db21, dw22, db22, None
+        return None, None, None, None, dw1, db1, dw21, db21, dw22, db22, None, None
 
 
 class DinoFeaturizer(nn.Module):
@@ -266,7 +273,11 @@ class DinoFeaturizer(nn.Module):
 
         if self.proj_type is not None:
             if self._native_head_ok(image_feat):
-                return self._head_native(image_feat)
+                amax = None
+                if cache_index is not None and self.token_cache is not None and self.token_cache.last is not None and \
+                        self.token_cache.last[0] is feat:
+                    amax = self.token_cache.last[1]
+                return self._head_native(image_feat, amax)
             code = self._head(image_feat)
         else:
             code = image_feat
@@ -280,7 +291,7 @@ class DinoFeaturizer(nn.Module):
                 and image_feat.stride(3) % 4 == 0 and image_feat.stride(0) % 4 == 0
                 and image_feat.stride(2) == image_feat.shape[3] * image_feat.stride(3))
 
-    def _head_native(self, image_feat):
+    def _head_native(self, image_feat, tokens_amax=None):
         """forward()'s tail on the native head: (feats, code) exactly as modules.py:108-116 returns them.  The three Dropout2d draws are
         made with the torch calls F.dropout2d makes, in the reference's order (cluster1's input :109, cluster2's :111, the returned
         map :114), so a seeded run consumes the generator like the reference; the masks go to the kernel as [B, C] scale vectors."""
@@ -309,7 +320,7 @@ class DinoFeaturizer(nn.Module):
             c20, c22 = self.cluster2[0], self.cluster2[2]
             w21, b21 = c20.weight.view(c20.out_channels, c20.in_channels), c20.bias
             w22, b22 = c22.weight.view(c22.out_channels, c22.in_channels), c22.bias
-        code, feats = _NativeHeadFunction.apply(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats)
+        code, feats = _NativeHeadFunction.apply(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax)
         code = code.view(B, fh, fw, self.dim).permute(0, 3, 1, 2)
         feats = feats.view(B, fh, fw, C).permute(0, 3, 1, 2) if feats is not None else image_feat
         return feats, code

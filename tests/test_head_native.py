@@ -167,3 +167,25 @@ def test_one_launch_dropout_masks_are_the_torch_generator_s_bernoulli_draws(B, C
             g.replay()
             assert torch.equal(got, want[k])
         assert gen.get_offset() == off
+
+
+def test_cached_tokens_arrive_converted_with_their_magnitude_word():
+    """stego_tokens_from_cache (TokenCache.fetch on a HIP device): rows of the fp16 table as fp32 + the largest magnitude of the patch
+    tokens (class token skipped) in one pass; the head run with that word (StegoHeadDesc.tokens_amax) is bitwise the head that scans
+    the tokens itself."""
+    from stego_amd import capi
+    dev = torch.device(DEV)
+    g = torch.Generator(device=dev).manual_seed(3)
+    table = (torch.randn(10, 1 + 49, 384, device=dev, generator=g) * 3).half()
+    table[:, 0, :] *= 50                                   # a class token larger than every patch token
+    index = torch.tensor([7, 2, 2, 9], device=dev)
+    out, amax = capi.tokens_from_cache(table, index, skip_rows=1)
+    assert torch.equal(out, table[index].float())
+    assert float(amax.view(torch.float32)) == float(table[index][:, 1:, :].float().abs().max())
+    net, cfg = _featurizer("vit_small", 70, "nonlinear", True)
+    net.eval()
+    image_feat = out[:, 1:, :].reshape(4, 7, 7, 384).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        f0, c0 = net._head_native(image_feat)
+        f1, c1 = net._head_native(image_feat, amax)
+    assert torch.equal(c0, c1) and torch.equal(f0, f1)

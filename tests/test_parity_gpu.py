@@ -56,7 +56,7 @@ def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None, preci
 def test_library_loaded_is_the_in_tree_hip_extension():
     lib = capi.load()
     assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
-    assert lib.stego_abi_version() == 3
+    assert lib.stego_abi_version() == 4
     assert torch.cuda.is_available()
 
 

@@ -22,7 +22,7 @@ def main():
         q = ("select s.kernel_name, count(*), avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3,"
              " sum(d.end-d.start)/1e6, max(s.arch_vgpr_count), max(s.accum_vgpr_count), max(s.sgpr_count),"
              " max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)"
-             " from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by 6 desc limit 14" % (kd, ks))
+             " from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by 6 desc limit 32" % (kd, ks))
         print("%-64s %6s %10s %10s %10s %10s %5s %5s %5s %7s %8s %5s" %
               ("kernel", "calls", "avg_us", "min_us", "max_us", "total_ms", "vgpr", "agpr", "sgpr", "lds", "grid", "wg"))
         for r in cur.execute(q):
