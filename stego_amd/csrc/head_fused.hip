@@ -3,18 +3,25 @@
 // Reference: src/modules.py:108-116 (Dropout2d x 3, cluster1 = Conv2d(C, K, 1x1), cluster2 = Conv2d(C, C) -> ReLU -> Conv2d(C, K)) and
 // what autograd derives for the six parameters.  On the channels-last token matrix the 1x1 convolutions are GEMMs:
 //     code = (X * m1) W1^T + b1 + relu((X * m2) W21^T + b21) W22^T + b22          feats_out = X * m3
-// with m* the per-(image, channel) scales of nn.Dropout2d.  Two kernels do all of it:
-//   * head_gemm_kernel  C[M, N] = epilogue(A'[M, K] B[N, K]^T): 128 x 128 tile per workgroup, 4 waves (one 64 x 64 quadrant each,
-//     v_mfma_f32_32x32x16_f16), operands read as fp32, scaled by the dropout mask of their image (A side), split into fp16 hi + lo and
-//     staged in LDS in 32-channel stages (hi*hi + hi*lo + lo*hi, fp32 accumulate: the fp32-class scheme of the loss kernels);
-//     epilogues: + bias (+ bias), + bias -> ReLU, += (accumulate into C), * 1[aux > 0]; the first N tile of the cluster1 GEMM also
-//     writes feats_out = X * m3 while it has X in registers (the dropped-out feature map of modules.py:116);
-//   * head_wgrad_kernel dW[N, C] = sum_t G'[t, N]^T X'[t, C] over a range of tokens (split over workgroups; partial tiles + a
+// with m* the per-(image, channel) scales of nn.Dropout2d.  Two kernels do the arithmetic:
+//   * head_gemm_kernel<KVEC, EPI, NW>  C[M, N] = epilogue(A'[M, K] B[N, K]^T): a 128 x 128 NW tile per workgroup, 4 NW waves (64 x 64
+//     each, v_mfma_f32_32x32x16_f16).  A (activations) is read as fp32, scaled by the dropout mask of its image (kept in LDS) and a
+//     power-of-two prescale, split into fp16 hi + lo and staged in LDS in 32-channel stages; B (weights) arrives pre-split - fp16 hi / lo
+//     planes written once per call by head_prep_absmax_kernel / head_prep_split_kernel - so staging it is a copy.  hi*hi + hi*lo + lo*hi,
+//     fp32 accumulate: the fp32-class scheme of the loss kernels.  Stages are double-buffered (one barrier per stage); the token operand
+//     is fetched two stages ahead, the weight units one.  The MFMAs compute TRANSPOSED 32 x 32 blocks (operands swapped), so that a lane
+//     holds runs of four consecutive columns of one output row: the epilogues (+ bias (+ bias), + bias -> ReLU, += C, * 1[aux > 0])
+//     use 16-byte global accesses.  The cluster1 GEMM also writes feats_out = X * m3 from the registers it stages (modules.py:116).
+//   * head_wgrad_kernel  dW[N, C] = sum_t G'[t, N]^T X'[t, C] over a range of tokens (split over workgroups; partial tiles + a
 //     reduction kernel, fixed order: bitwise repeatable): both operands are transposed on their way into LDS (the reduction index -
 //     the token - must be contiguous per MFMA lane), the dropout mask rides on X'; the first channel tile also sums the columns of
 //     G' (the bias gradients).
-// Forward: 3 launches (cluster1; cluster2[0] + ReLU -> H; cluster2[2] accumulated into code).  Backward: dHpre = (G W22) * 1[H > 0],
-// three weight-gradient GEMMs, one reduction.
+// plus small ones: operand magnitudes (head_absmax_kernel; or the producing GEMM's epilogue), the constants of a call (scale words, a
+// row of ones / zeros standing in for absent masks / biases: kernels never test a pointer), the cached-token gather.
+// Forward: cluster1; cluster2[0] + ReLU -> H (NW = 3: the token operand staged once for all 384 outputs); cluster2[2] accumulated into
+// code.  Backward: dHpre = (G W22) * 1[H > 0] (NW = 3), three weight-gradient GEMMs, three reductions.
+// What bounds them: the ~11 bytes per cycle a CU is delivered under full-chip load, L2 hits included - not HBM, not
+// the matrix cores (22 % busy); and what the compiler does to a staging loop unless told otherwise (comments at the loops).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <algorithm>
