@@ -1254,3 +1254,47 @@ def test_cpp_autograd_function_is_the_python_one_bit_for_bit():
     up = torch.ones((), device=dev, requires_grad=True)
     with pytest.raises(RuntimeError, match="differentiable once"):
         torch.autograd.grad(o[0], c, grad_outputs=up, create_graph=True)
+
+
+def test_without_the_torch_glue_extension_the_product_is_the_same(monkeypatch):
+    """A host where stego_amd/lib/_stego_torchglue.so is missing (or does not load against its torch): the Python autograd.Function
+    runs, eager draws come from Generator.get_offset / set_offset, captured steps keep the torch draw calls - outputs, gradients and
+    generator consumption equal the run with the extension, eagerly and replayed from a graph."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 96, dev)
+    assert capi.torchglue() is not None
+
+    def run(captured):
+        cfg = bench.Cfg()
+        loss_fn = M.ContrastiveCorrelationLoss(cfg)
+        c = d["code"].detach().clone().requires_grad_(True)
+        cp = d["code_pos"].detach().clone().requires_grad_(True)
+
+        def step():
+            c.grad = None
+            cp.grad = None
+            o = loss_fn(d["feats"], d["feats_pos"], None, None, c, cp)
+            (0.67 * o[0] + 0.25 * o[2] + 0.63 * o[4].mean()).backward()
+            return o
+        step()                                          # warm-up (workspaces, draw self-checks)
+        torch.cuda.synchronize()
+        if captured:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                o = step()
+            torch.manual_seed(21)
+            g.replay()
+        else:
+            torch.manual_seed(21)
+            o = step()
+        return [t.detach().clone() for t in o] + [c.grad.clone(), cp.grad.clone(), torch.rand(3, device=dev)]
+
+    with_ext = [run(False), run(True)]
+    monkeypatch.setattr(capi, "_torchglue_mod", False)
+    assert capi.torchglue() is None and M._native_autograd(bench.Cfg()) is None
+    without = [run(False), run(True)]
+    for a_run, b_run in zip(with_ext, without):
+        for a, b in zip(a_run, b_run):
+            assert torch.equal(a, b)
