@@ -231,8 +231,22 @@ class _NegLossMap(torch.Tensor):
             m = getattr(args[0], "_stego_mean", None)
             if m is not None:
                 return m
+        # identity conversions keep the shortcut alive: neg.float().mean(), neg.contiguous().mean(), neg.to(torch.float32).mean() and
+        # neg.view(-1) / flatten() / reshape(-1) before .mean() are the same tensor to the reference's reader
+        if func in _NEG_IDENTITY and args and getattr(args[0], "_stego_mean", None) is not None:
+            with torch._C.DisableTorchFunctionSubclass():
+                out = func(*args, **kwargs)
+            if isinstance(out, torch.Tensor) and out.dtype == args[0].dtype and out.numel() == args[0].numel() and \
+                    out.device == args[0].device:
+                out = out.as_subclass(_NegLossMap)
+                out._stego_mean = args[0]._stego_mean
+            return out
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
+
+
+_NEG_IDENTITY = (torch.Tensor.float, torch.Tensor.contiguous, torch.Tensor.to, torch.Tensor.view, torch.Tensor.reshape,
+                 torch.Tensor.flatten, torch.flatten, torch.reshape)
 
 
 class _CorrLossFunction(torch.autograd.Function):

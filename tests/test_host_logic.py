@@ -102,7 +102,15 @@ def test_negative_loss_mean_comes_from_the_kernel(oracle_backed):
     x = out[4]
     assert isinstance(x, torch.Tensor) and x.mean().dim() == 0
     np.testing.assert_allclose(float(x.mean()), float(x.detach().numpy().mean()), rtol=1e-5)
-    assert type(x + 1) is torch.Tensor and type(x.reshape(-1)) is torch.Tensor and type(x.detach()) is torch.Tensor
+    assert type(x + 1) is torch.Tensor and type(x.detach()) is torch.Tensor and type(x.reshape(-1)[:5]) is torch.Tensor
+    # identity conversions (what a reader of the reference may put in front of .mean()) keep the shortcut: same scalar, mean upstream
+    for conv in (lambda y: y.float(), lambda y: y.contiguous(), lambda y: y.reshape(-1), lambda y: y.view(-1), lambda y: y.flatten(),
+                 lambda y: y.to(torch.float32)):
+        _, gc, gpc = run(lambda y: conv(y).mean())
+        assert oracle_backend.last_neg_is_mean is True
+        np.testing.assert_array_equal(gc, g1)
+        np.testing.assert_array_equal(gpc, gp1)
+    assert type(x.double()) is torch.Tensor and x.double().mean().dtype == torch.float64        # (a real conversion: the plain tensor)
     assert type(torch.cat([x, x])) is torch.Tensor and x.mean(dim=0).shape == x.shape[1:]
     assert x.numel() == c.g["neg_inter_loss"].size
 
