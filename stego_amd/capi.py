@@ -146,6 +146,7 @@ def debug_set(name, value):
 def _check(rc):
     if rc != 0:
         _WS_CACHE.clear()            # a kept workspace may hold dirty hand-off words after a failed launch
+        _WS_PINNED.clear()
         msg = load().stego_error_string(rc).decode()
         raise RuntimeError("libstego_corr error %d: %s" % (rc, msg))
 
@@ -229,6 +230,7 @@ def _empty_bytes(n, dev):
 # a few counters in the workspace that must be zero when a launch starts and that every launch leaves zero again.  A kept
 # workspace is prepared once (stego_corr_workspace_prepare) and then costs neither an allocation nor a memset per call.
 _WS_CACHE = {}
+_WS_PINNED = set()        # keys of workspaces first used during a stream capture
 _SIDE_READY = set()
 _WS_CACHE_MAX = 16
 
@@ -236,6 +238,7 @@ _WS_CACHE_MAX = 16
 def reset_workspaces():
     """Forget the kept forward workspaces (call after a launch that failed: its counters may be dirty)."""
     _WS_CACHE.clear()
+    _WS_PINNED.clear()
     if _torchglue_mod:
         _torchglue_mod.reset_workspaces()
 
@@ -247,10 +250,16 @@ def _prepared_ws(lib, desc, dev):
     ws = _WS_CACHE.get(key)
     if ws is None:
         if len(_WS_CACHE) >= _WS_CACHE_MAX:
-            _WS_CACHE.pop(next(iter(_WS_CACHE)))
+            # forget the oldest workspace that no captured graph holds (a graph replays with the pointer it captured: its workspace
+            # must live as long as this cache does)
+            for k in _WS_CACHE:
+                if k not in _WS_PINNED:
+                    _WS_CACHE.pop(k)
+                    break
         ws = _empty_bytes(n, dev)
         with _on_device(dev):
             if torch.cuda.is_current_stream_capturing():
+                _WS_PINNED.add(key)
                 # a workspace first met while a graph is being captured (the capture stream is a stream of its own): prepared NOW on
                 # the library's side stream, not as a memset node that every replay would repeat in front of the forward (launches
                 # leave their counters zero, so once is enough)

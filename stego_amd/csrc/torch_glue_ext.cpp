@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -141,6 +142,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> ref_draws(const at::Generator& ge
 // instead of as a memset node in every replay.
 std::mutex ws_mutex;
 std::map<std::tuple<int, uintptr_t, std::string>, at::Tensor> ws_cache;
+std::set<std::tuple<int, uintptr_t, std::string>> ws_pinned;       // first used during a stream capture: never evicted
 
 at::Tensor prepared_workspace(const StegoCorrDesc& d, const std::string& desc_bytes, const at::Device& dev, hipStream_t stream)
 {
@@ -148,11 +150,16 @@ at::Tensor prepared_workspace(const StegoCorrDesc& d, const std::string& desc_by
     const auto key = std::make_tuple((int)dev.index(), reinterpret_cast<uintptr_t>(stream), desc_bytes);
     auto it = ws_cache.find(key);
     if (it != ws_cache.end()) return it->second;
-    if (ws_cache.size() >= 16) ws_cache.erase(ws_cache.begin());
+    if (ws_cache.size() >= 16) {
+        // forget one workspace that no captured graph holds (a graph replays with the pointer it captured)
+        for (auto e = ws_cache.begin(); e != ws_cache.end(); ++e)
+            if (!ws_pinned.count(e->first)) { ws_cache.erase(e); break; }
+    }
     const size_t n = L.workspace_bytes(&d);
     TORCH_CHECK(n > 0, "stego_corr_workspace_bytes: ", L.error_string(STEGO_ERR_UNSUPPORTED));
     at::Tensor ws = at::empty({(int64_t)n}, at::TensorOptions().dtype(at::kByte).device(dev));
     if (capturing(stream)) {
+        ws_pinned.insert(key);
         check(L.workspace_prepare_now(&d, ws.data_ptr(), n), "stego_corr_workspace_prepare_now");
     } else {
         check(L.workspace_prepare(&d, ws.data_ptr(), n, stream), "stego_corr_workspace_prepare");
@@ -166,6 +173,7 @@ void reset_workspaces()
 {
     std::lock_guard<std::mutex> lock(ws_mutex);
     ws_cache.clear();
+    ws_pinned.clear();
 }
 
 StegoMap as_map(const at::Tensor& t, const char* name)
