@@ -496,6 +496,195 @@ struct HeadWgradParams {
     int M, N, Kc, splits;
 };
 
+// Version 2 of the weight-gradient kernel (the default).  The reduction index of dW = G'^T X' is the token, and an MFMA lane wants 8
+// CONSECUTIVE tokens of one column - the transpose of how the operands lie in memory ([token][column] rows).  Version 1 (below, kept
+// for reference and for token strides that are not 16-byte multiples) transposes at the global load: a thread reads one column of 16
+// tokens with sixteen 4-byte loads (coalesced across the wave, 256 bytes per instruction).  This one loads rows as they lie - a
+// thread reads 16 bytes (four columns of one token): a quarter of the load instructions - stages the fp16 hi / lo planes ROW-major
+// ([token][column], 320-byte rows: 128 columns + padding) and lets the LDS transpose: ds_read_b64_tr_b16 (gfx950) hands lane q of a
+// 16-lane group column q of a [4 tokens][16 columns] block, i.e. four consecutive tokens of one column; two of them are an MFMA
+// fragment.  The padding makes the eight 8-byte row pieces of the two groups of a half-wave hit disjoint banks (row r of group g at
+// word 80 r + 8 g + 2 c).  (Lane p of a group passes the address of token p >> 2, columns 4 (p & 3): measured with
+// tools/ubench/tr_read.hip.)
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr int WG_SR = 320;                       // bytes per token row of a staged plane
+constexpr int WG_PLANE = HKS * WG_SR;            // 10240
+constexpr int WG_SIDE = 2 * WG_PLANE;            // hi, lo
+constexpr int WG_STAGE = 2 * WG_SIDE;            // G, X
+
+// this lane's A / B fragment of v_mfma_f32_32x32x16_f16: row (output index) colbase + (lane & 31), k = tokens 16 ks + 8 (lane >> 5) + 0..7
+__device__ __forceinline__ f16x8 wg_frag(const unsigned char* plane, int ks, int colbase, int lane)
+{
+    const int grp = lane >> 4, p = lane & 15;
+    const unsigned char* a = plane + (16 * ks + 8 * (grp >> 1) + (p >> 2)) * WG_SR + (colbase + 16 * (grp & 1) + 4 * (p & 3)) * 2;
+    typedef __attribute__((address_space(3))) fp16x4v* lds_ptr;
+    const fp16x4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(a));
+    const fp16x4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(a + 4 * WG_SR));
+    f16x8 r;
+    __builtin_memcpy(&r, &t0, 8);
+    __builtin_memcpy(reinterpret_cast<unsigned char*>(&r) + 8, &t1, 8);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) head_wgrad_tr_kernel(const HeadWgradParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // two stages of [G hi | G lo | X hi | X lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * HT, c0 = blockIdx.y * HT, split = blockIdx.z;
+    // token range of this split: whole stages of 32 tokens
+    const int n_stage = (prm.M + HKS - 1) / HKS;
+    const int s_beg = (int)((long long)n_stage * split / prm.splits), s_end = (int)((long long)n_stage * (split + 1) / prm.splits);
+    // my four columns (of G: n, of X: channels) and my token rows tr + 8 q of the stage
+    const int c4 = tid & 31, trow = tid >> 5;
+    const int ng = n0 + 4 * c4, cx = c0 + 4 * c4;
+    const bool gvec = (prm.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(prm.G) & 15) == 0 && prm.N % 4 == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float sg = head_scale(prm.amax_g), sx = head_scale(prm.amax_x);
+    const float unscale = 1.f / (sg * sx);
+    const int Bimg = (prm.M + prm.HW - 1) / prm.HW;
+    // column validity as 0 / 1 factors, clamped column numbers for the addresses (every load is unconditional)
+    f32x4 nkeep, ckeep;
+    int ngc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        nkeep[e] = ng + e < prm.N ? 1.f : 0.f;
+        ckeep[e] = cx + e < prm.Kc ? 1.f : 0.f;
+        ngc[e] = min(ng + e, prm.N - 1);
+    }
+    const int cxc = min(cx, prm.Kc - 4);             // (Kc is a multiple of 32: a run of four is inside or outside)
+    const int ngv = min(ng, prm.N - 4 < 0 ? 0 : prm.N - 4);
+
+    // load_stage: loads only, into raw registers; commit_stage scales, masks, sums the bias columns, splits and stores row-major
+    f32x4 rg[4], rx[4], rk0, rk1;
+    auto load_stage = [&](int st) {
+        const int t0 = st * HKS + trow;
+        // my rows t0 + 8 q span 24 tokens: at most two images when HW >= 32 (the host takes version 1 below that)
+        const int b0 = min(t0 / prm.HW, Bimg - 1), b1 = min(b0 + 1, Bimg - 1);
+        const int first1 = (b0 + 1) * prm.HW;
+        rk0 = *reinterpret_cast<const f32x4*>(prm.maskX + (size_t)b0 * prm.mask_ld + cxc);
+        rk1 = *reinterpret_cast<const f32x4*>(prm.maskX + (size_t)b1 * prm.mask_ld + cxc);
+        const float* x0 = prm.X + (long long)b0 * prm.x_img + cxc - (long long)b0 * prm.HW * prm.x_tok;
+        const float* x1 = prm.X + (long long)b1 * prm.x_img + cxc - (long long)b1 * prm.HW * prm.x_tok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = t0 + 8 * q;
+            const int mcl = m < prm.M ? m : prm.M - 1;
+            rx[q] = *reinterpret_cast<const f32x4*>((mcl >= first1 ? x1 : x0) + (long long)mcl * prm.x_tok);
+            const float* gr = prm.G + (size_t)mcl * prm.ldg;
+            if (gvec) rg[q] = *reinterpret_cast<const f32x4*>(gr + ngv);
+            else rg[q] = f32x4{gr[ngc[0]], gr[ngc[1]], gr[ngc[2]], gr[ngc[3]]};
+        }
+    };
+    auto put = [&](unsigned char* plane_hi, int row, const float (&v)[4]) {
+        unsigned h0, l0, h1, l1;
+        split_f16_pair(v[0], v[1], h0, l0);
+        split_f16_pair(v[2], v[3], h1, l1);
+        *reinterpret_cast<u32x2*>(plane_hi + row * WG_SR + 8 * c4) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(plane_hi + WG_PLANE + row * WG_SR + 8 * c4) = u32x2{l0, l1};
+    };
+    auto commit_stage = [&](unsigned char* stg, int st) {
+        const int t0 = st * HKS + trow;
+        const int first1 = (min(t0 / prm.HW, Bimg - 1) + 1) * prm.HW;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = t0 + 8 * q;
+            const int mcl = m < prm.M ? m : prm.M - 1;
+            // (zeroing by 0 / 1 factors, not by selects: a value that is only used conditionally has its load sunk into a branch)
+            const float okf = m < prm.M ? 1.f : 0.f;
+            const f32x4 mk = mcl >= first1 ? rk1 : rk0;
+            float vg[4], vx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gq = rg[q][e] * (okf * nkeep[e]);
+                bsum[e] += gq;
+                vg[e] = gq * sg;
+                vx[e] = rx[q][e] * (mk[e] * (sx * okf * ckeep[e]));
+            }
+            put(stg, trow + 8 * q, vg);
+            put(stg + WG_SIDE, trow + 8 * q, vx);
+        }
+    };
+    auto mma_stage = [&](const unsigned char* stg) {
+        const unsigned char* Gh = stg;
+        const unsigned char* Xh = stg + WG_SIDE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 ah0 = wg_frag(Gh, ks, 64 * wr, lane), al0 = wg_frag(Gh + WG_PLANE, ks, 64 * wr, lane);
+            const f16x8 ah1 = wg_frag(Gh, ks, 64 * wr + 32, lane), al1 = wg_frag(Gh + WG_PLANE, ks, 64 * wr + 32, lane);
+            const f16x8 bh0 = wg_frag(Xh, ks, 64 * wc, lane), bl0 = wg_frag(Xh + WG_PLANE, ks, 64 * wc, lane);
+            const f16x8 bh1 = wg_frag(Xh, ks, 64 * wc + 32, lane), bl1 = wg_frag(Xh + WG_PLANE, ks, 64 * wc + 32, lane);
+            // (operands swapped: transposed blocks, see head_mma_stage)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, al0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, al0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, al1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, al1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, ah0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, ah0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, ah1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, ah1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, ah0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, ah0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, ah1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, ah1, acc[1][1], 0, 0, 0);
+        }
+    };
+    if (s_beg < s_end) {
+        load_stage(s_beg);
+        commit_stage(lds, s_beg);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int st = s_beg; st < s_end; ++st) {
+        const bool more = st + 1 < s_end;
+        load_stage(min(st + 1, s_end - 1));
+        __builtin_amdgcn_sched_barrier(0);       // the loads go out BEFORE the MFMAs (left alone, the scheduler puts them behind)
+        mma_stage(lds + cur * WG_STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) commit_stage(lds + (cur ^ 1) * WG_STAGE, st + 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // (transposed blocks, see head_mma_stage: lane & 31 is the row n, registers hold runs of four consecutive channels)
+    float* out = prm.part + (size_t)split * prm.N * prm.Kc;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int nn = n0 + 64 * wr + 32 * mi + (lane & 31);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int cc = c0 + 64 * wc + 32 * ni + 8 * jj + 4 * (lane >> 5);
+                if (nn < prm.N && cc < prm.Kc) {                   // (Kc is a multiple of 32: a run of four is inside or outside)
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * jj + e] * unscale;
+                    *reinterpret_cast<f32x4*>(out + (size_t)nn * prm.Kc + cc) = v;
+                }
+            }
+    }
+    if (blockIdx.y == 0 && prm.part_bias) {       // column sums of G': 8 partial rows (one per token-row group) through the dead stages
+        f32x4* cs = reinterpret_cast<f32x4*>(lds);
+        cs[trow * 32 + c4] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            f32x4 t = cs[tid];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t += cs[r * 32 + tid];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n0 + 4 * tid + e < prm.N) prm.part_bias[(size_t)split * prm.N + n0 + 4 * tid + e] = t[e];
+        }
+    }
+}
+
 // (A 128 x 384 variant of this kernel - the G columns of a tile staged once for all channels, 12 waves, 462 -> 308 MB of L2-level
 // traffic for the C x C gradient - was built and measured: 155 us against 142 us for the 3 x 3 tiles of 128 x 128 at two workgroups
 // per CU.  Like the GEMMs, this kernel runs at the ~11 bytes per cycle a CU is delivered under full-chip load, not at its MFMA rate.)
@@ -924,9 +1113,17 @@ int stego_head_bwd(const StegoHeadDesc* d, const float* tokens, const float* mas
         w.part = part; w.part_bias = pbias; w.M = M; w.N = N; w.Kc = C; w.splits = splits;
         w.amax_g = G == d_code ? scl + HS_G : scl + HS_DH;
         w.amax_x = X == tokens ? scl + HS_X : scl + HS_H;
-        hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&head_wgrad_kernel), 4 * HSIDE);
-        if (er != hipSuccess) return er;
-        hipLaunchKernelGGL(head_wgrad_kernel, dim3((N + HT - 1) / HT, (C + HT - 1) / HT, splits), dim3(256), 4 * HSIDE, s, w);
+        hipError_t er;
+        const dim3 grid((N + HT - 1) / HT, (C + HT - 1) / HT, splits);
+        if (d->HW >= HKS && (x_tok & 3) == 0 && (x_img & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(w.maskX) & 15) == 0) {
+            // (HW >= 32: a stage of 32 tokens spans at most two images, which is what the mask selection assumes)
+            if ((er = ensure_dynamic_lds(reinterpret_cast<const void*>(&head_wgrad_tr_kernel), 2 * WG_STAGE)) != hipSuccess) return er;
+            hipLaunchKernelGGL(head_wgrad_tr_kernel, grid, dim3(256), 2 * WG_STAGE, s, w);
+        } else {
+            if ((er = ensure_dynamic_lds(reinterpret_cast<const void*>(&head_wgrad_kernel), 4 * HSIDE)) != hipSuccess) return er;
+            hipLaunchKernelGGL(head_wgrad_kernel, grid, dim3(256), 4 * HSIDE, s, w);
+        }
         er = hipGetLastError();
         if (er != hipSuccess) return er;
         const long long numel = (long long)N * C;
