@@ -537,7 +537,12 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
         // gathered as 4 x 2 bytes per lane and step
         {
             const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
-            const int gb = 4 * kq * HB_LDR + 16 * HW_NP * wave + cl;      // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl
+            // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl - four ROWS of one column per lane: the LDS transposes
+            // (ds_read_b64_tr_b16: lane p of a 16-lane group passes the address of row p >> 2, columns 4 (p & 3) .. + 3 of a
+            // [4 rows][16 columns] block and receives column p, rows 0..3; one read per fragment instead of four 2-byte reads)
+            const int gt = (4 * kq + (cl >> 2)) * HB_LDR + 16 * HW_NP * wave + 4 * (cl & 3);
+            typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+            typedef __attribute__((address_space(3))) fp16x4v* lds_tr_ptr;
 #pragma unroll 2
             for (int kk = 0; kk < TP; kk += 16) {
                 f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
@@ -547,12 +552,12 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
                     al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + kk);
                 }
 #pragma unroll
-                for (int np = 0; np < HW_NP; ++np)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        bh[np][e] = Gh[gb + (kk + e) * HB_LDR + 16 * np];
-                        bl[np][e] = Gl[gb + (kk + e) * HB_LDR + 16 * np];
-                    }
+                for (int np = 0; np < HW_NP; ++np) {
+                    const fp16x4v th = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gh + gt + kk * HB_LDR + 16 * np));
+                    const fp16x4v tl = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gl + gt + kk * HB_LDR + 16 * np));
+                    __builtin_memcpy(&bh[np], &th, 8);
+                    __builtin_memcpy(&bl[np], &tl, 8);
+                }
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
