@@ -9,6 +9,7 @@
 //     CUDAGeneratorImpl::philox_cuda_state(increment).  Python cannot reach it; this can.  The increment is registered with the
 //     generator in the same call (eagerly: advances the offset; capturing: grows the graph's whole-graph increment), so the generator
 //     moves exactly as the seven torch calls would move it.
+// (3) head: the segmentation head's autograd function (stego_head_fwd / stego_head_bwd), same reason as (2).
 // (2) corr_loss: ContrastiveCorrelationLoss.forward (src/modules.py:349-398, given the draws) as a torch::autograd::Function over
 //     stego_corr_fwd_prepared / stego_corr_bwd.  The reference's training loop is eager (Lightning, train_segmentation.py:154-181): what
 //     a user of the drop-in pays per step is the host side of this call, and the Python autograd.Function it replaces
@@ -25,6 +26,7 @@
 #include <string>
 #include <tuple>
 #include "../../include/stego_corr.h"
+#include "../../include/stego_head.h"
 
 namespace {
 
@@ -42,6 +44,10 @@ struct Lib {
     decltype(&stego_ref_draws) ref_draws;
     decltype(&stego_ref_draws_indirect) ref_draws_indirect;
     decltype(&stego_ref_draws_advance) ref_draws_advance;
+    decltype(&stego_head_fwd_workspace_bytes) head_fwd_ws;
+    decltype(&stego_head_bwd_workspace_bytes) head_bwd_ws;
+    decltype(&stego_head_fwd) head_fwd;
+    decltype(&stego_head_bwd) head_bwd;
 } L;
 
 template <class F> void sym(F& f, const char* name)
@@ -66,6 +72,10 @@ void bind(const std::string& path)
     sym(L.ref_draws, "stego_ref_draws");
     sym(L.ref_draws_indirect, "stego_ref_draws_indirect");
     sym(L.ref_draws_advance, "stego_ref_draws_advance");
+    sym(L.head_fwd_ws, "stego_head_fwd_workspace_bytes");
+    sym(L.head_bwd_ws, "stego_head_bwd_workspace_bytes");
+    sym(L.head_fwd, "stego_head_fwd");
+    sym(L.head_bwd, "stego_head_bwd");
     TORCH_CHECK(L.abi_version() == STEGO_ABI_VERSION, "libstego_corr.so has ABI ", L.abi_version(), ", this module was built for ",
                 STEGO_ABI_VERSION);
 }
@@ -305,6 +315,103 @@ std::vector<at::Tensor> corr_loss(const at::Tensor& feats, const at::Tensor& fea
     return CorrLoss::apply(feats, feats_pos, code, code_pos, coords1, coords2, perms, desc, mode);
 }
 
+// ------------------------------------------------------------------------------------------------ (3) the segmentation head
+// DinoFeaturizer.forward's tail (src/modules.py:108-116) as a torch::autograd::Function over stego_head_fwd / stego_head_bwd - the C++
+// twin of stego_amd/featurizers.py::_NativeHeadFunction (kept for hosts without this module): two such calls per training step.
+using OptT = c10::optional<at::Tensor>;
+const float* optp(const OptT& t) { return (t.has_value() && t->defined()) ? t->data_ptr<float>() : nullptr; }
+
+StegoHeadDesc head_desc(const at::Tensor& tokens, int64_t K, bool nonlinear)
+{
+    TORCH_CHECK(tokens.dim() == 3 && tokens.scalar_type() == at::kFloat && tokens.stride(2) == 1,
+                "head: expected a float32 [B, HW, C] token tensor with contiguous channels");
+    StegoHeadDesc d{};
+    d.B = (int32_t)tokens.size(0); d.HW = (int32_t)tokens.size(1); d.C = (int32_t)tokens.size(2); d.K = (int32_t)K;
+    d.nonlinear = nonlinear ? 1 : 0;
+    d.tok_stride = tokens.stride(1);
+    d.img_stride = d.B > 1 ? tokens.stride(0) : (int64_t)d.HW * tokens.stride(1);
+    d.tokens_amax = nullptr;
+    return d;
+}
+
+struct HeadFn : public torch::autograd::Function<HeadFn> {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& tokens, const OptT& m1, const OptT& m2, const OptT& m3,
+                                 const at::Tensor& w1, const at::Tensor& b1, const OptT& w21, const OptT& b21, const OptT& w22,
+                                 const OptT& b22, bool want_feats, const OptT& tokens_amax)
+    {
+        TORCH_CHECK(L.handle, "bind() first");
+        require_device(tokens, "tokens"); require_device(w1, "cluster1.weight");
+        const bool nonlinear = w21.has_value() && w21->defined();
+        bool need_grad = w1.requires_grad() || b1.requires_grad();
+        for (const OptT* t : {&w21, &b21, &w22, &b22}) need_grad = need_grad || (t->has_value() && (*t)->defined() && (*t)->requires_grad());
+        StegoHeadDesc d = head_desc(tokens, w1.size(0), nonlinear);
+        if (tokens_amax.has_value() && tokens_amax->defined()) d.tokens_amax = reinterpret_cast<const uint32_t*>(tokens_amax->data_ptr());
+        const at::Device dev = tokens.device();
+        c10::DeviceGuard guard(dev);
+        hipStream_t stream = current_stream(tokens);
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const int64_t B = d.B, HW = d.HW, C = d.C, K = d.K;
+        at::Tensor code = at::empty({B, HW, K}, f32), feats, saved_h;
+        if (want_feats) feats = at::empty({B, HW, C}, f32);
+        if (nonlinear && need_grad) saved_h = at::empty({B * HW * C + 8}, f32);
+        size_t nws = L.head_fwd_ws(&d);
+        TORCH_CHECK(nws > 0, "stego_head_fwd: unsupported shape (C a multiple of 32, K <= 128, 16-byte token rows)");
+        if (nonlinear && saved_h.defined()) nws -= ((size_t)B * HW * C * 4 + 255) / 256 * 256;      // (H lives in saved_h)
+        at::Tensor ws = at::empty({(int64_t)nws}, f32.dtype(at::kByte));
+        auto wp = [](const at::Tensor& t) { return t.data_ptr<float>(); };
+        TORCH_CHECK(w1.is_contiguous() && b1.is_contiguous(), "head: contiguous parameters expected");
+        check(L.head_fwd(&d, tokens.data_ptr<float>(), optp(m1), optp(m2), optp(m3), wp(w1), wp(b1), optp(w21), optp(b21), optp(w22),
+                         optp(b22), code.data_ptr<float>(), feats.defined() ? feats.data_ptr<float>() : nullptr,
+                         saved_h.defined() ? saved_h.data_ptr<float>() : nullptr, ws.data_ptr(), nws, stream), "stego_head_fwd");
+        ctx->set_materialize_grads(false);
+        ctx->saved_data["K"] = K;
+        ctx->saved_data["nonlinear"] = nonlinear;
+        if (need_grad) {
+            auto ot = [](const OptT& t) { return (t.has_value() && t->defined()) ? *t : at::Tensor(); };
+            ctx->save_for_backward({tokens, ot(m1), ot(m2), saved_h, ot(w22)});
+        }
+        if (!feats.defined()) return {code};             // (an undefined tensor cannot be an output: eval mode returns the code alone)
+        ctx->mark_non_differentiable({feats});
+        return {code, feats};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        at::Tensor none;
+        variable_list out(12, none);
+        if (!g[0].defined()) return out;
+        TORCH_CHECK(!(g[0].requires_grad() && at::GradMode::is_enabled()), "the head kernels are differentiable once (no double backward)");
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &tokens = saved[0], &m1 = saved[1], &m2 = saved[2], &saved_h = saved[3], &w22 = saved[4];
+        const bool nonlinear = ctx->saved_data["nonlinear"].toBool();
+        const int64_t K = ctx->saved_data["K"].toInt();
+        StegoHeadDesc d = head_desc(tokens, K, nonlinear);
+        const at::Device dev = tokens.device();
+        c10::DeviceGuard guard(dev);
+        hipStream_t stream = current_stream(tokens);
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const int64_t C = d.C;
+        at::Tensor dw1 = at::empty({K, C}, f32), db1 = at::empty({K}, f32), dw21, db21, dw22, db22;
+        if (nonlinear) { dw21 = at::empty({C, C}, f32); db21 = at::empty({C}, f32); dw22 = at::empty({K, C}, f32); db22 = at::empty({K}, f32); }
+        const at::Tensor d_code = dense_f32(g[0]);
+        const size_t nws = L.head_bwd_ws(&d);
+        at::Tensor ws = at::empty({(int64_t)nws}, f32.dtype(at::kByte));
+        check(L.head_bwd(&d, tokens.data_ptr<float>(), fptr(m1), fptr(m2), nonlinear ? saved_h.data_ptr<float>() : nullptr, fptr(w22),
+                         d_code.data_ptr<float>(), dw1.data_ptr<float>(), db1.data_ptr<float>(), nonlinear ? dw21.data_ptr<float>() : nullptr,
+                         nonlinear ? db21.data_ptr<float>() : nullptr, nonlinear ? dw22.data_ptr<float>() : nullptr,
+                         nonlinear ? db22.data_ptr<float>() : nullptr, ws.data_ptr(), nws, stream), "stego_head_bwd");
+        out[4] = dw1; out[5] = db1; out[6] = dw21; out[7] = db21; out[8] = dw22; out[9] = db22;
+        return out;
+    }
+};
+
+std::vector<at::Tensor> head(const at::Tensor& tokens, const OptT& m1, const OptT& m2, const OptT& m3, const at::Tensor& w1,
+                             const at::Tensor& b1, const OptT& w21, const OptT& b21, const OptT& w22, const OptT& b22, bool want_feats,
+                             const OptT& tokens_amax)
+{
+    return HeadFn::apply(tokens, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -317,4 +424,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return corr_loss(a, b, c, d, e, f, g, std::string(desc), mode);
     }, "ContrastiveCorrelationLoss.forward given the draws (autograd through stego_corr_bwd)");
     m.def("reset_workspaces", &reset_workspaces);
+    m.def("head", &head, "DinoFeaturizer's head (dropout masks given) -> [code [B, HW, K]] or [code, feats [B, HW, C]] (want_feats)");
 }

@@ -320,7 +320,12 @@ class DinoFeaturizer(nn.Module):
             c20, c22 = self.cluster2[0], self.cluster2[2]
             w21, b21 = c20.weight.view(c20.out_channels, c20.in_channels), c20.bias
             w22, b22 = c22.weight.view(c22.out_channels, c22.in_channels), c22.bias
-        code, feats = _NativeHeadFunction.apply(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax)
+        ext = capi.torchglue() if getattr(self.cfg, "native_autograd", True) else None
+        if ext is not None and hasattr(ext, "head"):       # the same op as a C++ autograd function (csrc/torch_glue_ext.cpp)
+            outs = ext.head(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax)
+            code, feats = outs[0], (outs[1] if len(outs) > 1 else None)
+        else:
+            code, feats = _NativeHeadFunction.apply(tok, m1, m2, m3, w1, b1, w21, b21, w22, b22, want_feats, tokens_amax)
         code = code.view(B, fh, fw, self.dim).permute(0, 3, 1, 2)
         feats = feats.view(B, fh, fw, C).permute(0, 3, 1, 2) if feats is not None else image_feat
         return feats, code

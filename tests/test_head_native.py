@@ -189,3 +189,31 @@ def test_cached_tokens_arrive_converted_with_their_magnitude_word():
         f0, c0 = net._head_native(image_feat)
         f1, c1 = net._head_native(image_feat, amax)
     assert torch.equal(c0, c1) and torch.equal(f0, f1)
+
+
+def test_cpp_head_function_is_the_python_one_bit_for_bit():
+    """csrc/torch_glue_ext.cpp::HeadFn (default) against featurizers._NativeHeadFunction (cfg.native_autograd = False): same C ABI calls,
+    so feats, code and the six parameter gradients are bitwise equal - training mode (masks, saved H) and eval mode."""
+    from stego_amd import capi
+    assert capi.torchglue() is not None and hasattr(capi.torchglue(), "head")
+    net, cfg = _featurizer("vit_small", 70, "nonlinear", True)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    tokens = torch.randn(6, 1 + 14 * 14, 384, device=DEV, generator=g)
+    image_feat = tokens[:, 1:, :].reshape(6, 14, 14, 384).permute(0, 3, 1, 2)
+    up = torch.randn(6, 70, 14, 14, device=DEV, generator=g) / 196
+    params = [p for n, p in net.named_parameters() if n.startswith("cluster")]
+    res = {}
+    for native_autograd in (True, False):
+        cfg.native_autograd = native_autograd
+        rec = []
+        for train in (True, False):
+            net.train(train)
+            for p in params:
+                p.grad = None
+            torch.manual_seed(5)
+            feats, code = net._head_native(image_feat)
+            (code * up).sum().backward()
+            rec += [feats.detach().clone(), code.detach().clone()] + [p.grad.detach().clone() for p in params]
+        res[native_autograd] = rec
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

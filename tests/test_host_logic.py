@@ -331,7 +331,7 @@ def test_torch_glue_extension_is_built_and_bound_to_the_library():
     _build.build_torchglue()
     ext = capi.torchglue()
     assert ext is not None
-    for name in ("bind", "philox_state", "ref_draws", "corr_loss", "reset_workspaces"):
+    for name in ("bind", "philox_state", "ref_draws", "corr_loss", "head", "reset_workspaces"):
         assert hasattr(ext, name)
     x = torch.zeros(2, 8, 4, 4)
     desc = capi.make_desc(2, 8, 4, 4, 4, 2, 0, type("C", (), dict(pointwise=True, zero_clamp=True, stabalize=False))(), (0.1, 0.2, 0.3))
