@@ -380,9 +380,11 @@ class Trainer:
             for batch in loader:
                 batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 loss = model.training_step(batch, step)
-                history.append(float(loss.detach()))
+                # the loss stays on the device (a float() here is a host sync every step: the CPU could never run ahead of the GPU);
+                # values are read when they are printed and once at the end
+                history.append(loss.detach())
                 if self.rank == 0 and step % self.log_every == 0:
-                    print("step %5d  loss %.5f  " % (step, history[-1]) +
+                    print("step %5d  loss %.5f  " % (step, float(history[-1])) +
                           "  ".join("%s %.5f" % (k, float(v)) for k, v in model.logged.items() if k.startswith("loss/pos") or k.startswith("loss/neg")))
                 step += 1
                 if self.val_loader is not None and self.val_check_interval and step % self.val_check_interval == 0:
@@ -391,7 +393,7 @@ class Trainer:
                     break
         if self.checkpoint_path and self.rank == 0:
             model.save_checkpoint(self.checkpoint_path)
-        return history
+        return [float(v) for v in torch.stack(history).cpu()] if history else []
 
     def _shard_loader(self, loader):
         """Data parallelism needs every rank to see its own slice: a loader without a DistributedSampler over a dataset that is
