@@ -511,3 +511,23 @@ def test_state_dict_is_key_for_key_the_reference_lightning_checkpoint(arch, tmp_
     assert loaded.global_step == 1234 and loaded.n_classes == m["n_classes"]
     for k, v in loaded.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_linear_probe_loss_in_its_spatial_form_is_the_reference_s_masked_mean():
+    """training_step's linear-probe loss: the reference flattens the upsampled logits to [pixels, classes], boolean-indexes the valid
+    pixels and takes nn.CrossEntropyLoss (train_segmentation.py:199-203); the trainer here calls F.cross_entropy on [B, C, H, W] with the
+    invalid labels as ignore_index.  Same value and same gradient, labels outside [0, n_classes) included."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    n_classes = 27
+    logits = torch.randn(3, n_classes, 20, 24, requires_grad=True)
+    label = torch.randint(-1, n_classes + 2, (3, 20, 24))
+    flat = label.reshape(-1)
+    mask = (flat >= 0) & (flat < n_classes)
+    ref = torch.nn.CrossEntropyLoss()(logits.permute(0, 2, 3, 1).reshape(-1, n_classes)[mask], flat[mask]).mean()
+    g_ref, = torch.autograd.grad(ref, logits)
+    valid = (label >= 0) & (label < n_classes)
+    new = F.cross_entropy(logits, torch.where(valid, label, torch.full_like(label, -100)), ignore_index=-100)
+    g_new, = torch.autograd.grad(new, logits)
+    assert abs(float(ref) - float(new)) <= 1e-6 * abs(float(ref))
+    assert torch.allclose(g_ref, g_new, rtol=1e-5, atol=1e-9)
