@@ -83,7 +83,9 @@ struct Geometry {
     int n_roles, nset, NCH, KQ, LDK;
     int NCH2, NKC, kper;            // fused forward: C / 32 feature stages, code K-chunks of kper channels
     size_t stats_bytes, sync_bytes, fs_bytes, csf_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
+    size_t bwd_dt_bytes, bwd_slots_bytes, bwd_pool_bytes;    // lists-first backward: DT rows, list slots, overflow pool (0: not covered)
 };
+constexpr size_t BWD_STAMP_BYTES = 65536;    // debug stamps behind the DT rows
 
 Geometry geometry(const StegoCorrDesc* d, bool helper)
 {
@@ -111,7 +113,17 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
     g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8 * 4, 256) + 256;   // + 3 more granules per tile: sum lp, sum clamp, applied;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
     g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.csf_bytes + g.ctx_bytes;
-    g.bwd_ws_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256) + 65536;   // tail: debug stamps
+    g.bwd_dt_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256);
+    g.bwd_slots_bytes = g.bwd_pool_bytes = 0;
+    if (!helper && d->H <= 64 && d->W <= 64) {
+        // corr_unsample_list_kernel: a 1 KB slot per (image, pixel row, 16-pixel bin) unit of orig_code, a 256-byte slot per unit of
+        // orig_code_pos, and room for every entry (16 bytes, at most 4 per (item, point)) in the overflow pool - an item is one
+        // (tile, side) whose gradient rows land in a destination image
+        const size_t units = (size_t)d->B * d->H * ((d->W + 15) / 16);
+        g.bwd_slots_bytes = round_up(units * (1024 + 256), 256);
+        g.bwd_pool_bytes = round_up((size_t)4 * d->S * d->S * ((size_t)(2 + d->n_neg) * d->B + (size_t)d->n_neg * d->B + d->B) * 16, 256);
+    }
+    g.bwd_ws_bytes = g.bwd_dt_bytes + BWD_STAMP_BYTES + g.bwd_slots_bytes + g.bwd_pool_bytes;
     return g;
 }
 
@@ -133,6 +145,15 @@ int fill_bwd_ctx(const StegoCorrDesc* d, bool helper, const void* saved_ctx, voi
     prm->tapyx = reinterpret_cast<const int4*>(ctx + g.cs_bytes + g.nrm_bytes);
     prm->tapw = reinterpret_cast<const float4*>(ctx + g.cs_bytes + g.nrm_bytes + g.tap_bytes);
     prm->dt = static_cast<float*>(workspace);
+    if (!helper && g.bwd_pool_bytes && g.bwd_dt_bytes < ((size_t)1 << 32) && g.bwd_pool_bytes < ((size_t)1 << 32) &&
+        g.bwd_slots_bytes < ((size_t)1 << 32)) {
+        unsigned char* ws = static_cast<unsigned char*>(workspace);
+        prm->uslots = reinterpret_cast<unsigned*>(ws + g.bwd_dt_bytes + BWD_STAMP_BYTES);
+        prm->upool = reinterpret_cast<unsigned*>(ws + g.bwd_dt_bytes + BWD_STAMP_BYTES + g.bwd_slots_bytes);
+        prm->dt_bytes = (unsigned)g.bwd_dt_bytes;
+        prm->uslots_bytes = (unsigned)g.bwd_slots_bytes;
+        prm->upool_bytes = (unsigned)g.bwd_pool_bytes;
+    }
     prm->KQ = g.KQ;
     prm->LDK = g.LDK;
     return STEGO_OK;

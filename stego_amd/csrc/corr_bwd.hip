@@ -305,10 +305,10 @@ __device__ __forceinline__ void normalize_bwd_store_t(f32x4 (&d)[NT][HW_NP], con
     }
 }
 
+// One tile of the split-fp16 backward (the body of corr_bwd_tile_h_kernel and of the tile role of corr_bwd_tile_build_kernel).
 template <int NT, bool DENSE>      // DENSE: some upstream gradient is a tensor (not the training case)
-__global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdParams prm)
+__device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int tile, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // channel tiles are processed in groups whose operand images fit LDS next to G: all of them up to K = 80, two groups beyond
     constexpr int NTG = NT <= 5 ? NT : (NT + 1) / 2;
     constexpr int NG = (NT + NTG - 1) / NTG;
@@ -322,7 +322,6 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int B = prm.B, P = prm.P, K = prm.K, ldk = prm.LDK;
-    const int tile = blockIdx.x;
     const int b = tile % B, p = tile / B;
     const bool sameAB = p == 0;
     const int sA = b;
@@ -331,8 +330,8 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
     const float* csB = prm.cs + (size_t)sB * TP * ldk;
 
     // debug bit 8: phase stamps (100 MHz global clock), 4 per tile, second half of the workspace tail
-    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)blockIdx.x * 4;
-    const bool stamp_on = (prm.debug & 8) && tid == 0 && blockIdx.x < 1024;
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)tile * 4;
+    const bool stamp_on = (prm.debug & 8) && tid == 0 && tile < 1024;
     if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- upstreams folded into (pointer, index multiplier, scale) triples: absent / broadcast gradients need no branches
@@ -587,6 +586,13 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdPa
         normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
     }
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int NT, bool DENSE>
+__global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_h_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bwd_tile_h_body<NT, DENSE>(prm, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------- unsample
@@ -1018,8 +1024,399 @@ __global__ void __launch_bounds__(UR_WAVES * 64, (MT <= 2 && UR_NT <= 5) ? 4 : 2
     if (stamp_on) ts[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+// =========================================================================================== lists first: the training backward
+// corr_bwd_tile_build_kernel + corr_unsample_list_kernel (scalar upstreams, split-fp16 GEMMs, maps up to 64 x 64).  The row kernel
+// above spends three dependent load rounds per unit (perms -> items, tap words -> worklist, DT rows) of which only the last needs the
+// tile kernel's output.  Here the first two run BESIDE the tiles, in the same launch: with B = 32 the 224 tile workgroups leave 32
+// CUs free, and B "builder" workgroups at the front of the grid turn perms + the forward's tap tables into the entry list of every
+// (destination, image, pixel row, 16-pixel bin) unit - which DT rows land there, with which weights.  The second launch is then ONE
+// wave per unit pair: its lists arrive in one load (fixed slots), every DT row of the unit is in flight at once (16-byte loads), the
+// rows are accumulated as one-hot GEMMs on the f32 MFMA in registers, and the pixels leave as 16-byte stores.  One wave per unit, the
+// list order fixed by a stable counting sort: no atomics on data, no reduction between waves, bitwise repeatable.
+// (A version with the unsample INSIDE the same launch, handing the DT rows over through device counters, was measured slower than the
+// kernel boundary it removed: profiles/r04b_bwd_one_launch_attempt.txt.)
+constexpr int BF_ITEM_CAP = 1032;                 // items of one destination image: n_sets + n_neg B <= 1026 (fill_bwd_ctx)
+constexpr int BF_MAXH = 64, BF_MAXMT = 4;         // maps up to 64 x 64
+constexpr int BF_NKEY = 2 * BF_MAXH * BF_MAXMT;   // list keys of one image: (destination, pixel row, 16-pixel bin)
+constexpr int UL_CAP0 = 63, UL_CAP1 = 15;         // entries in the slot of a dest-0 / dest-1 unit, behind a 16-byte header {count, overflow start}
+constexpr int UL_SLOT0 = 16 * (UL_CAP0 + 1), UL_SLOT1 = 16 * (UL_CAP1 + 1);
+constexpr int BFS_ITEMS = 0;                                          // int2[BF_ITEM_CAP]  {sample set, DT base (floats)}
+constexpr int BFS_HIST = BFS_ITEMS + BF_ITEM_CAP * 8;                 // unsigned[HW_WAVES][BF_NKEY] counts, then running positions
+constexpr int BFS_OVF = BFS_HIST + HW_WAVES * BF_NKEY * 4;            // unsigned[BF_NKEY] overflow start of every list (pool entries)
+constexpr int BFS_SCAN = BFS_OVF + BF_NKEY * 4;                       // unsigned[HW_WAVES + 1] partial sums of the block scan
+constexpr int BFS_MISC = BFS_SCAN + 64;                               // int[4]: items of dest 0, overflow slab of dest 0 / dest 1
+constexpr int BF_LDS_BYTES = BFS_MISC + 64;
+static_assert(BF_NKEY == HW_THREADS, "one thread per list key in the prefix");
+
+typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// ---- builder role: the entry lists of destination images bi, bi + n_build, ... (dest 0 = orig_code with its anchor and negative
+// items, dest 1 = orig_code_pos with its one item, handled together).  A stable counting sort of the (item, point, tap row) sequence
+// by list key, in LDS: wave w owns the item halves w, w + 8, ...; counts per (wave, key), a block-wide prefix, then every element
+// takes its slot with a returning LDS add on its wave's OWN counter - lanes of one instruction that hit the same counter are
+// served in an order the hardware fixes (no other wave touches it), so the lists come out the same launch after launch.
+__device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int bi, unsigned char* smem)
+{
+    int2* items = reinterpret_cast<int2*>(smem + BFS_ITEMS);
+    unsigned* hist = reinterpret_cast<unsigned*>(smem + BFS_HIST);
+    unsigned* ovf = reinterpret_cast<unsigned*>(smem + BFS_OVF);
+    unsigned* scan = reinterpret_cast<unsigned*>(smem + BFS_SCAN);
+    int* misc = reinterpret_cast<int*>(smem + BFS_MISC);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int B = prm.B, P = prm.P, H = prm.H, W = prm.W, ldk = prm.LDK;
+    const int MT = (W + 15) >> 4;
+    const int side_elems = TP * ldk;
+    const unsigned EPI = 4u * (unsigned)P;                   // entry slots per item: two rows, at most two bins each
+    const unsigned light0 = (unsigned)(B * H * MT) * UL_SLOT0;       // byte offset of the dest-1 slots
+    const __amdgpu_buffer_rsrc_t pool = bf_rsrc(prm.upool, prm.upool_bytes);
+    const __amdgpu_buffer_rsrc_t slots = bf_rsrc(prm.uslots, prm.uslots_bytes);
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * side_elems) + 2048 + 2 * bi;
+    const bool stamp_on = (prm.debug & 8) && tid == 0 && bi < 512;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
+    unsigned* myhist = hist + wave * BF_NKEY;
+
+    for (int j = bi; j < B; j += prm.n_build) {
+        __syncthreads();                                     // the previous image's LDS tables are dead
+        // ---- items of dest 0 (the anchor's own tiles, then the negatives whose perm picked image j: modules.py:385), then dest 1's one item
+        if (wave == 0) {
+            const int n_own = prm.n_sets;
+            for (int u = lane; u < n_own; u += 64) items[u] = make_int2(j, ((u * B + j) * 2 + 0) * side_elems);
+            int n_seen = 0, below = 0;
+            const int n_negc = prm.n_neg * B;
+            for (int t0 = 0; t0 < n_negc; t0 += 64) {
+                const int t = t0 + lane;
+                const long long pv = t < n_negc ? prm.perms[t] : -1;
+                const bool m = (int)pv == j && t < n_negc;
+                const unsigned long long mask = __ballot(m);
+                const int s = 2 * B + t;
+                if (m) items[n_own + n_seen + lane_prefix(mask)] = make_int2(s, (s * 2 + 1) * side_elems);
+                n_seen += __builtin_popcountll(mask);
+                below += __builtin_popcountll(__ballot(t < n_negc && (int)pv < j));
+            }
+            const int n0 = n_own + n_seen;
+            if (lane == 0) {
+                items[n0] = make_int2(B + j, ((B + j) * 2 + 1) * side_elems);
+                misc[0] = n0;
+                misc[1] = (int)(EPI * (unsigned)(prm.n_sets * j + below));          // overflow slabs: room for every entry of the image
+                misc[2] = (int)(EPI * (unsigned)(prm.n_sets * B + n_negc + j));
+            }
+        }
+        for (int i = tid; i < HW_WAVES * BF_NKEY; i += HW_THREADS) hist[i] = 0u;
+        __syncthreads();
+        const int n0 = misc[0], n_ih = 2 * (n0 + 1);         // item halves: 64 points each
+        const unsigned slab0 = (unsigned)misc[1], slab1 = (unsigned)misc[2];
+        // the (<= 4) list keys of a point: tap rows y0 and y0 + 1 (a clamped lower row carries zero weights: no entry), in each
+        // the bin of x0 and - when x0 is the last pixel of its bin - the bin of x0 + 1
+        auto point_keys = [&](int dest, int q, int wd, int (&key)[4]) {
+            const int y0 = wd >> 16, x0 = wd & 0xffff;
+            const int b0 = x0 >> 4, b1 = (x0 & 15) == 15 && b0 + 1 < MT ? b0 + 1 : -1;
+            const bool v = q < P;
+            const int r0 = (dest * H + y0) * BF_MAXMT, r1 = r0 + BF_MAXMT;
+            key[0] = v ? r0 + b0 : -1;
+            key[1] = v && b1 >= 0 ? r0 + b1 : -1;
+            key[2] = v && y0 + 1 < H ? r1 + b0 : -1;
+            key[3] = v && y0 + 1 < H && b1 >= 0 ? r1 + b1 : -1;
+        };
+        // ---- pass 0: counts per (wave, key)
+        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * HW_WAVES) {
+            int wd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ih = min(ih0 + u * HW_WAVES, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
+                wd[u] = reinterpret_cast<const int*>(prm.tapyx + (size_t)items[it].x * TP + q)[0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ih = ih0 + u * HW_WAVES;
+                if (ih < n_ih) {                             // uniform
+                    int key[4];
+                    point_keys((ih >> 1) >= n0, (ih & 1) * 64 + lane, wd[u], key);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (key[c] >= 0) __hip_atomic_fetch_add(myhist + key[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- prefix: thread k owns key k.  A list's first UL_CAP entries live in the unit's slot, the rest in the image's overflow
+        // slab (lists in key order per destination); inside a list the waves come in order
+        {
+            const int kd1 = H * BF_MAXMT;                    // first key of dest 1
+            const bool d1 = tid >= kd1;
+            const unsigned cap = d1 ? UL_CAP1 : UL_CAP0;
+            unsigned c[HW_WAVES], tot = 0u;
+#pragma unroll
+            for (int w = 0; w < HW_WAVES; ++w) { c[w] = hist[w * BF_NKEY + tid]; tot += c[w]; }
+            const unsigned over = tot > cap ? tot - cap : 0u;
+            unsigned inc = over;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) scan[wave] = inc;
+            __syncthreads();
+            unsigned base = inc - over;
+#pragma unroll
+            for (int w = 0; w < HW_WAVES; ++w) base += w < wave ? scan[w] : 0u;
+            if (tid == kd1) scan[HW_WAVES] = base;           // dest 1's overflow restarts in its own slab
+            __syncthreads();
+            const unsigned ostart = d1 ? slab1 + (base - scan[HW_WAVES]) : slab0 + base;
+            ovf[tid] = ostart;
+            const int rm = tid - (d1 ? kd1 : 0), m = rm & (BF_MAXMT - 1);     // rm = row * 4 + bin
+            if (tid < 2 * kd1 && m < MT) {
+                const unsigned ui = (unsigned)((j * H + (rm >> 2)) * MT + m);
+                __builtin_amdgcn_raw_buffer_store_b128(bu32x4{tot, ostart, 0u, 0u}, slots, d1 ? light0 + ui * UL_SLOT1 : ui * UL_SLOT0, 0, 0);
+            }
+            unsigned run = 0u;                               // list-relative running positions per (wave, key)
+#pragma unroll
+            for (int w = 0; w < HW_WAVES; ++w) { hist[w * BF_NKEY + tid] = run; run += c[w]; }
+        }
+        __syncthreads();
+        // ---- pass 1: every element takes its position and leaves its entry {DT row, x0, weight left, weight right}
+        const int kd1 = H * BF_MAXMT;
+        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * HW_WAVES) {
+            int wd[4];
+            float4 w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ih = min(ih0 + u * HW_WAVES, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
+                const size_t e = (size_t)items[it].x * TP + q;
+                wd[u] = reinterpret_cast<const int*>(prm.tapyx + e)[0];
+                w4[u] = prm.tapw[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ih = ih0 + u * HW_WAVES;
+                if (ih < n_ih) {                             // uniform
+                    const int it = ih >> 1, q = (ih & 1) * 64 + lane;
+                    const bool d1 = it >= n0;
+                    int key[4];
+                    point_keys(d1, q, wd[u], key);
+                    bu32x4 ent;
+                    ent[0] = (unsigned)(items[it].y + q * ldk);
+                    ent[1] = (unsigned)(wd[u] & 0xffff);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (key[c] >= 0) {
+                            const unsigned pos = __hip_atomic_fetch_add(myhist + key[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            ent[2] = __builtin_bit_cast(unsigned, c >= 2 ? w4[u].z : w4[u].x);
+                            ent[3] = __builtin_bit_cast(unsigned, c >= 2 ? w4[u].w : w4[u].y);
+                            const int rm = key[c] - (d1 ? kd1 : 0);
+                            const unsigned ui = (unsigned)((j * H + (rm >> 2)) * MT + (rm & (BF_MAXMT - 1)));
+                            const unsigned cap = d1 ? UL_CAP1 : UL_CAP0;
+                            if (pos < cap) __builtin_amdgcn_raw_buffer_store_b128(ent, slots, (d1 ? light0 + ui * UL_SLOT1 : ui * UL_SLOT0) + 16u * (1u + pos), 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(ent, pool, (ovf[key[c]] + (pos - cap)) * 16u, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_build_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = blockIdx.x;
+    if (w < prm.n_build) bwd_builder_role(prm, w, smem);
+    else bwd_tile_h_body<NT, false>(prm, w - prm.n_build, smem);
+}
+
+// ---- second launch: wave k takes the pair of units {dest 0, dest 1} x (image, row, bin) k
+// Channels: NQ x 64 as 16-byte loads (lane l16 holds channels 64 qd + 4 l16 .. + 3: accumulator tile 4 qd + c is channel 64 qd + 4 l16 + c,
+// so a pixel leaves as one 16-byte store per lane), + TAIL 16-channel tiles as 4-byte loads (channel 64 NQ + l16).
+constexpr int UL_WAVES = 4;
+template <int NQ, int TAIL>
+__global__ void __launch_bounds__(64 * UL_WAVES) corr_unsample_list_kernel(const BwdParams prm)
+{
+    constexpr int NA = 4 * NQ + TAIL;                        // accumulator tiles
+    constexpr int EG0 = (UL_CAP0 + 1) / 4, EG1 = (UL_CAP1 + 1) / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = prm.B, H = prm.H, W = prm.W, K = prm.K, ldk = prm.LDK;
+    const int MT = (W + 15) >> 4;
+    const int n_pairs = B * H * MT;
+    const int k = blockIdx.x * UL_WAVES + wave;
+    if (k >= n_pairs) return;
+    const int l16 = lane & 15, k4 = lane >> 4;
+    const __amdgpu_buffer_rsrc_t pool = bf_rsrc(prm.upool, prm.upool_bytes);
+    const __amdgpu_buffer_rsrc_t slots = bf_rsrc(prm.uslots, prm.uslots_bytes);
+    const __amdgpu_buffer_rsrc_t dtr = bf_rsrc(prm.dt, prm.dt_bytes);
+    const unsigned light0 = (unsigned)n_pairs * UL_SLOT0;
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 2 * blockIdx.x;
+    const bool stamp_on = (prm.debug & 8) && threadIdx.x == 0 && blockIdx.x < 1024;
+    if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
+    const int m = k % MT, jr = k / MT;                       // jr = image * H + row
+
+    // both slots in one round: lane 0 the header, lane i entry i - 1
+    bu32x4 s0 = __builtin_amdgcn_raw_buffer_load_b128(slots, (unsigned)k * UL_SLOT0 + 16u * lane, 0, 0);
+    bu32x4 s1 = __builtin_amdgcn_raw_buffer_load_b128(slots, light0 + (unsigned)k * UL_SLOT1 + 16u * (lane & 15), 0, 0);
+    const unsigned n0 = __builtin_amdgcn_readfirstlane(s0[0]), o0 = __builtin_amdgcn_readfirstlane(s0[1]);
+    const unsigned n1 = __builtin_amdgcn_readfirstlane(s1[0]), o1 = __builtin_amdgcn_readfirstlane(s1[1]);
+
+    f32x4 acc[2][NA];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[u][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the DT rows of NG groups of 4 entries held by the lanes first .. first + n - 1 of `ent` (group g, lane group k4: entry 4 g + k4)
+    struct Rows { f32x4 q[NQ]; float t[TAIL > 0 ? TAIL : 1]; };
+    auto issue = [&](const bu32x4& ent, int first, int n, auto& rows, auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int e = min(4 * g + k4, max(n - 1, 0));
+            const unsigned row = (unsigned)__shfl((int)ent[0], first + e, 64);
+#pragma unroll
+            for (int qd = 0; qd < NQ; ++qd)
+                rows[g].q[qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dtr, (row + 64u * qd + 4u * l16) * 4u, 0, 0));
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t)
+                rows[g].t[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dtr, (row + (unsigned)min(64 * NQ + 16 * t + l16, ldk - 1)) * 4u, 0, 0));
+        }
+    };
+    auto consume = [&](const bu32x4& ent, int first, int n, auto& rows, f32x4 (&ac)[NA], auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (4 * g < n) {                                  // uniform
+                const int e = min(4 * g + k4, n - 1);
+                const int x0 = __shfl((int)ent[1], first + e, 64);
+                float wa = __builtin_bit_cast(float, __shfl((int)ent[2], first + e, 64));
+                float wb = __builtin_bit_cast(float, __shfl((int)ent[3], first + e, 64));
+                if (4 * g + k4 >= n) { wa = 0.f; wb = 0.f; }
+                const int dx = 16 * m + l16 - x0;
+                const float a = dx == 0 ? wa : (dx == 1 ? wb : 0.f);
+#pragma unroll
+                for (int qd = 0; qd < NQ; ++qd)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        ac[4 * qd + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rows[g].q[qd][c], ac[4 * qd + c], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < TAIL; ++t)
+                    ac[4 * NQ + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rows[g].t[t], ac[4 * NQ + t], 0, 0, 0);
+            }
+        }
+    };
+    {
+        Rows r0[EG0], r1[EG1];
+        const int c0 = (int)min(n0, (unsigned)UL_CAP0), c1 = (int)min(n1, (unsigned)UL_CAP1);
+        issue(s0, 1, c0, r0, std::integral_constant<int, EG0>());
+        issue(s1, 1, c1, r1, std::integral_constant<int, EG1>());
+        __builtin_amdgcn_sched_barrier(0);                   // every DT row is in flight before the first use waits
+        consume(s0, 1, c0, r0, acc[0], std::integral_constant<int, EG0>());
+        consume(s1, 1, c1, r1, acc[1], std::integral_constant<int, EG1>());
+    }
+    // lists longer than their slot (a few percent of the units at the training shape): 64 entries per round from the overflow slab
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rest = u ? (int)n1 - UL_CAP1 : (int)n0 - UL_CAP0;
+        const unsigned ob = u ? o1 : o0;
+        for (int e0 = 0; e0 < rest; e0 += 64) {
+            const int n = min(64, rest - e0);
+            const bu32x4 ent = __builtin_amdgcn_raw_buffer_load_b128(pool, (ob + (unsigned)(e0 + min(lane, n - 1))) * 16u, 0, 0);
+            Rows r[16];
+            issue(ent, 0, n, r, std::integral_constant<int, 16>());
+            __builtin_amdgcn_sched_barrier(0);
+            consume(ent, 0, n, r, acc[u], std::integral_constant<int, 16>());
+        }
+    }
+    // acc[u][a][reg] is pixel 16 m + 4 k4 + reg of row jr of destination u; channel 64 qd + 4 l16 + c (a = 4 qd + c), 64 NQ + 16 t + l16 (tail)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float* out = (u == 0 ? prm.d_code : prm.d_code_pos) + (size_t)jr * W * K;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int x = 16 * m + 4 * k4 + reg;
+            if (x < W) {
+                float* px = out + (size_t)x * K;
+#pragma unroll
+                for (int qd = 0; qd < NQ; ++qd) {
+                    const int ch = 64 * qd + 4 * l16;
+                    const f32x4 v = f32x4{acc[u][4 * qd][reg], acc[u][4 * qd + 1][reg], acc[u][4 * qd + 2][reg], acc[u][4 * qd + 3][reg]};
+                    if (ch + 3 < K) {
+                        typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4_a4*>(px + ch));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (ch + c < K) __builtin_nontemporal_store(v[c], px + ch + c);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TAIL; ++t) {
+                    const int ch = 64 * NQ + 16 * t + l16;
+                    if (ch < K) __builtin_nontemporal_store(acc[u][4 * NQ + t][reg], px + ch);
+                }
+            }
+        }
+    }
+    if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+// the lists-first backward covers: forward() semantics, scalar upstreams, split-fp16 GEMMs, maps up to 64 x 64
+bool bwd_lists_supported(const BwdParams& prm)
+{
+    const int nt = (prm.KQ + 15) / 16;
+    const bool split = prm.mode == 0 && !(prm.debug & 512) && (prm.precision == PREC_F16X3 || nt > 5);
+    const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride > 0);
+    return prm.uslots && prm.upool && split && !dense && prm.H <= BF_MAXH && prm.W <= 16 * BF_MAXMT &&
+           !(prm.debug & (32 | 1024)) && (size_t)prm.n_sets * prm.B * 2 * TP * prm.LDK < ((size_t)1 << 30);
+}
+
+hipError_t launch_corr_bwd_lists(const BwdParams& prm_in, hipStream_t stream)
+{
+    BwdParams prm = prm_in;
+    const int nt = (prm.KQ + 15) / 16;
+    const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
+    int lds = SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2;
+    if (lds < BF_LDS_BYTES) lds = BF_LDS_BYTES;
+    const int n_tiles = prm.n_sets * prm.B;
+    prm.n_build = prm.B < 32 ? prm.B : 32;
+    {
+        const dim3 grid(prm.n_build + n_tiles), block(HW_THREADS);
+#define STEGO_BWDL_CASE(N)                                                                                        \
+    case N: {                                                                                                     \
+        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_build_kernel<N>), lds);   \
+        if (ea != hipSuccess) return ea;                                                                          \
+        hipLaunchKernelGGL((corr_bwd_tile_build_kernel<N>), grid, block, lds, stream, prm);                       \
+        break;                                                                                                    \
+    }
+        switch (nt) {
+            STEGO_BWDL_CASE(1)
+            STEGO_BWDL_CASE(2)
+            STEGO_BWDL_CASE(3)
+            STEGO_BWDL_CASE(4)
+            STEGO_BWDL_CASE(5)
+            STEGO_BWDL_CASE(6)
+            STEGO_BWDL_CASE(7)
+            default:
+            STEGO_BWDL_CASE(8)
+        }
+#undef STEGO_BWDL_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int n_pairs = prm.B * prm.H * ((prm.W + 15) >> 4);
+    const dim3 grid((n_pairs + UL_WAVES - 1) / UL_WAVES), block(64 * UL_WAVES);
+    if (prm.K <= 64) hipLaunchKernelGGL((corr_unsample_list_kernel<1, 0>), grid, block, 0, stream, prm);
+    else if (prm.K <= 80) hipLaunchKernelGGL((corr_unsample_list_kernel<1, 1>), grid, block, 0, stream, prm);
+    else hipLaunchKernelGGL((corr_unsample_list_kernel<2, 0>), grid, block, 0, stream, prm);
+    return hipGetLastError();
+}
+
 hipError_t launch_corr_bwd(const BwdParams& prm, hipStream_t stream)
 {
+    if (bwd_lists_supported(prm)) return launch_corr_bwd_lists(prm, stream);
     // ---- tile kernel
     {
         const int cside = TP * prm.LDK * 4;

@@ -110,6 +110,11 @@ struct BwdParams {
     const int4* tapyx;                         //                          bilinear tap pixels [nset][128]
     const float4* tapw;                        //                          bilinear tap weights [nset][128]
     float* dt;                                 // workspace: raw-sample gradients [n_tiles][2][128][LDK]
+    // lists-first backward (corr_bwd_tile_build_kernel + corr_unsample_list_kernel): the unsample's entry lists, in the workspace
+    unsigned* uslots;                          // per (destination, image, pixel row, 16-pixel bin): header {count, overflow start} + the first entries; null = row kernel
+    unsigned* upool;                           // overflow entries {DT row (float index), x0, w_left, w_right}, 16 bytes each
+    unsigned dt_bytes, uslots_bytes, upool_bytes;
+    int n_build;                               // builder workgroups at the front of the tile launch
     int KQ, LDK;
     int g_neg_loss_stride;                     // 1 dense, 0 broadcast scalar
     int B, K, H, W, S, P, n_neg, n_sets;
