@@ -1244,7 +1244,16 @@ __global__ void __launch_bounds__(64 * UL_WAVES) corr_unsample_list_kernel(const
     const int B = prm.B, H = prm.H, W = prm.W, K = prm.K, ldk = prm.LDK;
     const int MT = (W + 15) >> 4;
     const int n_pairs = B * H * MT;
-    const int k = blockIdx.x * UL_WAVES + wave;
+    // every unit of image j on XCD j % 8 (block b runs on XCD b % 8: observed, used for speed only): the builder of image j and the tiles
+    // of anchor j ran there, and plain stores leave their lines in that L2 across the kernel boundary (measured -1 us per step)
+    int k;
+    {
+        const int upi = H * MT, wpi = (upi + UL_WAVES - 1) / UL_WAVES;
+        const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+        const int j = (sl / wpi) * 8 + x, u = (sl % wpi) * UL_WAVES + wave;
+        if (j >= B || u >= upi) return;
+        k = j * upi + u;
+    }
     if (k >= n_pairs) return;
     const int l16 = lane & 15, k4 = lane >> 4;
     const __amdgpu_buffer_rsrc_t pool = bf_rsrc(prm.upool, prm.upool_bytes);
@@ -1406,8 +1415,8 @@ hipError_t launch_corr_bwd_lists(const BwdParams& prm_in, hipStream_t stream)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const int n_pairs = prm.B * prm.H * ((prm.W + 15) >> 4);
-    const dim3 grid((n_pairs + UL_WAVES - 1) / UL_WAVES), block(64 * UL_WAVES);
+    const int upi = prm.H * ((prm.W + 15) >> 4), wpi = (upi + UL_WAVES - 1) / UL_WAVES;
+    const dim3 grid(((prm.B + 7) / 8) * 8 * wpi), block(64 * UL_WAVES);
     if (prm.K <= 64) hipLaunchKernelGGL((corr_unsample_list_kernel<1, 0>), grid, block, 0, stream, prm);
     else if (prm.K <= 80) hipLaunchKernelGGL((corr_unsample_list_kernel<1, 1>), grid, block, 0, stream, prm);
     else hipLaunchKernelGGL((corr_unsample_list_kernel<2, 0>), grid, block, 0, stream, prm);

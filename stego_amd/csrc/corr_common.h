@@ -120,7 +120,7 @@ struct BwdParams {
     int B, K, H, W, S, P, n_neg, n_sets;
     int mode;
     int precision;                             // PREC_*: F16X3 = the tile kernel's GEMMs as split-fp16 products (mode 0)
-    int debug;                                 // 1 skip MFMA, 2 skip scatter, 4 / 16 load ablations, 8 stamps, 32 band unsample, 64 / 128 unsample ablations, 512 fp32-MFMA tile kernel
+    int debug;                                 // 1 skip MFMA, 2 skip scatter, 4 / 16 load ablations, 8 stamps, 32 band unsample, 64 / 128 unsample ablations, 512 fp32-MFMA tile kernel, 1024 tile + row kernels instead of lists first
     float cmin, cmax;
 };
 

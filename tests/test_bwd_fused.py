@@ -1,7 +1,7 @@
 """The lists-first backward (corr_bwd_tile_build_kernel: builders beside the tiles; corr_unsample_list_kernel: one wave per
 destination unit, csrc/corr_bwd.hip) against the fp64 oracle's autograd restatement (reference: autograd through
 src/modules.py:325-347, 369-391) and against the tile + row kernels it replaces, through the C ABI.  Needs the MI355X."""
-from ctypes import byref
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +14,7 @@ from stego_amd import capi
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+BASE = int(os.environ.get("STEGO_DEBUG_BWD", "0"))     # (tools: variants of the kernels under test)
 TWO_LAUNCHES = 1024          # STEGO_DEBUG_BWD bit: take the plain tile kernel + the row kernel (three dependent rounds per unit)
 
 
@@ -46,7 +47,7 @@ class _Case:
     def backward(self, g_intra=0.67, g_inter=0.25, g_neg=0.63, two_launches=False):
         B, C, H, W, K, S, n_neg = self.dims
         t = self.t
-        capi.debug_set("STEGO_DEBUG_BWD", TWO_LAUNCHES if two_launches else 0)
+        capi.debug_set("STEGO_DEBUG_BWD", TWO_LAUNCHES if two_launches else BASE)
         try:
             gi = torch.tensor(g_intra, device=DEV)
             ge = torch.tensor(g_inter, device=DEV)
@@ -56,7 +57,7 @@ class _Case:
                                     self.icd, self.ecd, self.ncd, gi, ge, gnl, None, None, None)
             torch.cuda.synchronize()
         finally:
-            capi.debug_set("STEGO_DEBUG_BWD", 0)
+            capi.debug_set("STEGO_DEBUG_BWD", BASE)
         return dc.contiguous().cpu().numpy(), dcp.contiguous().cpu().numpy()
 
     def oracle(self, g_intra=0.67, g_inter=0.25, g_neg=0.63):

@@ -19,7 +19,7 @@ lm, icd, ecd, nl, ncd, saved = out
 sw, sm, sctx = saved
 g_intra = torch.tensor(0.67, device=dev); g_inter = torch.tensor(0.25, device=dev)
 g_neg = torch.full((1,), 0.63 / (n_neg * B * S ** 4), device=dev)
-capi.debug_set("STEGO_DEBUG_BWD", 8)
+capi.debug_set("STEGO_DEBUG_BWD", int(os.environ.get("SDB", "8")))
 nws = lib.stego_corr_bwd_workspace_bytes(byref(desc))
 ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
 dc = torch.empty(B, H, W, K, device=dev); dcp = torch.empty(B, H, W, K, device=dev)
