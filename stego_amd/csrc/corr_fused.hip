@@ -50,13 +50,6 @@
 #include "corr_tile.h"
 #include "host_util.h"
 
-#ifndef STEGO_EARLY_CD
-#define STEGO_EARLY_CD 0
-#endif
-#ifndef STEGO_PF_COORDS
-#define STEGO_PF_COORDS 0
-#endif
-
 namespace stego {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -752,14 +745,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     if (tid == 0) { tile_slot[0] = -1; team_cnt[0] = 0u; fin[1] = 0.f; }       // fin[1]: the tail saw a hand-off word time out
     __syncthreads();
 
-#if STEGO_PF_COORDS
     // the gather waves that wait for the tile (5 .. 11) pull coords2 into this CU's L1 meanwhile: the tap tables are then built from
-    // L1 hits instead of a cold round trip (the gather stream - the critical path - starts that much earlier)
+    // L1 hits instead of a cold round trip (the gather stream - the critical path - starts that much earlier: -1.0 us same box, r04d)
     if (!helper && wave8 >= 5) {
         const int idx = 32 * ((wave8 - 5) * 64 + lane);
         if (idx < B * P * 2) { const float x = prm.coords2[idx]; asm volatile("" :: "v"(x)); }
     }
-#endif
     // ---- phase 1 (the MFMA team, 4 waves): my share of the anchor sets of my XCD, 2 G points per wave and pass.  The team
     // syncs through an LDS counter, not s_barrier: the gather team is not part of it - it works out the tile, builds its tap
     // table and fills the B sides of the first four ring slots meanwhile (none of which needs an anchor).
@@ -957,25 +948,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             else mma_stage_fh(As, sameAB ? As : As + RS_SIDE, kper, accc, lane, wr, wc);
             TL(n, 3);
         }
-#if STEGO_EARLY_CD
-        // cd is final once the last code chunk is multiplied: it leaves NOW, straight from the accumulators (32 consecutive floats of a
-        // row per half-wave), twelve stages before the sweep - whose stores (36 MB chip-wide within ~6 us) are what the way out waits for.
-        // cscc: finish_codes ran in the gather team's static head, before B(0); a self-correlation tile's B side is its normalised A side.
-        {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = 64 * wc + 32 * ni + (lane & 31);
-                const float sc = sameAB ? 1.f : cscc[col];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < P && col < P) __builtin_nontemporal_store(accc[mi][ni][r] * sc, cd_out + row * P + col);
-                    }
-            }
-        }
-#endif
         // ... then the feature stages
         zero_acc(accf);
 #pragma unroll 1
@@ -1322,17 +1294,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         if (vec_ok && ok[0] && ok[3]) {
             // streaming stores: nobody in this launch reads the outputs again, and lines that never become dirty in the
             // L2s do not have to be written back when the kernel ends
-#if !STEGO_EARLY_CD
             __builtin_nontemporal_store(cd4, reinterpret_cast<f32x4*>(cd_out + e0));
-#endif
             if (w_out) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(w_out + e0));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (ok[k]) {
-#if !STEGO_EARLY_CD
                     cd_out[e0 + k] = cd4[k];
-#endif
                     if (w_out) w_out[e0 + k] = w4[k];
                 }
         }
