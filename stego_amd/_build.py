@@ -103,10 +103,13 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
 def build_torchglue(force=False, verbose=False):
     """Compile csrc/torch_glue_ext.cpp against the installed torch (pybind11 module, no device code) -> lib/_stego_torchglue.so."""
     deps = [TORCHGLUE_SRC, os.path.join(CSRC, "..", "..", "include", "stego_corr.h")]
-    if not force and os.path.exists(TORCHGLUE_PATH) and all(os.path.getmtime(TORCHGLUE_PATH) >= os.path.getmtime(d) for d in deps):
-        return TORCHGLUE_PATH
     import sysconfig
     import torch
+    stamp = TORCHGLUE_PATH + ".torch"          # the torch build the extension was compiled against: another one makes it stale
+    built_for = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if not force and os.path.exists(TORCHGLUE_PATH) and built_for == torch.__version__ and \
+            all(os.path.getmtime(TORCHGLUE_PATH) >= os.path.getmtime(d) for d in deps):
+        return TORCHGLUE_PATH
     from torch.utils import cpp_extension
     os.makedirs(LIB_DIR, exist_ok=True)
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
@@ -122,6 +125,8 @@ def build_torchglue(force=False, verbose=False):
     if res.returncode != 0:
         raise RuntimeError("g++ failed on %s:\n%s%s" % (TORCHGLUE_SRC, res.stdout, res.stderr))
     os.replace(TORCHGLUE_PATH + ".tmp", TORCHGLUE_PATH)
+    with open(stamp, "w") as f:
+        f.write(torch.__version__)
     return TORCHGLUE_PATH
 
 

@@ -147,6 +147,8 @@ def _check(rc):
     if rc != 0:
         _WS_CACHE.clear()            # a kept workspace may hold dirty hand-off words after a failed launch
         _WS_PINNED.clear()
+        if _torchglue_mod:           # ... and so may the ones the C++ autograd function keeps
+            _torchglue_mod.reset_workspaces()
         msg = load().stego_error_string(rc).decode()
         raise RuntimeError("libstego_corr error %d: %s" % (rc, msg))
 
@@ -339,11 +341,17 @@ def torchglue():
         else:
             import importlib.util
             load()
-            spec = importlib.util.spec_from_file_location("_stego_torchglue", path)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            mod.bind(_build.LIB_PATH)
-            _torchglue_mod = mod
+            try:
+                spec = importlib.util.spec_from_file_location("_stego_torchglue", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.bind(_build.LIB_PATH)
+                _torchglue_mod = mod
+            except (ImportError, OSError, RuntimeError) as e:      # e.g. a stale build against another torch: the product runs without it
+                import warnings
+                warnings.warn("stego_amd: %s does not load (%s: %s) - using the Python autograd function; rebuild with "
+                              "stego_amd._build.build_torchglue(force=True)" % (path, type(e).__name__, str(e)[:200]))
+                _torchglue_mod = False
     return _torchglue_mod or None
 
 

@@ -80,8 +80,12 @@ void bind(const std::string& path)
                 STEGO_ABI_VERSION);
 }
 
+void reset_workspaces();
+
+// A failed or aborted launch can leave the hand-off words of a prepared workspace dirty: nothing cached survives an error.
 void check(int rc, const char* what)
 {
+    if (rc != STEGO_OK) reset_workspaces();
     TORCH_CHECK(rc == STEGO_OK, what, ": ", L.error_string(rc), " (", rc, ")");
 }
 
@@ -150,13 +154,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> ref_draws(const at::Generator& ge
 // that must be zero when a launch starts and that every launch leaves zero again (stego_corr_workspace_prepare once, then one launch
 // per call).  A workspace first met during a capture is prepared on the library's side stream (stego_corr_workspace_prepare_now)
 // instead of as a memset node in every replay.
-std::mutex ws_mutex;
+std::recursive_mutex ws_mutex;
 std::map<std::tuple<int, uintptr_t, std::string>, at::Tensor> ws_cache;
 std::set<std::tuple<int, uintptr_t, std::string>> ws_pinned;       // first used during a stream capture: never evicted
 
 at::Tensor prepared_workspace(const StegoCorrDesc& d, const std::string& desc_bytes, const at::Device& dev, hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lock(ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ws_mutex);
     const auto key = std::make_tuple((int)dev.index(), reinterpret_cast<uintptr_t>(stream), desc_bytes);
     auto it = ws_cache.find(key);
     if (it != ws_cache.end()) return it->second;
@@ -181,7 +185,7 @@ at::Tensor prepared_workspace(const StegoCorrDesc& d, const std::string& desc_by
 
 void reset_workspaces()
 {
-    std::lock_guard<std::mutex> lock(ws_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ws_mutex);
     ws_cache.clear();
     ws_pinned.clear();
 }

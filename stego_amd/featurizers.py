@@ -287,10 +287,15 @@ class DinoFeaturizer(nn.Module):
     def _native_head_ok(self, image_feat):
         """The hand-written head kernels (include/stego_head.h) take channels-last fp32 token maps on a HIP device; cfg.native_head
         (default True) turns them off."""
-        return (image_feat.is_cuda and image_feat.dtype == torch.float32 and image_feat.stride(1) == 1 and image_feat.dim() == 4
+        if not (image_feat.is_cuda and image_feat.dtype == torch.float32 and image_feat.dim() == 4 and image_feat.stride(1) == 1
                 and getattr(self.cfg, "native_head", True) and image_feat.shape[1] % 32 == 0 and self.dim <= 128
                 and image_feat.stride(3) % 4 == 0 and image_feat.stride(0) % 4 == 0
-                and image_feat.stride(2) == image_feat.shape[3] * image_feat.stride(3))
+                and image_feat.stride(2) == image_feat.shape[3] * image_feat.stride(3)):
+            return False
+        # the limits of head_check (csrc/head_fused.hip: at least 16 tokens per image, 32-bit byte offsets): maps beyond them - a 2 x 2
+        # token map of a 32-pixel crop, say - run through the torch head (self._head), as they did before the native head existed
+        B, C, fh, fw = image_feat.shape
+        return fh * fw >= 16 and B * fh * fw < (1 << 30) and B * fh * fw * C < (1 << 30)
 
     def _head_native(self, image_feat, tokens_amax=None):
         """forward()'s tail on the native head: (feats, code) exactly as modules.py:108-116 returns them.  The three Dropout2d draws are

@@ -347,6 +347,20 @@ class _HelperFunction(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- the loss
+_PAIR_SET_BOUND = []
+
+
+def _pair_set_bound():
+    """Largest batch of the single-launch forward: the tiles of one pair-set run at the same time, one per compute unit
+    (fused_supported, csrc/corr_fused.hip: device_cu_count() & ~7) - 256 on a whole MI355X, fewer on a partitioned one."""
+    if not _PAIR_SET_BOUND:
+        n = 256
+        if torch.cuda.is_available():
+            n = max(8, torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count & ~7)
+        _PAIR_SET_BOUND.append(n)
+    return _PAIR_SET_BOUND[0]
+
+
 class ContrastiveCorrelationLoss(nn.Module):
     """Drop-in for the reference class (modules.py:314-398); same cfg keys:
     feature_samples, neg_samples, pointwise, zero_clamp, stabalize, use_salience,
@@ -397,7 +411,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         if S * S > 128 or K > 128 or H > 32767 or W > 32767:
             return False
         if K > 72:
-            return K % 2 == 0 and C in (384, 768) and B <= 256 and H <= 256 and W <= 256
+            return K % 2 == 0 and C in (384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
         return True
 
     def generic_helper(self, f1, f2, c1, c2, shift):

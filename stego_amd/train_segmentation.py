@@ -54,7 +54,6 @@ def load_config(path=None, overrides=()):
 MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: even, channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
 MAX_CODE_DIM_ANY_PATH = 72       # above it: the single-launch forward only (its conditions are checked in __init__)
-MI355X_COMPUTE_UNITS = 256
 
 
 class LitUnsupervisedSegmenter(nn.Module):
@@ -99,18 +98,22 @@ class LitUnsupervisedSegmenter(nn.Module):
                               % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
             if MAX_CODE_DIM_ANY_PATH < dim <= MAX_CODE_DIM:
                 # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
-                # csrc/corr_fused.hip): the same conditions here, with the cfg keys named
+                # csrc/corr_fused.hip); what it does not take runs on generic_forward like dim > 128 does (fused_kernels_cover decides per
+                # call, from the tensors): the same conditions here, with the cfg keys named, as a warning
+                from .modules import _pair_set_bound
                 why = []
                 if dim % 2:
-                    why.append("cfg.dim must be even")
+                    why.append("cfg.dim is odd")
                 if cfg.arch != "dino":
-                    why.append("cfg.arch must be 'dino' (channels-last feature maps of width 384 / 768)")
-                if cfg.batch_size > MI355X_COMPUTE_UNITS:
-                    why.append("cfg.batch_size = %d must not exceed the %d compute units (the tiles of one pair-set run at the "
-                               "same time)" % (cfg.batch_size, MI355X_COMPUTE_UNITS))
+                    why.append("cfg.arch is not 'dino' (channels-last feature maps of width 384 / 768)")
+                if cfg.batch_size > _pair_set_bound():
+                    why.append("cfg.batch_size = %d exceeds the %d compute units (the tiles of one pair-set run at the same time)"
+                               % (cfg.batch_size, _pair_set_bound()))
                 if why:
-                    raise ValueError("cfg.dim=%d: code dimensions above %d run on the single-launch forward only: %s"
-                                     % (dim, MAX_CODE_DIM_ANY_PATH, "; ".join(why)))
+                    import warnings
+                    warnings.warn("cfg.dim=%d: code dimensions above %d run on the single-launch forward only, and %s: this configuration "
+                                  "runs on ContrastiveCorrelationLoss.generic_forward: same results, several times slower"
+                                  % (dim, MAX_CODE_DIM_ANY_PATH, "; ".join(why)))
         for p in self.contrastive_corr_loss_fn.parameters():
             p.requires_grad = False
         self.automatic_optimization = False

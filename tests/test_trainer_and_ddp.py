@@ -325,14 +325,14 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
 
 def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():
     """cfg.dim > 128 / cfg.feature_samples > 11 are valid in the reference (train_config.yml:39,51 are free): they run on the generic
-    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; 72 < dim <= 128 with an odd dim (a
-    shape only the single-launch kernel could take, and cannot) still fails early."""
+    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 with an odd
+    dim (a shape only the single-launch kernel could take, and cannot): valid in the reference, it runs on the generic path too."""
     for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=12"], "cfg.feature_samples=12")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.warns(UserWarning, match=key):
             LitUnsupervisedSegmenter(5, cfg)
     cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "dim=99"])
-    with pytest.raises(ValueError, match="cfg.dim=99"):
+    with pytest.warns(UserWarning, match="cfg.dim=99"):
         LitUnsupervisedSegmenter(5, cfg)
 
 
