@@ -395,8 +395,12 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
                         const bool in = grp * CTR + ch < K;
                         unsigned h, l;
                         split_f16_pair(in ? r0[side][it][e] : 0.f, in ? r1[side][it][e] : 0.f, h, l);
-                        *reinterpret_cast<unsigned*>(dh + ch * HB_LDR + 2 * pp) = h;
-                        *reinterpret_cast<unsigned*>(dl + ch * HB_LDR + 2 * pp) = l;
+                        // (4-point groups of a channel row XOR-swizzled by ch >> 4: the 20 channel groups of a wave's store
+                        // otherwise fall into 4 banks - rows are 68 dwords apart - a 5-way conflict on each of the 48 stores per lane;
+                        // ch >> 4 is the MFMA's channel tile mc, so the fragment reads below stay conflict-free)
+                        const int col = (((pp >> 1) ^ (ch >> 4)) << 2) + 2 * (pp & 1);
+                        *reinterpret_cast<unsigned*>(dh + ch * HB_LDR + col) = h;
+                        *reinterpret_cast<unsigned*>(dl + ch * HB_LDR + col) = l;
                     }
                 }
             }
@@ -512,8 +516,9 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
                 f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
                 for (int mc = 0; mc < NTG; ++mc) {
-                    ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + kk);
-                    al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + kk);
+                    const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;          // swizzled 4-point group (see convert_codes)
+                    ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + ks);
+                    al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + ks);
                 }
 #pragma unroll
                 for (int np = 0; np < HW_NP; ++np) {
@@ -547,8 +552,9 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
                 f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
                 for (int mc = 0; mc < NTG; ++mc) {
-                    ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + kk);
-                    al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + kk);
+                    const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;
+                    ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + ks);
+                    al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + ks);
                 }
 #pragma unroll
                 for (int np = 0; np < HW_NP; ++np) {
