@@ -69,9 +69,8 @@ __device__ __forceinline__ void normalize_bwd_store(f32x4 (&d)[2][NT], const flo
 }
 
 template <int NT>
-__global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams prm)
+__device__ __forceinline__ void bwd_tile_body(const BwdParams& prm, const int tile, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int ldk = prm.LDK;
     const int cside = TP * ldk * 4;
     float* nrm = reinterpret_cast<float*>(smem + SMB_NRM);
@@ -83,7 +82,6 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int B = prm.B, P = prm.P, K = prm.K;
-    const int tile = blockIdx.x;
     const int b = tile % B, p = tile / B;
     const bool direct = prm.mode == 1;
     const bool sameAB = !direct && p == 0;
@@ -92,8 +90,8 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     const float* Bn = sameAB ? An : reinterpret_cast<const float*>(Bn_b);
 
     // debug bit 8: phase stamps (100 MHz global clock), 4 per tile, second half of the workspace tail
-    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)blockIdx.x * 4;
-    const bool stamp_on = (prm.debug & 8) && tid == 0 && blockIdx.x < 1024;
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(prm.dt + (size_t)prm.n_sets * B * 2 * TP * ldk) + 4096 + (size_t)tile * 4;
+    const bool stamp_on = (prm.debug & 8) && tid == 0 && tile < 1024;
     if (stamp_on) ts[0] = __builtin_amdgcn_s_memrealtime();
     // ---- async copies of the normalised sampled codes (saved by the forward) + their norms
     {
@@ -237,6 +235,13 @@ __global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
 }
 
+template <int NT>
+__global__ void __launch_bounds__(NTHREADS) corr_bwd_tile_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bwd_tile_body<NT>(prm, (int)blockIdx.x, smem);
+}
+
 // ------------------------------------------------------------------------------- tile kernel, split-fp16 GEMMs
 // The same backward with the two code GEMMs on the fp16 matrix cores (forward() semantics: precision F16X3, and any mode once
 // K > 80; the fp32 MFMA of the kernel above runs at the VALU rate on gfx950: 2 x 4.3 us per tile).  Every fp32 operand is
@@ -265,7 +270,7 @@ constexpr int HW_NP = TP / (16 * HW_WAVES);           // 16-point tiles per wave
 template <int NT>
 __device__ __forceinline__ void normalize_bwd_store_t(f32x4 (&d)[NT][HW_NP], const float* __restrict__ Cn, int ldk,
                                                       const float* __restrict__ nrm, float* __restrict__ dt_out,
-                                                      int K, int KQ, int lane, int wave)
+                                                      int K, int KQ, int lane, int wave, bool wt = false)
 {
     const int cl = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -299,7 +304,10 @@ __device__ __forceinline__ void normalize_bwd_store_t(f32x4 (&d)[NT][HW_NP], con
                     v[reg] = big ? (dn - cn[mc][reg] * dot) * inv : dn * inv;
                     if (ch0 + reg >= K) v[reg] = 0.f;
                 }
-                *reinterpret_cast<f32x4*>(dt_out + (size_t)pt * ldk + ch0) = v;
+                float* dst = dt_out + (size_t)pt * ldk + ch0;
+                // wt: written through (16-byte sc1 store, the cost of a plain one) instead of staying dirty in the L2 until the launch ends
+                if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+                else *reinterpret_cast<f32x4*>(dst) = v;
             }
         }
     }
@@ -490,6 +498,7 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
     float* dtA = prm.dt + ((size_t)tile * 2 + 0) * TP * ldk;
     const bool skip = (prm.debug & 1) || tmax == 0.f; // (no upstream: G = 0, the gradients are zero)
 
+    const bool early_dB = NG == 1 && !sameAB && !skip && !(prm.debug & 2048);      // (debug 2048: both sides at the end, plain)
     f32x4 dAt[NT][HW_NP], dBt[NT][HW_NP];
 #pragma unroll
     for (int mc = 0; mc < NT; ++mc)
@@ -506,80 +515,99 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
         __syncthreads();                              // CT of this group (and, the first time, G) complete
         if (stamp_on && grp == 0) ts[1] = __builtin_amdgcn_s_memrealtime();
         if (skip) continue;
-        // ---- dAn^T = Bn^T . G^T: channel rows of CT(B) (A operand) against the ROWS 16 (HW_NP wave + np) + j of G (B operand:
-        // B[k][j] = G[j][k], k-contiguous in a row-major G)
-        {
-            const int ra = cl * HB_LDR + 4 * kq;
-            const int rg = (16 * HW_NP * wave + cl) * HB_LDR + 4 * kq;
+        auto gemm_dA = [&]() {
+            // ---- dAn^T = Bn^T . G^T: channel rows of CT(B) (A operand) against the ROWS 16 (HW_NP wave + np) + j of G (B operand:
+            // B[k][j] = G[j][k], k-contiguous in a row-major G)
+            {
+                const int ra = cl * HB_LDR + 4 * kq;
+                const int rg = (16 * HW_NP * wave + cl) * HB_LDR + 4 * kq;
 #pragma unroll 2
-            for (int kk = 0; kk < TP; kk += 16) {
-                f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
+                for (int kk = 0; kk < TP; kk += 16) {
+                    f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
-                for (int mc = 0; mc < NTG; ++mc) {
-                    const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;          // swizzled 4-point group (see convert_codes)
-                    ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + ks);
-                    al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + ks);
+                    for (int mc = 0; mc < NTG; ++mc) {
+                        const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;          // swizzled 4-point group (see convert_codes)
+                        ah[mc] = *reinterpret_cast<const f16x4*>(BTh + ra + 16 * mc * HB_LDR + ks);
+                        al[mc] = *reinterpret_cast<const f16x4*>(BTl + ra + 16 * mc * HB_LDR + ks);
+                    }
+#pragma unroll
+                    for (int np = 0; np < HW_NP; ++np) {
+                        bh[np] = *reinterpret_cast<const f16x4*>(Gh + rg + 16 * np * HB_LDR + kk);
+                        bl[np] = *reinterpret_cast<const f16x4*>(Gl + rg + 16 * np * HB_LDR + kk);
+                    }
+                    // the three terms outermost: consecutive MFMAs never wait for each other's accumulator
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int mc = 0; mc < NTG; ++mc)
+#pragma unroll
+                            for (int np = 0; np < HW_NP; ++np)
+                                if (grp * NTG + mc < NT)
+                                    dAt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                                        term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dAt[grp * NTG + mc][np], 0, 0, 0);
                 }
-#pragma unroll
-                for (int np = 0; np < HW_NP; ++np) {
-                    bh[np] = *reinterpret_cast<const f16x4*>(Gh + rg + 16 * np * HB_LDR + kk);
-                    bl[np] = *reinterpret_cast<const f16x4*>(Gl + rg + 16 * np * HB_LDR + kk);
-                }
-                // the three terms outermost: consecutive MFMAs never wait for each other's accumulator
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int mc = 0; mc < NTG; ++mc)
-#pragma unroll
-                        for (int np = 0; np < HW_NP; ++np)
-                            if (grp * NTG + mc < NT)
-                                dAt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
-                                    term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dAt[grp * NTG + mc][np], 0, 0, 0);
             }
-        }
-        // ---- dBn^T = An^T . G: channel rows of CT(A) against the COLUMNS 16 (HW_NP wave + np) + j of G (k = anchor point),
-        // gathered as 4 x 2 bytes per lane and step
-        {
-            const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
-            // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl - four ROWS of one column per lane: the LDS transposes
-            // (ds_read_b64_tr_b16: lane p of a 16-lane group passes the address of row p >> 2, columns 4 (p & 3) .. + 3 of a
-            // [4 rows][16 columns] block and receives column p, rows 0..3; one read per fragment instead of four 2-byte reads)
-            const int gt = (4 * kq + (cl >> 2)) * HB_LDR + 16 * HW_NP * wave + 4 * (cl & 3);
-            typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
-            typedef __attribute__((address_space(3))) fp16x4v* lds_tr_ptr;
+        };
+        auto gemm_dB = [&]() {
+            // ---- dBn^T = An^T . G: channel rows of CT(A) against the COLUMNS 16 (HW_NP wave + np) + j of G (k = anchor point),
+            // gathered as 4 x 2 bytes per lane and step
+            {
+                const int ra = cl * HB_LDR + 4 * kq;                          // CT(A): channel cl (+16 mc), k = kk + 4 kq ..
+                // G: row kk + 4 kq + e, column 16 (HW_NP wave + np) + cl - four ROWS of one column per lane: the LDS transposes
+                // (ds_read_b64_tr_b16: lane p of a 16-lane group passes the address of row p >> 2, columns 4 (p & 3) .. + 3 of a
+                // [4 rows][16 columns] block and receives column p, rows 0..3; one read per fragment instead of four 2-byte reads)
+                const int gt = (4 * kq + (cl >> 2)) * HB_LDR + 16 * HW_NP * wave + 4 * (cl & 3);
+                typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+                typedef __attribute__((address_space(3))) fp16x4v* lds_tr_ptr;
 #pragma unroll 2
-            for (int kk = 0; kk < TP; kk += 16) {
-                f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
+                for (int kk = 0; kk < TP; kk += 16) {
+                    f16x4 ah[NTG], al[NTG], bh[HW_NP], bl[HW_NP];
 #pragma unroll
-                for (int mc = 0; mc < NTG; ++mc) {
-                    const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;
-                    ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + ks);
-                    al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + ks);
+                    for (int mc = 0; mc < NTG; ++mc) {
+                        const int ks = ((((kk >> 2) + kq) ^ mc) << 2) - 4 * kq;
+                        ah[mc] = *reinterpret_cast<const f16x4*>(ATh + ra + 16 * mc * HB_LDR + ks);
+                        al[mc] = *reinterpret_cast<const f16x4*>(ATl + ra + 16 * mc * HB_LDR + ks);
+                    }
+#pragma unroll
+                    for (int np = 0; np < HW_NP; ++np) {
+                        const fp16x4v th = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gh + gt + kk * HB_LDR + 16 * np));
+                        const fp16x4v tl = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gl + gt + kk * HB_LDR + 16 * np));
+                        __builtin_memcpy(&bh[np], &th, 8);
+                        __builtin_memcpy(&bl[np], &tl, 8);
+                    }
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int mc = 0; mc < NTG; ++mc)
+#pragma unroll
+                            for (int np = 0; np < HW_NP; ++np)
+                                if (grp * NTG + mc < NT)
+                                    dBt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                                        term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dBt[grp * NTG + mc][np], 0, 0, 0);
                 }
-#pragma unroll
-                for (int np = 0; np < HW_NP; ++np) {
-                    const fp16x4v th = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gh + gt + kk * HB_LDR + 16 * np));
-                    const fp16x4v tl = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(Gl + gt + kk * HB_LDR + 16 * np));
-                    __builtin_memcpy(&bh[np], &th, 8);
-                    __builtin_memcpy(&bl[np], &tl, 8);
-                }
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int mc = 0; mc < NTG; ++mc)
-#pragma unroll
-                        for (int np = 0; np < HW_NP; ++np)
-                            if (grp * NTG + mc < NT)
-                                dBt[grp * NTG + mc][np] = __builtin_amdgcn_mfma_f32_16x16x16f16(
-                                    term == 2 ? al[mc] : ah[mc], term == 1 ? bl[np] : bh[np], dBt[grp * NTG + mc][np], 0, 0, 0);
             }
+        };
+        if (early_dB) {
+            // The B side first: its rows leave (normalised, written through) while the A side is multiplied, so half of the DT bytes are
+            // out of the L2 before the launch ends - what is still dirty then is written back behind the last workgroup, in front of the
+            // unsample launch.  The A-side rows stay plain: the unsample units of this anchor's image run on this XCD and hit them in L2.
+            gemm_dB();
+#pragma unroll
+            for (int mc = 0; mc < NT; ++mc)
+#pragma unroll
+                for (int np = 0; np < HW_NP; ++np) dBt[mc][np] *= inv_tile;
+            normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave, true);
+            gemm_dA();
+        } else {
+            gemm_dA();
+            gemm_dB();
         }
     }
     if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int mc = 0; mc < NT; ++mc)
 #pragma unroll
-        for (int np = 0; np < HW_NP; ++np) { dAt[mc][np] *= inv_tile; dBt[mc][np] *= inv_tile; }
+        for (int np = 0; np < HW_NP; ++np) { dAt[mc][np] *= inv_tile; if (!early_dB) dBt[mc][np] *= inv_tile; }
     if (sameAB) {
         // c1 is c2: both adjoints hit the same samples (same register layout: just add)
 #pragma unroll
@@ -589,7 +617,7 @@ __device__ __forceinline__ void bwd_tile_h_body(const BwdParams& prm, const int 
         normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
     } else {
         normalize_bwd_store_t<NT>(dAt, csA, ldk, nrm, dtA, K, prm.KQ, lane, wave);
-        normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
+        if (!early_dB) normalize_bwd_store_t<NT>(dBt, csB, ldk, nrm + TP, dtA + (size_t)TP * ldk, K, prm.KQ, lane, wave);
     }
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1052,7 +1080,7 @@ constexpr int BFS_OVF = BFS_HIST + HW_WAVES * BF_NKEY * 4;            // unsigne
 constexpr int BFS_SCAN = BFS_OVF + BF_NKEY * 4;                       // unsigned[HW_WAVES + 1] partial sums of the block scan
 constexpr int BFS_MISC = BFS_SCAN + 64;                               // int[4]: items of dest 0, overflow slab of dest 0 / dest 1
 constexpr int BF_LDS_BYTES = BFS_MISC + 64;
-static_assert(BF_NKEY == HW_THREADS, "one thread per list key in the prefix");
+static_assert(BF_NKEY % HW_THREADS == 0 && BF_NKEY % NTHREADS == 0, "whole keys per thread in the prefix");
 
 typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
 
@@ -1066,6 +1094,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigne
 // by list key, in LDS: wave w owns the item halves w, w + 8, ...; counts per (wave, key), a block-wide prefix, then every element
 // takes its slot with a returning LDS add on its wave's OWN counter - lanes of one instruction that hit the same counter are
 // served in an order the hardware fixes (no other wave touches it), so the lists come out the same launch after launch.
+template <int NW>        // waves of the workgroup: 8 beside the split-fp16 tiles, 4 beside the fp32 ones
 __device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int bi, unsigned char* smem)
 {
     int2* items = reinterpret_cast<int2*>(smem + BFS_ITEMS);
@@ -1113,7 +1142,7 @@ __device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int
                 misc[2] = (int)(EPI * (unsigned)(prm.n_sets * B + n_negc + j));
             }
         }
-        for (int i = tid; i < HW_WAVES * BF_NKEY; i += HW_THREADS) hist[i] = 0u;
+        for (int i = tid; i < NW * BF_NKEY; i += (64 * NW)) hist[i] = 0u;
         __syncthreads();
         const int n0 = misc[0], n_ih = 2 * (n0 + 1);         // item halves: 64 points each
         const unsigned slab0 = (unsigned)misc[1], slab1 = (unsigned)misc[2];
@@ -1130,16 +1159,16 @@ __device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int
             key[3] = v && y0 + 1 < H && b1 >= 0 ? r1 + b1 : -1;
         };
         // ---- pass 0: counts per (wave, key)
-        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * HW_WAVES) {
+        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * NW) {
             int wd[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ih = min(ih0 + u * HW_WAVES, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
+                const int ih = min(ih0 + u * NW, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
                 wd[u] = reinterpret_cast<const int*>(prm.tapyx + (size_t)items[it].x * TP + q)[0];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ih = ih0 + u * HW_WAVES;
+                const int ih = ih0 + u * NW;
                 if (ih < n_ih) {                             // uniform
                     int key[4];
                     point_keys((ih >> 1) >= n0, (ih & 1) * 64 + lane, wd[u], key);
@@ -1150,17 +1179,23 @@ __device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int
             }
         }
         __syncthreads();
-        // ---- prefix: thread k owns key k.  A list's first UL_CAP entries live in the unit's slot, the rest in the image's overflow
-        // slab (lists in key order per destination); inside a list the waves come in order
+        // ---- prefix: thread t owns the keys t KPT .. t KPT + KPT - 1.  A list's first UL_CAP entries live in the unit's slot, the rest in
+        // the image's overflow slab (lists in key order per destination); inside a list the waves come in order
         {
+            constexpr int KPT = BF_NKEY / (64 * NW);
             const int kd1 = H * BF_MAXMT;                    // first key of dest 1
-            const bool d1 = tid >= kd1;
-            const unsigned cap = d1 ? UL_CAP1 : UL_CAP0;
-            unsigned c[HW_WAVES], tot = 0u;
+            unsigned c[KPT][NW], tot[KPT], over[KPT], osum = 0u;
 #pragma unroll
-            for (int w = 0; w < HW_WAVES; ++w) { c[w] = hist[w * BF_NKEY + tid]; tot += c[w]; }
-            const unsigned over = tot > cap ? tot - cap : 0u;
-            unsigned inc = over;
+            for (int i = 0; i < KPT; ++i) {
+                const int key = tid * KPT + i;
+                tot[i] = 0u;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { c[i][w] = hist[w * BF_NKEY + key]; tot[i] += c[i][w]; }
+                const unsigned cap = key >= kd1 ? UL_CAP1 : UL_CAP0;
+                over[i] = tot[i] > cap ? tot[i] - cap : 0u;
+                osum += over[i];
+            }
+            unsigned inc = osum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
@@ -1168,38 +1203,48 @@ __device__ __forceinline__ void bwd_builder_role(const BwdParams& prm, const int
             }
             if (lane == 63) scan[wave] = inc;
             __syncthreads();
-            unsigned base = inc - over;
+            unsigned base = inc - osum;
 #pragma unroll
-            for (int w = 0; w < HW_WAVES; ++w) base += w < wave ? scan[w] : 0u;
-            if (tid == kd1) scan[HW_WAVES] = base;           // dest 1's overflow restarts in its own slab
+            for (int w = 0; w < NW; ++w) base += w < wave ? scan[w] : 0u;
+            unsigned kb[KPT];                                // overflow entries in front of each of my keys
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) { kb[i] = base; base += over[i]; }
+#pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                if (tid * KPT + i == kd1) scan[NW] = kb[i];  // dest 1's overflow restarts in its own slab
             __syncthreads();
-            const unsigned ostart = d1 ? slab1 + (base - scan[HW_WAVES]) : slab0 + base;
-            ovf[tid] = ostart;
-            const int rm = tid - (d1 ? kd1 : 0), m = rm & (BF_MAXMT - 1);     // rm = row * 4 + bin
-            if (tid < 2 * kd1 && m < MT) {
-                const unsigned ui = (unsigned)((j * H + (rm >> 2)) * MT + m);
-                __builtin_amdgcn_raw_buffer_store_b128(bu32x4{tot, ostart, 0u, 0u}, slots, d1 ? light0 + ui * UL_SLOT1 : ui * UL_SLOT0, 0, 0);
-            }
-            unsigned run = 0u;                               // list-relative running positions per (wave, key)
 #pragma unroll
-            for (int w = 0; w < HW_WAVES; ++w) { hist[w * BF_NKEY + tid] = run; run += c[w]; }
+            for (int i = 0; i < KPT; ++i) {
+                const int key = tid * KPT + i;
+                const bool d1 = key >= kd1;
+                const unsigned ostart = d1 ? slab1 + (kb[i] - scan[NW]) : slab0 + kb[i];
+                ovf[key] = ostart;
+                const int rm = key - (d1 ? kd1 : 0), m = rm & (BF_MAXMT - 1);     // rm = row * 4 + bin
+                if (key < 2 * kd1 && m < MT) {
+                    const unsigned ui = (unsigned)((j * H + (rm >> 2)) * MT + m);
+                    __builtin_amdgcn_raw_buffer_store_b128(bu32x4{tot[i], ostart, 0u, 0u}, slots, d1 ? light0 + ui * UL_SLOT1 : ui * UL_SLOT0, 0, 0);
+                }
+                unsigned run = 0u;                           // list-relative running positions per (wave, key)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { hist[w * BF_NKEY + key] = run; run += c[i][w]; }
+            }
         }
         __syncthreads();
         // ---- pass 1: every element takes its position and leaves its entry {DT row, x0, weight left, weight right}
         const int kd1 = H * BF_MAXMT;
-        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * HW_WAVES) {
+        for (int ih0 = wave; ih0 < n_ih; ih0 += 4 * NW) {
             int wd[4];
             float4 w4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ih = min(ih0 + u * HW_WAVES, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
+                const int ih = min(ih0 + u * NW, n_ih - 1), it = ih >> 1, q = (ih & 1) * 64 + lane;
                 const size_t e = (size_t)items[it].x * TP + q;
                 wd[u] = reinterpret_cast<const int*>(prm.tapyx + e)[0];
                 w4[u] = prm.tapw[e];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ih = ih0 + u * HW_WAVES;
+                const int ih = ih0 + u * NW;
                 if (ih < n_ih) {                             // uniform
                     const int it = ih >> 1, q = (ih & 1) * 64 + lane;
                     const bool d1 = it >= n0;
@@ -1232,8 +1277,18 @@ __global__ void __launch_bounds__(HW_THREADS) corr_bwd_tile_build_kernel(const B
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = blockIdx.x;
-    if (w < prm.n_build) bwd_builder_role(prm, w, smem);
+    if (w < prm.n_build) bwd_builder_role<HW_WAVES>(prm, w, smem);
     else bwd_tile_h_body<NT, false>(prm, w - prm.n_build, smem);
+}
+
+// the same beside the exact-fp32 tiles (F32 mode): 256-thread workgroups, four builder waves
+template <int NT>
+__global__ void __launch_bounds__(NTHREADS) corr_bwd_tile32_build_kernel(const BwdParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = blockIdx.x;
+    if (w < prm.n_build) bwd_builder_role<NTHREADS / 64>(prm, w, smem);
+    else bwd_tile_body<NT>(prm, w - prm.n_build, smem);
 }
 
 // ---- second launch: wave k takes the pair of units {dest 0, dest 1} x (image, row, bin) k
@@ -1382,9 +1437,9 @@ __global__ void __launch_bounds__(64 * UL_WAVES) corr_unsample_list_kernel(const
 bool bwd_lists_supported(const BwdParams& prm)
 {
     const int nt = (prm.KQ + 15) / 16;
-    const bool split = prm.mode == 0 && !(prm.debug & 512) && (prm.precision == PREC_F16X3 || nt > 5);
     const bool dense = prm.g_intra_cd || prm.g_inter_cd || prm.g_neg_cd || (prm.g_neg_loss && prm.g_neg_loss_stride > 0);
-    return prm.uslots && prm.upool && split && !dense && prm.H <= BF_MAXH && prm.W <= 16 * BF_MAXMT &&
+    if ((prm.debug & 512) && nt > 5) return false;       // (the fp32-MFMA tile kernel ends at K = 80)
+    return prm.uslots && prm.upool && prm.mode == 0 && !dense && prm.H <= BF_MAXH && prm.W <= 16 * BF_MAXMT &&
            !(prm.debug & (32 | 1024)) && (size_t)prm.n_sets * prm.B * 2 * TP * prm.LDK < ((size_t)1 << 30);
 }
 
@@ -1393,31 +1448,52 @@ hipError_t launch_corr_bwd_lists(const BwdParams& prm_in, hipStream_t stream)
     BwdParams prm = prm_in;
     const int nt = (prm.KQ + 15) / 16;
     const int ntg = nt <= 5 ? nt : (nt + 1) / 2;
-    int lds = SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2;
+    // split-fp16 GEMMs in F16X3 mode and - whatever the mode - for code dimensions above 80 (launch_corr_bwd has the same rule)
+    const bool split = !(prm.debug & 512) && (prm.precision == PREC_F16X3 || nt > 5);
+    int lds = split ? SMH_CT + (4 * 16 * ntg + 2 * TP) * HB_LDR * 2 : SMB_AN + 2 * TP * prm.LDK * 4 + TP * LDG * 4;
     if (lds < BF_LDS_BYTES) lds = BF_LDS_BYTES;
     const int n_tiles = prm.n_sets * prm.B;
     prm.n_build = prm.B < 32 ? prm.B : 32;
     {
-        const dim3 grid(prm.n_build + n_tiles), block(HW_THREADS);
+        const dim3 grid(prm.n_build + n_tiles);
 #define STEGO_BWDL_CASE(N)                                                                                        \
     case N: {                                                                                                     \
         hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile_build_kernel<N>), lds);   \
         if (ea != hipSuccess) return ea;                                                                          \
-        hipLaunchKernelGGL((corr_bwd_tile_build_kernel<N>), grid, block, lds, stream, prm);                       \
+        hipLaunchKernelGGL((corr_bwd_tile_build_kernel<N>), grid, dim3(HW_THREADS), lds, stream, prm);            \
         break;                                                                                                    \
     }
-        switch (nt) {
-            STEGO_BWDL_CASE(1)
-            STEGO_BWDL_CASE(2)
-            STEGO_BWDL_CASE(3)
-            STEGO_BWDL_CASE(4)
-            STEGO_BWDL_CASE(5)
-            STEGO_BWDL_CASE(6)
-            STEGO_BWDL_CASE(7)
-            default:
-            STEGO_BWDL_CASE(8)
+#define STEGO_BWDL32_CASE(N)                                                                                      \
+    case N: {                                                                                                     \
+        hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_bwd_tile32_build_kernel<N>), lds); \
+        if (ea != hipSuccess) return ea;                                                                          \
+        hipLaunchKernelGGL((corr_bwd_tile32_build_kernel<N>), grid, dim3(NTHREADS), lds, stream, prm);            \
+        break;                                                                                                    \
+    }
+        if (split) {
+            switch (nt) {
+                STEGO_BWDL_CASE(1)
+                STEGO_BWDL_CASE(2)
+                STEGO_BWDL_CASE(3)
+                STEGO_BWDL_CASE(4)
+                STEGO_BWDL_CASE(5)
+                STEGO_BWDL_CASE(6)
+                STEGO_BWDL_CASE(7)
+                default:
+                STEGO_BWDL_CASE(8)
+            }
+        } else {
+            switch (nt) {
+                STEGO_BWDL32_CASE(1)
+                STEGO_BWDL32_CASE(2)
+                STEGO_BWDL32_CASE(3)
+                STEGO_BWDL32_CASE(4)
+                default:
+                STEGO_BWDL32_CASE(5)
+            }
         }
 #undef STEGO_BWDL_CASE
+#undef STEGO_BWDL32_CASE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

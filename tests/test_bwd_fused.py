@@ -164,3 +164,23 @@ def test_back_to_back_backwards_on_rotating_contexts_never_see_stale_rows():
         for (dc, dcp), (rc, rcp) in zip(outs, alone):
             assert np.array_equal(dc.contiguous().cpu().numpy(), rc), rep
             assert np.array_equal(dcp.contiguous().cpu().numpy(), rcp), rep
+
+
+@pytest.mark.parametrize("shape", [(32, 384, 28, 28, 70, 11, 5), (3, 32, 6, 9, 8, 5, 2), (4, 64, 40, 40, 70, 11, 5), (40, 32, 8, 8, 24, 5, 5)])
+def test_lists_first_backward_in_exact_fp32_mode(shape):
+    """F32 mode: the exact-fp32 tile kernel with four-wave builders beside it, the same unsample kernel."""
+    B, C, H, W, K, S, n_neg = shape
+    # (seeds whose cd has no element within fp32 rounding of the clamp bound: there the pass mask of any fp32 evaluation - the reference's
+    # included - may differ from the fp64 oracle's, one whole term of a gradient sum)
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=2024 if C == 384 else 11 + B + W, dino_like=C == 384)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    case = _Case(d, cfg, precision=capi.PREC_F32)
+    a = case.backward()
+    a2 = case.backward()
+    b = case.backward(two_launches=True)
+    dc, dcp = case.oracle()
+    assert_close(a[0], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(a[1], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+    for x, y, z in zip(a, a2, b):
+        assert np.array_equal(x, y)
+        assert np.abs(x - z).max() <= 4e-6 * float(np.abs(z).max()) + 1e-30
