@@ -217,6 +217,227 @@ def _relayout_threshold(code):
     return 0 if code.shape[1] > 72 else 1 << 16
 
 
+class _LossFamily:
+    """The three scalar outputs of ONE forward call - pos_intra_loss.mean(), pos_inter_loss.mean(), neg_inter_loss.mean(), as the
+    autograd outputs of the loss op - and the device constants a weighted sum of them needs as upstream gradients."""
+    _const = {}
+
+    def __init__(self, o_intra, o_inter, o_neg):
+        self.outs = (o_intra, o_inter, o_neg)
+
+    @classmethod
+    def const(cls, value, like):
+        key = (float(value), like.device, like.dtype)
+        t = cls._const.get(key)
+        if t is None:
+            if torch.cuda.is_available() and like.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None                    # (no allocation + fill inside a capture: the caller takes the plain path)
+            if len(cls._const) > 256:
+                cls._const.clear()
+            t = cls._const[key] = torch.full((), float(value), device=like.device, dtype=like.dtype)
+        return t
+
+
+def _is_number(x):
+    return isinstance(x, (int, float)) and not isinstance(x, bool)
+
+
+class _LazyLoss:
+    """c0 * pos_intra + c1 * pos_inter + c2 * neg_inter of ONE forward call, not yet evaluated: what the reference's training step
+    writes as ``(pos_inter_weight * pos_inter_loss + pos_intra_weight * pos_intra_loss + neg_inter_weight * neg_inter_loss) *
+    correspondence_weight`` (train_segmentation.py:178-181) - five scalar kernels forward and four backward around a 50 us loss.
+
+    THE CONTRACT, in one place.  This is NOT a tensor: it only answers (a) multiplication / division by a Python number, negation,
+    addition / subtraction of another combination of the SAME forward call (all of which stay lazy), and (b) ``.backward()`` without an
+    explicit gradient, which hands the three coefficients to the loss op's backward as its upstream gradients (no kernel at all).
+    EVERYTHING else - any torch function, any other operand, any attribute or method of a tensor (``.item()``, ``float()``,
+    ``.detach()``, ``+ other_loss``, ``torch.stack([...])``, logging) - first evaluates the sum with the plain torch ops on the plain
+    tensors (``materialize()``: exactly the expression the caller wrote, with its normal autograd graph) and then behaves as that
+    tensor does: same values, same gradients, only slower.  Tested op by op against the plain expression (tests/test_parity_gpu.py)."""
+    __slots__ = ("_fam", "_c", "_value")
+
+    def __init__(self, fam, coeffs):
+        self._fam, self._c, self._value = fam, tuple(float(c) for c in coeffs), None
+
+    # ---- the lazy algebra
+    def _scaled(self, k):
+        return _LazyLoss(self._fam, [c * k for c in self._c])
+
+    def __mul__(self, k):
+        return self._scaled(k) if _is_number(k) else self.materialize() * k
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return self._scaled(1.0 / k) if _is_number(k) and k != 0 else self.materialize() / k
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __pos__(self):
+        return self
+
+    def _same(self, other):
+        if isinstance(other, _LossScalar) and getattr(other, "_stego_fam", None) is self._fam:
+            other = other._lazy()
+        return other if isinstance(other, _LazyLoss) and other._fam is self._fam else None
+
+    def __add__(self, other):
+        o = self._same(other)
+        if o is not None:
+            return _LazyLoss(self._fam, [a + b for a, b in zip(self._c, o._c)])
+        if _is_number(other) and other == 0:       # (``loss = 0; loss += ...``: train_segmentation.py:146,181)
+            return self
+        return self.materialize() + (other.materialize() if isinstance(other, _LazyLoss) else other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        o = self._same(other)
+        if o is not None:
+            return _LazyLoss(self._fam, [a - b for a, b in zip(self._c, o._c)])
+        return self.materialize() - (other.materialize() if isinstance(other, _LazyLoss) else other)
+
+    def __rsub__(self, other):
+        return (-self).__add__(other)
+
+    # ---- evaluation: the caller's expression on the plain tensors
+    def materialize(self):
+        if self._value is None:
+            with torch._C.DisableTorchFunctionSubclass():
+                v = None
+                for c, o in zip(self._c, self._fam.outs):
+                    if o is None or c == 0.0:
+                        continue
+                    t = o.as_subclass(torch.Tensor) * c
+                    v = t if v is None else v + t
+                if v is None:
+                    ref = next(o for o in self._fam.outs if o is not None)
+                    v = ref.as_subclass(torch.Tensor) * 0.0
+            self._value = v
+        return self._value
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if gradient is None and not create_graph and self._value is None:
+            outs, grads = [], []
+            for c, o in zip(self._c, self._fam.outs):
+                if o is None or c == 0.0 or not o.requires_grad:
+                    continue
+                g = _LossFamily.const(c, o)
+                if g is None:
+                    outs = None
+                    break
+                outs.append(o.as_subclass(torch.Tensor))
+                grads.append(g)
+            if outs:
+                return torch.autograd.backward(outs, grads, retain_graph=retain_graph, inputs=inputs)
+        return self.materialize().backward(gradient, retain_graph=retain_graph, create_graph=create_graph, inputs=inputs)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def plain(x):
+            if isinstance(x, _LazyLoss):
+                return x.materialize()
+            if isinstance(x, (list, tuple)):
+                return type(x)(plain(y) for y in x)
+            return x
+        return func(*plain(args), **{k: plain(v) for k, v in (kwargs or {}).items()})
+
+    def __getattr__(self, name):               # anything a tensor has and this does not: the tensor's
+        return getattr(self.materialize(), name)
+
+    def __float__(self):
+        return float(self.materialize())
+
+    def __repr__(self):
+        return "_LazyLoss(%s)" % (repr(self.materialize()),)
+
+    def __format__(self, spec):
+        return format(self.materialize(), spec)
+
+    def __bool__(self):
+        return bool(self.materialize())
+
+    def __int__(self):
+        return int(self.materialize())
+
+    def __array__(self, dtype=None):
+        return self.materialize().detach().cpu().numpy() if dtype is None else self.materialize().detach().cpu().numpy().astype(dtype)
+
+    __hash__ = object.__hash__
+
+
+def _delegate(name):
+    def f(self, *args, **kwargs):
+        return getattr(self.materialize(), name)(*[a.materialize() if isinstance(a, _LazyLoss) else a for a in args], **kwargs)
+    f.__name__ = name
+    return f
+
+
+# the remaining operators of a tensor (Python looks special methods up on the type, not through __getattr__): the tensor's own
+for _n in ("__abs__", "__pow__", "__rpow__", "__rtruediv__", "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__", "__matmul__",
+           "__rmatmul__", "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "__getitem__", "__len__", "__iter__",
+           "__invert__", "__and__", "__or__", "__xor__", "__complex__", "__index__", "__round__"):
+    setattr(_LazyLoss, _n, _delegate(_n))
+del _n
+
+
+class _LossScalar(torch.Tensor):
+    """One of the three scalar outputs (a REAL tensor: value, storage and autograd node are the op's own).  Multiplied by a Python number,
+    or added to a sibling, it answers with a _LazyLoss (see its contract); ``.mean()`` of the 0-dim scalar is the scalar itself
+    (train_segmentation.py:169-171 takes it); every other use is the plain tensor's."""
+
+    def _lazy(self):
+        return _LazyLoss(self._stego_fam, [1.0 if i == self._stego_idx else 0.0 for i in range(3)])
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if not kwargs and args and isinstance(args[0], _LossScalar) and getattr(args[0], "_stego_fam", None) is not None:
+            me = args[0]
+            if func in (torch.Tensor.mean, torch.mean) and len(args) == 1 and me.dim() == 0:
+                return me
+            if len(args) == 2:
+                other = args[1]
+                if func in (torch.Tensor.mul, torch.Tensor.__mul__, torch.Tensor.__rmul__, torch.mul) and _is_number(other):
+                    return me._lazy() * other
+                if func in (torch.Tensor.div, torch.Tensor.__truediv__, torch.true_divide, torch.div) and _is_number(other) and other != 0:
+                    return me._lazy() / other
+                if func in (torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.add) and \
+                        (isinstance(other, _LazyLoss) or (isinstance(other, _LossScalar) and getattr(other, "_stego_fam", None) is me._stego_fam)):
+                    return me._lazy() + other
+                if func in (torch.Tensor.sub, torch.Tensor.__sub__, torch.sub) and \
+                        (isinstance(other, _LazyLoss) or (isinstance(other, _LossScalar) and getattr(other, "_stego_fam", None) is me._stego_fam)):
+                    return me._lazy() - other
+            if len(args) == 1 and func in (torch.Tensor.neg, torch.Tensor.__neg__, torch.neg):
+                return -me._lazy()
+        elif not kwargs and len(args) == 2 and isinstance(args[1], _LossScalar) and getattr(args[1], "_stego_fam", None) is not None:
+            me, other = args[1], args[0]       # number * scalar reaches here as Tensor.__rmul__(me, number): handled above; this is torch.mul(number, me)
+            if func in (torch.mul,) and _is_number(other):
+                return me._lazy() * other
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return out
+
+
+def _lazy_scalars(o_intra, o_inter, o_neg):
+    """Wrap the op's three scalar outputs (any may be None) as _LossScalar siblings of one family.  The family holds the PLAIN outputs
+    and the wrappers hold the family - no reference cycle through a tensor's __dict__ (torch.cuda.graph() runs gc.collect() on entry;
+    collecting such a cycle crashed the interpreter)."""
+    plain = tuple(None if o is None else o.as_subclass(torch.Tensor) for o in (o_intra, o_inter, o_neg))
+    fam = _LossFamily(*plain)
+    members = []
+    for i, o in enumerate(plain):
+        if o is None:
+            members.append(None)
+            continue
+        w = o.as_subclass(_LossScalar)
+        w._stego_idx = i
+        w._stego_fam = fam
+        members.append(w)
+    return members
+
+
 class _NegLossMap(torch.Tensor):
     """The negative loss tensor forward() returns (modules.py:390, ``torch.cat(neg_losses)``), carrying the mean the forward launch
     computed anyway.  The reference's training step only ever takes ``neg_inter_loss.mean()`` (train_segmentation.py:176): that call
@@ -475,10 +696,12 @@ class ContrastiveCorrelationLoss(nn.Module):
         else:
             out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
         neg_loss = out[4]
+        lazy = getattr(cfg, "lazy_loss_sums", True)               # (off: the three scalars are plain tensors)
+        o_intra, o_inter, o_neg = _lazy_scalars(out[0], out[2], out[6] if n_neg > 0 else None) if lazy else (out[0], out[2], out[6])
         if n_neg > 0:
             neg_loss = neg_loss.as_subclass(_NegLossMap)          # (an alias: same storage, same autograd node)
-            neg_loss._stego_mean = out[6]
-        return out[0], out[1], out[2], out[3], neg_loss, out[5]
+            neg_loss._stego_mean = o_neg
+        return o_intra, out[1], o_inter, out[3], neg_loss, out[5]
 
     def forward(self,
                 orig_feats: torch.Tensor, orig_feats_pos: torch.Tensor,

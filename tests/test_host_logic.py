@@ -337,3 +337,55 @@ def test_torch_glue_extension_is_built_and_bound_to_the_library():
     desc = capi.make_desc(2, 8, 4, 4, 4, 2, 0, type("C", (), dict(pointwise=True, zero_clamp=True, stabalize=False))(), (0.1, 0.2, 0.3))
     with pytest.raises(RuntimeError, match="MI355X only"):
         ext.corr_loss(x, x, x[:, :4], x[:, :4], torch.zeros(2, 2, 2, 2), torch.zeros(2, 2, 2, 2), torch.zeros(0, 2, dtype=torch.long), bytes(desc), 0)
+
+
+def test_lazy_loss_sum_contract_every_use_equals_the_plain_expression():
+    """modules._LossScalar / _LazyLoss (the weighted sum of the three loss scalars the reference's training step writes,
+    train_segmentation.py:178-181): what stays lazy is a closed list; everything else must be exactly the plain tensor expression."""
+    import math
+    import numpy as np
+    import torch
+    from stego_amd import modules as M
+
+    x = torch.tensor([0.3, -1.2, 2.0], dtype=torch.float64, requires_grad=True)
+
+    def family(lazy):
+        o = [x[i] * 2.0 + 0.1 * i for i in range(3)]
+        return M._lazy_scalars(*o) if lazy else o
+
+    # (expression, stays lazy?)
+    exprs = [
+        (lambda a, b, c: (0.25 * b + 0.67 * a + 0.63 * c) * 1.5, True),        # the reference's line
+        (lambda a, b, c: 0.25 * b.mean() + 0.67 * a.mean() + 0.63 * c.mean(), True),
+        (lambda a, b, c: 0 + (a * 2 - b / 4) + (-c), True),
+        (lambda a, b, c: a + b, True),
+        (lambda a, b, c: torch.mul(2.0, a) - 3 * a, True),
+        (lambda a, b, c: (a * 2) + 1.0, False),
+        (lambda a, b, c: (a * 2) * torch.tensor(3.0, dtype=torch.float64), False),
+        (lambda a, b, c: a * b, False),
+        (lambda a, b, c: (a * 2) ** 2 + abs(b * -1) + 1 / (c * 2), False),
+        (lambda a, b, c: torch.stack([0.5 * a, b * 2.0, c]).sum(), False),
+        (lambda a, b, c: (2.0 * a).exp() + torch.sin(b * 0.5), False),
+        (lambda a, b, c: 2 - a * 3, False),
+        (lambda a, b, c: (a * 2).clamp(min=0.0) + (b * 2).detach(), False),
+        (lambda a, b, c: a.exp(), False),
+    ]
+    for k, (f, stays_lazy) in enumerate(exprs):
+        e = f(*family(True))
+        r = f(*family(False))
+        assert isinstance(e, M._LazyLoss) == stays_lazy, k
+        assert math.isclose(float(e), float(r), rel_tol=1e-14, abs_tol=1e-15), k
+        x.grad = None
+        f(*family(True)).backward()
+        g = x.grad.clone()
+        x.grad = None
+        f(*family(False)).backward()
+        np.testing.assert_allclose(g.numpy(), x.grad.numpy(), rtol=1e-14, atol=1e-15, err_msg=str(k))
+    # two forward calls never mix lazily; formatting, comparisons, numpy, item()
+    a1, _, _ = family(True)
+    _, b2, _ = family(True)
+    assert isinstance(a1 * 2 + b2 * 2, torch.Tensor)
+    e = (family(True)[0] * 2)
+    assert ("%.4f" % e) == ("%.4f" % float(e)) and bool(e > 0) and np.asarray(e.detach()).shape == () and e.item() == float(e)
+    assert isinstance(e.detach(), torch.Tensor) and not isinstance(e.detach(), M._LossScalar)
+    # with cfg.lazy_loss_sums = False nothing is wrapped (checked on the GPU path: tests/test_parity_gpu.py)

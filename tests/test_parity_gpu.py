@@ -1298,3 +1298,53 @@ def test_without_the_torch_glue_extension_the_product_is_the_same(monkeypatch):
     for a_run, b_run in zip(with_ext, without):
         for a, b in zip(a_run, b_run):
             assert torch.equal(a, b)
+
+
+def test_lazy_loss_sum_gives_the_plain_gradients_eagerly_and_inside_a_captured_graph():
+    """The reference's weighted sum of the three loss scalars (train_segmentation.py:178-181) written on the outputs of forward():
+    with cfg.lazy_loss_sums (default) the coefficients reach the loss op's backward as its upstream gradients without a kernel;
+    values and gradients equal the plain tensor expression's (cfg.lazy_loss_sums = False), eagerly and replayed from a HIP graph."""
+    import copy
+    B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=4)
+    t = {k: _dev(v) for k, v in d.items()}
+    f, fp = _channels_last(t["feats"]), _channels_last(t["feats_pos"])
+    cfg = O.CorrCfg()
+    cfg.corr_precision = "f16x3"
+    plain_cfg = copy.copy(cfg)
+    plain_cfg.lazy_loss_sums = False
+
+    def run(cfg_, c, cp):
+        out = M.ContrastiveCorrelationLoss(cfg_).forward_explicit(f, fp, c, cp, t["coords1"], t["coords2"], t["perms"])
+        loss = 0
+        loss += (0.25 * out[2].mean() + 0.67 * out[0].mean() + 0.63 * out[4].mean()) * 1.5
+        return out, loss
+
+    res = {}
+    for name, cfg_ in (("lazy", cfg), ("plain", plain_cfg)):
+        c = _channels_last(t["code"]).detach().requires_grad_(True)
+        cp = _channels_last(t["code_pos"]).detach().requires_grad_(True)
+        out, loss = run(cfg_, c, cp)
+        assert isinstance(loss, M._LazyLoss) == (name == "lazy")
+        val = float(loss)                      # (evaluates a copy of the sum; the lazy object itself stays lazy for backward())
+        out, loss = run(cfg_, c, cp)
+        loss.backward()
+        res[name] = (val, c.grad.clone(), cp.grad.clone())
+    assert abs(res["lazy"][0] - res["plain"][0]) <= 1e-6 * abs(res["plain"][0])
+    for a, b in zip(res["lazy"][1:], res["plain"][1:]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    # captured: the device constants exist (made by the eager run above), so the lazy backward is capturable
+    c = _channels_last(t["code"]).detach().requires_grad_(True)
+    cp = _channels_last(t["code_pos"]).detach().requires_grad_(True)
+    for _ in range(2):
+        c.grad = cp.grad = None
+        run(cfg, c, cp)[1].backward()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    c.grad = cp.grad = None
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (the backward runs on the autograd engine's device thread)
+        run(cfg, c, cp)[1].backward()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(c.grad, res["plain"][1], rtol=1e-5, atol=1e-6 * float(res["plain"][1].abs().max()))
+    assert torch.allclose(cp.grad, res["plain"][2], rtol=1e-5, atol=1e-6 * float(res["plain"][2].abs().max()))
