@@ -403,8 +403,11 @@ def test_backward_is_linear_in_upstream():
     g1 = _run(inputs, d["perms"], cfg, upstream=lambda o: o[0])
     g2 = _run(inputs, d["perms"], cfg, upstream=lambda o: o[2] + o[4].sum())
     g3 = _run(inputs, d["perms"], cfg, upstream=lambda o: 2.0 * o[0] - 3.0 * (o[2] + o[4].sum()))
-    np.testing.assert_allclose(g3["d_code"], 2.0 * g1["d_code"] - 3.0 * g2["d_code"], rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(g3["d_code_pos"], 2.0 * g1["d_code_pos"] - 3.0 * g2["d_code_pos"], rtol=1e-4, atol=1e-7)
+    # (g1 has scalar upstreams only and runs on the lists-first unsample, g2 / g3 carry a dense upstream and run on the row kernel: two
+    # fixed summation orders - the bar is fp32 rounding of a ~12-term sum relative to the largest gradient, not 1e-7 absolute)
+    for k in ("d_code", "d_code_pos"):
+        want = 2.0 * g1[k] - 3.0 * g2[k]
+        np.testing.assert_allclose(g3[k], want, rtol=1e-4, atol=4e-6 * float(np.abs(want).max()))
 
 
 def test_on_device_rng_path_equals_explicit_draws():

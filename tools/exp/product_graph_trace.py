@@ -23,7 +23,7 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
     step()
 torch.cuda.synchronize()
 for _ in range(60): g.replay()
