@@ -1344,14 +1344,16 @@ __global__ void __launch_bounds__(64 * UL_WAVES) corr_unsample_list_kernel(const
         constexpr int NG = decltype(ng_tag)::value;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int e = min(4 * g + k4, max(n - 1, 0));
-            const unsigned row = (unsigned)__shfl((int)ent[0], first + e, 64);
+            if (4 * g < n) {                                  // uniform: groups beyond the list issue nothing
+                const int e = min(4 * g + k4, n - 1);
+                const unsigned row = (unsigned)__shfl((int)ent[0], first + e, 64);
 #pragma unroll
-            for (int qd = 0; qd < NQ; ++qd)
-                rows[g].q[qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dtr, (row + 64u * qd + 4u * l16) * 4u, 0, 0));
+                for (int qd = 0; qd < NQ; ++qd)
+                    rows[g].q[qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dtr, (row + 64u * qd + 4u * l16) * 4u, 0, 0));
 #pragma unroll
-            for (int t = 0; t < TAIL; ++t)
-                rows[g].t[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dtr, (row + (unsigned)min(64 * NQ + 16 * t + l16, ldk - 1)) * 4u, 0, 0));
+                for (int t = 0; t < TAIL; ++t)
+                    rows[g].t[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dtr, (row + (unsigned)min(64 * NQ + 16 * t + l16, ldk - 1)) * 4u, 0, 0));
+            }
         }
     };
     auto consume = [&](const bu32x4& ent, int first, int n, auto& rows, f32x4 (&ac)[NA], auto ng_tag) {

@@ -228,6 +228,16 @@ def test_neighbour_file_name_and_format(tmp_path):
     assert torch.equal(P.load_nns(str(tmp_path / name)), nns)
     import numpy as np
     assert list(np.load(str(tmp_path / name)).keys()) == ["nns"]
+    # both directions against the reference's own lines: its reader (data.py:509-510: ``loaded = np.load(feature_cache_file);
+    # self.nns = loaded["nns"]``) on our file, our reader on what its writer leaves (precompute_knns.py:96:
+    # ``np.savez_compressed(feature_cache_file, nns=nearest_neighbors.numpy())``), and its file-name expression (data.py:503-504)
+    loaded = np.load(str(tmp_path / name))
+    assert np.array_equal(loaded["nns"], nns.numpy()) and loaded["nns"].dtype == np.int64
+    ref_name = "nns_{}_{}_{}_{}_{}.npz".format("vit_small", "cocostuff27", "train", "five", 224)
+    assert ref_name == name
+    np.savez_compressed(str(tmp_path / "ref_written.npz"), nns=nns.numpy())
+    assert torch.equal(P.load_nns(str(tmp_path / "ref_written.npz")), nns)
+    assert open(str(tmp_path / "ref_written.npz"), "rb").read() == open(str(tmp_path / name), "rb").read()     # byte-identical archives
 
 
 def test_token_cache_serves_the_frozen_backbone_from_memory():

@@ -18,5 +18,10 @@ if os.environ.get("VARIANT"): capi.debug_set("STEGO_FWD_VARIANT", int(os.environ
 if os.environ.get("DEBUG"): capi.debug_set("STEGO_DEBUG", int(os.environ["DEBUG"]))
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     d = sets[i % 4]
-    capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+    out = capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+    if os.environ.get("BWD"):              # + the training backward (scalar upstreams)
+        lm, icd, ecd, nl, ncd, saved = out
+        gi = torch.tensor(0.67, device=dev); ge = torch.tensor(0.25, device=dev)
+        gn = torch.full((1,), 0.63 / (n_neg * B * S ** 4), device=dev).expand(n_neg * B, S, S, S, S)
+        capi.corr_bwd(desc, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved, icd, ecd, ncd, gi, ge, gn, None, None, None)
 torch.cuda.synchronize()
