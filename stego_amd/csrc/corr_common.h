@@ -152,9 +152,10 @@ struct FusedParams {
     int KQ, LDK;
     int B, C, K, H, W, S, P, n_neg, n_sets;
     int n_owner;                               // workgroups [0, n_owner) share phase 1
+    int p1_light;                              // 1: the workgroups without a gather stream carry phase 1 (set by the launcher)
     int ps_round;                              // pair-sets per round of tiles (all of them unless there are more tiles than CUs)
     int pointwise;
-    int debug;                                 // 32 never rendezvous (always repair), 64 owners skip phase 1 (always help),
+    int debug;                                 // 32 never rendezvous (always repair), 64 owners skip phase 1 (always help), 128 even phase-1 shares,
                                                // 256 phase stamps
     int timeout_ticks;                         // bound of every spin, 100 MHz ticks
     float cmin, cmax;

@@ -199,7 +199,7 @@ __device__ __forceinline__ void point_taps(const FusedParams& prm, const f32x2 c
 //   piece 3:    codes, context rows  [ROWS][LDK floats]       (what the backward reads)
 // so that every plane leaves as ONE contiguous run per anchor (scattered sc1 stores straight from the registers ran at
 // 0.4 TB/s chip-wide: 22 us for 8.6 MB).
-template <int NJ, int PREC>
+template <int NJ, int PREC, bool LIGHT = false>
 struct P1Layout {
     static constexpr int NCH2 = 4 * NJ;
     static constexpr int PLANES = PREC == PREC_F16X3 ? 2 : 1;
@@ -207,14 +207,21 @@ struct P1Layout {
     static constexpr int G = NJ <= 3 ? 2 : 1;                  // points per half-wave and pass (register budget: 48 NJ G)
     static constexpr int MROWS = 4 * 2 * G;                    // rows the four waves of the MFMA team take per pass
     static constexpr int XW = NJ <= 3 ? 2 : 0;                 // gather waves (8, 9) that take two overflow rows each in the FIRST pass
-    static constexpr int ROWS = MROWS + 2 * XW;                // rows of a pass = geometry of the staging area
+    // LIGHT (round 4): a workgroup WITHOUT a gather stream of its own - a self-correlation tile or a tile-less helper - samples with all
+    // twelve waves (2 G rows each) and stages in the WHOLE ring, linearly: it carries most of phase 1 (see the kernel)
+    static constexpr int ROWS = LIGHT ? 12 * 2 * G : MROWS + 2 * XW;     // rows of a pass = geometry of the staging area
     static constexpr int STAGE_BYTES = ROWS * 128;             // one feature stage of a pass (either format)
-    static constexpr int SPP = RS_SIDE / STAGE_BYTES;          // feature stages per piece
-    static_assert(NCH2 <= 2 * SPP, "feature stages fit pieces 0-1");
-    static_assert(4 * ROWS * 128 <= RS_SIDE && ROWS * (128 + 4) * 4 <= RS_SIDE, "code stages fit piece 2, context rows piece 3");
-    static constexpr int CF = 2 * RS_STAGE;
-    static constexpr int CX = 3 * RS_STAGE;
-    __device__ static __forceinline__ int feat_plane(int s2, int pp) { return (s2 / SPP) * RS_STAGE + (s2 % SPP) * STAGE_BYTES + pp * ROWS * RB; }
+    static constexpr int SPP = LIGHT ? 1 : RS_SIDE / STAGE_BYTES;        // feature stages per piece
+    static_assert(LIGHT || NCH2 <= 2 * SPP, "feature stages fit pieces 0-1");
+    static_assert(LIGHT || (4 * ROWS * 128 <= RS_SIDE && ROWS * (128 + 4) * 4 <= RS_SIDE), "code stages fit piece 2, context rows piece 3");
+    static constexpr int CF = LIGHT ? NCH2 * STAGE_BYTES : 2 * RS_STAGE;
+    static constexpr int CX = LIGHT ? CF + 4 * ROWS * 128 : 3 * RS_STAGE;
+    static_assert(!LIGHT || CX + ROWS * (128 + 4) * 4 <= RS_NS * RS_STAGE, "the light staging fits the ring");
+    __device__ static __forceinline__ int feat_plane(int s2, int pp)
+    {
+        if constexpr (LIGHT) return s2 * STAGE_BYTES + pp * ROWS * RB;
+        else return (s2 / SPP) * RS_STAGE + (s2 % SPP) * STAGE_BYTES + pp * ROWS * RB;
+    }
 };
 
 // bilinear blend of the four taps with a FIXED rounding sequence (one multiply, three fmas)
@@ -225,11 +232,11 @@ __device__ __forceinline__ float blend4(const float4 w, float t0, float t1, floa
 
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
-template <int NJ, int PREC, int NKCT, int G>
+template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false>
 __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane,
                                                unsigned char* lds, unsigned long long* tsd)
 {
-    typedef P1Layout<NJ, PREC> LY;
+    typedef P1Layout<NJ, PREC, LIGHT> LY;
     constexpr int ROWS = LY::ROWS;
     const int hl = lane & 31, hw = lane >> 5;
     const int crow = prm.LDK * 4;
@@ -380,12 +387,12 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
 
 // Writes staged rows [row0, row0 + nrows) (global point index blk0 + row) out: the planes `first`, `first + step`, ...
 // of the plane list {feature planes, code stages, context} by this wave, 16 bytes per lane, write-through.
-template <int NJ, int PREC>
+template <int NJ, int PREC, bool LIGHT = false>
 __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int blk0, int row0, int nrows, int first,
                                             int step, int lane, const unsigned char* lds, __amdgpu_buffer_rsrc_t fs_rsrc,
                                             __amdgpu_buffer_rsrc_t csf_rsrc, __amdgpu_buffer_rsrc_t cs_rsrc)
 {
-    typedef P1Layout<NJ, PREC> LY;
+    typedef P1Layout<NJ, PREC, LIGHT> LY;
     constexpr int NFP = LY::NCH2 * LY::PLANES, ROWS = LY::ROWS;
     const int crow = prm.LDK * 4;
     const unsigned char* lds_cf = lds + LY::CF;
@@ -763,8 +770,58 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     const int p1nb = p1x < B ? (B - p1x + 7) >> 3 : 0;
     const int p1nslot = (prm.n_owner - p1x + 7) >> 3;
     const long long p1L = (long long)p1nb * TP;
-    const int p1beg = (int)(p1L * p1r / p1nslot), p1end = (int)(p1L * (p1r + 1) / p1nslot);
-    if (mfma_team && p1_here) {
+    int p1beg = (int)(p1L * p1r / p1nslot), p1end = (int)(p1L * (p1r + 1) / p1nslot);
+    // Round 4: who carries phase 1.  The workgroups whose gather team streams a B side finish their share 4 (median) to 9 us (slowest)
+    // later than the ones without a gather stream (stamps by slot class, profiles/r04f): their 16 points' taps and write-through
+    // stores queue behind the gather head in the CU's own memory pipeline, and every anchor waits for its slowest contributor.  With
+    // prm.p1_light (one round, B a multiple of 8, a workgroup on every CU) the LIGHT workgroups of an XCD - the self-correlation
+    // tiles, which the placement puts on its slots 0 .. B/8 - 1 (they come first in tile order and prefer the XCD of their own image),
+    // and the tile-less helpers behind the tiles - sample with all twelve waves, 24 G rows per workgroup in one pass; what they do
+    // not cover is spread over the others (5-6 rows at B = 32, nothing at B = 16).
+    typedef P1Layout<NJ, PREC, true> LYL;
+    bool p1_is_light = false;
+    if (prm.p1_light) {
+        const int tile_slots = (n_tiles - p1x + 7) >> 3;                 // slots of this XCD that hold a tile
+        const int n_light = p1nb + (p1nslot - tile_slots), n_heavy = p1nslot - n_light;
+        const int R = (int)p1L, capL = n_light * LYL::ROWS;
+        p1_is_light = p1r < p1nb || p1r >= tile_slots;
+        const int lr = p1r < p1nb ? p1r : p1nb + (p1r - tile_slots);     // rank among the light / the other workgroups of the XCD
+        const int hr = p1r - p1nb;
+        if (R <= capL) {
+            p1beg = p1_is_light ? R * lr / n_light : 0;
+            p1end = p1_is_light ? R * (lr + 1) / n_light : 0;
+        } else if (p1_is_light) {
+            p1beg = LYL::ROWS * lr;
+            p1end = p1beg + LYL::ROWS;
+        } else {
+            p1beg = capL + (int)((long long)(R - capL) * hr / n_heavy);
+            p1end = capL + (int)((long long)(R - capL) * (hr + 1) / n_heavy);
+        }
+    }
+    if (p1_here && p1_is_light) {
+        // ---- a light workgroup: every wave samples 2 G rows, the MFMA team copies out and publishes
+        const int lr0 = 2 * LYL::G * wave8;
+        if (mfma_team) __builtin_amdgcn_s_setprio(3);
+        if (p1beg + lr0 < p1end)
+            p1_sample_rows<NJ, PREC, NKCT, LYL::G, true>(prm, p1x, p1beg, p1end, lr0, lane, ring, (stamp_on && mfma_team) ? ts + 8 : nullptr);
+        if (!mfma_team) {
+            team_arrive(team_cnt, lane);
+        } else {
+            const int nrows = p1end - p1beg;
+            team_barrier(team_cnt, FUSED_WAVES, lane);
+            if (nrows > 0) {
+                const int to_edge = (((p1beg >> 7) + 1) << 7) - p1beg;
+                const int n0 = min(nrows, to_edge);
+                p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, 0, n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                if (n0 < nrows) p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, n0, nrows - n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+            }
+            if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have landed
+            team_barrier(team_cnt, FUSED_WAVES + 4, lane);
+            if (tid == 0 && nrows > 0) p1_publish(prm, p1x, p1beg, nrows);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    } else if (mfma_team && p1_here) {
         const int x = p1x, beg = p1beg, end = p1end;
         unsigned epoch = 0;
         // the team shares its SIMDs with two gather waves each, and everybody's anchors wait for it: it goes first
@@ -1440,6 +1497,16 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     if (sd > 8) {                          // (tools: an explicit number of phase-1 owners between the two, a multiple of 8)
         const int want = sd & ~7;
         prm.n_owner = want < prm.n_owner ? prm.n_owner : (want > all ? all : want);
+    }
+    // phase 1 carried by the light workgroups (see the kernel): one round, whole images per XCD, a workgroup on every CU, and what the
+    // light ones cannot take fits one pass (16 rows at C = 384, 8 at 768) of the others
+    {
+        const int G = prm.C <= 384 ? 2 : 1, rowsL = 24 * G, rowsH = 8 * G;
+        const int per_x = prm.B / 8, slots = all / 8, tile_slots = n_tiles / 8;
+        const int n_light = per_x + (slots - tile_slots), n_heavy = slots - n_light;
+        const int R = per_x * TP, rest = R - n_light * rowsL;
+        prm.p1_light = !(prm.debug & 128) && prm.B % 8 == 0 && n_tiles % 8 == 0 && n_tiles <= all && prm.n_owner == all && prm.ps_round >= prm.n_sets &&
+                       slots >= tile_slots && n_light > 0 && (rest <= 0 || (n_heavy > 0 && (rest + n_heavy - 1) / n_heavy <= rowsH)) ? 1 : 0;
     }
     prm.timeout_ticks = 20000;                                    // 200 us of the 100 MHz clock (debug 64: the anchor wait gives up after 1 us)
     const int lds = RING_LDS_BYTES;

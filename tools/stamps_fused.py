@@ -50,6 +50,11 @@ for prec in (capi.PREC_F16X3,):
         print("   ring loop (anchor ready -> E0) percentiles 0/10/25/50/75/90/100:", np.round(np.percentile(loop, [0, 10, 25, 50, 75, 90, 100]), 1))
         print("   ring loop mean by XCD (workgroup %% 8):", [round(float(loop[x::8].mean()), 1) for x in range(8)])
         print("   ring loop mean by slot (workgroup // 8) quartiles:", [round(float(loop[8 * a: 8 * a + 56].mean()), 1) for a in (0, 7, 14, 21)])
+        slot = np.arange(nt) >> 3
+        for cname, sel in (("intra slots 0-3 (no gather)", slot < 4), ("gathered slots 4-27", slot >= 4)):
+            if sel.any():
+                print("   %-28s" % cname + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
+                      (("p1 landed", 9), ("p1 stores", 10), ("p1 done", 1), ("anchor", 2), ("E0", 3), ("end", 5))))
         last = int(np.argmax(rel[:, 5]))
         print("   last workgroup %d: end %.2f | tail start %.2f  granules in %.2f  sums done %.2f  tail end %.2f" %
               ((last, rel[last, 5]) + tuple(rel[last, 12:16])))
