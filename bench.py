@@ -570,7 +570,7 @@ def main():
         if split is not None:
             abb = algorithmic_bytes_bwd(B, K, H, W, S, n_neg)
             tb = split["backward_ms"] * 1e-3
-            roof_bwd = dict(bound="hbm", kernel="backward = corr_bwd_tile_build_kernel + corr_unsample_list_kernel (F16X3; corr_bwd_tile_kernel + corr_unsample_row_kernel in F32 mode) (step time minus the forward-only step time)",
+            roof_bwd = dict(bound="hbm", kernel="backward = corr_bwd_tile_build_kernel (corr_bwd_tile32_build_kernel in F32 mode) + corr_unsample_list_kernel (step time minus the forward-only step time)",
                             achieved=abb / tb / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=abb / tb / HBM_PEAK,
                             algorithmic_bytes=abb, us=tb * 1e6)
 

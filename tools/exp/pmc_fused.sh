@@ -8,7 +8,7 @@ for CNT in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   NAME=$(echo $CNT | tr ' ' '_' | cut -c1-40)
-  timeout 200 rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_$NAME -o pmc -- BWD=1 python tools/exp/fwd_loop.py 12 > /dev/null 2> $OUT/pmc_$NAME.err
+  timeout 200 rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_$NAME -o pmc -- env BWD=1 python tools/exp/fwd_loop.py 12 > /dev/null 2> $OUT/pmc_$NAME.err
   python tools/rocpd_stats.py $OUT/pmc_$NAME/pmc_results.db 2>&1 | grep -E "counter|corr_fused|corr_bwd_tile_build|corr_unsample_list" | tee -a $OUT/summary.txt
 done
 find $OUT -name "*.db" -delete

@@ -20,7 +20,7 @@ python tools/stamps_fused.py > $OUT/stamps_fused.txt 2>&1
 python tools/stamps_bwd_lists.py > $OUT/stamps_bwd_lists.txt 2>&1
 python tools/bench_knn.py > $OUT/knn_100k.json 2>> $OUT/bench.err
 find $OUT -name "*.db" -delete
-rm -rf $OUT/ks $OUT/pmc/pmc_*
+rm -rf $OUT/ks; find $OUT/pmc -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/bench*.json")):
