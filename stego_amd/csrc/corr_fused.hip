@@ -208,15 +208,18 @@ struct P1Layout {
     static constexpr int MROWS = 4 * 2 * G;                    // rows the four waves of the MFMA team take per pass
     static constexpr int XW = NJ <= 3 ? 2 : 0;                 // gather waves (8, 9) that take two overflow rows each in the FIRST pass
     // LIGHT (round 4): a workgroup WITHOUT a gather stream of its own - a self-correlation tile or a tile-less helper - samples with all
-    // twelve waves (2 G rows each) and stages in the WHOLE ring, linearly: it carries most of phase 1 (see the kernel)
-    static constexpr int ROWS = LIGHT ? 12 * 2 * G : MROWS + 2 * XW;     // rows of a pass = geometry of the staging area
+    // twelve waves (2 G rows each; the eight gather waves a second chunk of 2 when the registers allow G = 2) and stages in the WHOLE
+    // ring, linearly; the context rows of the backward go straight to memory (nobody reads them in this launch: plain stores).  It
+    // carries phase 1 for its XCD (see the kernel)
+    static constexpr int XB = NJ <= 3 ? 1 : 0;                 // second chunk of the gather waves
+    static constexpr int ROWS = LIGHT ? 12 * 2 * G + 8 * 2 * XB : MROWS + 2 * XW;     // rows of a pass = geometry of the staging area
     static constexpr int STAGE_BYTES = ROWS * 128;             // one feature stage of a pass (either format)
     static constexpr int SPP = LIGHT ? 1 : RS_SIDE / STAGE_BYTES;        // feature stages per piece
     static_assert(LIGHT || NCH2 <= 2 * SPP, "feature stages fit pieces 0-1");
     static_assert(LIGHT || (4 * ROWS * 128 <= RS_SIDE && ROWS * (128 + 4) * 4 <= RS_SIDE), "code stages fit piece 2, context rows piece 3");
     static constexpr int CF = LIGHT ? NCH2 * STAGE_BYTES : 2 * RS_STAGE;
-    static constexpr int CX = LIGHT ? CF + 4 * ROWS * 128 : 3 * RS_STAGE;
-    static_assert(!LIGHT || CX + ROWS * (128 + 4) * 4 <= RS_NS * RS_STAGE, "the light staging fits the ring");
+    static constexpr int CX = LIGHT ? 0 : 3 * RS_STAGE;        // (LIGHT: not staged)
+    static_assert(!LIGHT || CF + 4 * ROWS * 128 <= RS_NS * RS_STAGE, "the light staging fits the ring");
     __device__ static __forceinline__ int feat_plane(int s2, int pp)
     {
         if constexpr (LIGHT) return s2 * STAGE_BYTES + pp * ROWS * RB;
@@ -370,13 +373,16 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
             const int k = 64 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r1;
         }
-        if (2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(lds_cx + lr * crow + 8 * hl) = r0;
-        if (64 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (64 + hl)) = r1;
+        unsigned char* cx_row = lds_cx + lr * crow;
+        if constexpr (LIGHT) cx_row = reinterpret_cast<unsigned char*>(prm.cs + ((size_t)ba[g] * TP + qq) * prm.LDK);     // straight to memory
+        const bool cx_on = !LIGHT || act[g];
+        if (cx_on && 2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(cx_row + 8 * hl) = r0;
+        if (cx_on && 64 + hl < prm.KQ) *reinterpret_cast<float*>(cx_row + 4 * (64 + hl)) = r1;
         if (96 + hl < kall) {
             const int k = 96 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r2;
         }
-        if (96 + hl < prm.KQ) *reinterpret_cast<float*>(lds_cx + lr * crow + 4 * (96 + hl)) = r2;
+        if (cx_on && 96 + hl < prm.KQ) *reinterpret_cast<float*>(cx_row + 4 * (96 + hl)) = r2;
         if (act[g] && hl == 0) prm.nrm[(size_t)ba[g] * TP + qq] = nr;
     };
 #pragma unroll
@@ -415,7 +421,7 @@ __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int 
         for (int u = lane; u < nrows * 8; u += 64)
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), csf_rsrc, base + u * 16, 0, 16);
     }
-    if (pl < nplanes) {                                              // context rows (LDK floats: whole 16-byte units)
+    if (!LIGHT && pl < nplanes) {                                    // context rows (LDK floats: whole 16-byte units)
         const unsigned char* src = lds_cx + row0 * crow;
         const unsigned base = (unsigned)(((size_t)set * TP + q0) * crow);
         for (int u = lane; u < (nrows * crow) >> 4; u += 64)
@@ -799,28 +805,28 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         }
     }
     if (p1_here && p1_is_light) {
-        // ---- a light workgroup: every wave samples 2 G rows, the MFMA team copies out and publishes
-        const int lr0 = 2 * LYL::G * wave8;
-        if (mfma_team) __builtin_amdgcn_s_setprio(3);
+        // ---- a light workgroup: every wave samples 2 G rows (the gather waves 2 more), all twelve copy out, one lane publishes
+        const int lr0 = mfma_team ? 2 * LYL::G * wave : LYL::MROWS + 2 * LYL::G * (wave8 - 4);
+        __builtin_amdgcn_s_setprio(3);
         if (p1beg + lr0 < p1end)
             p1_sample_rows<NJ, PREC, NKCT, LYL::G, true>(prm, p1x, p1beg, p1end, lr0, lane, ring, (stamp_on && mfma_team) ? ts + 8 : nullptr);
-        if (!mfma_team) {
-            team_arrive(team_cnt, lane);
-        } else {
-            const int nrows = p1end - p1beg;
-            team_barrier(team_cnt, FUSED_WAVES, lane);
-            if (nrows > 0) {
-                const int to_edge = (((p1beg >> 7) + 1) << 7) - p1beg;
-                const int n0 = min(nrows, to_edge);
-                p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, 0, n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
-                if (n0 < nrows) p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, n0, nrows - n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
-            }
-            if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have landed
-            team_barrier(team_cnt, FUSED_WAVES + 4, lane);
-            if (tid == 0 && nrows > 0) p1_publish(prm, p1x, p1beg, nrows);
-            __builtin_amdgcn_s_setprio(0);
+        if constexpr (LYL::XB > 0) {
+            const int lr1 = LYL::MROWS + 8 * 2 * LYL::G + 2 * (wave8 - 4);
+            if (!mfma_team && p1beg + lr1 < p1end) p1_sample_rows<NJ, PREC, NKCT, 1, true>(prm, p1x, p1beg, p1end, lr1, lane, ring, nullptr);
         }
+        const int nrows = p1end - p1beg;
+        team_barrier(team_cnt, FUSED_WAVES, lane);
+        if (nrows > 0) {
+            const int to_edge = (((p1beg >> 7) + 1) << 7) - p1beg;
+            const int n0 = min(nrows, to_edge);
+            p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, 0, n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+            if (n0 < nrows) p1_copy_out<NJ, PREC, true>(prm, p1x, p1beg, n0, nrows - n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+        }
+        if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+        team_barrier(team_cnt, 2 * FUSED_WAVES, lane);
+        if (tid == 0 && nrows > 0) p1_publish(prm, p1x, p1beg, nrows);
+        __builtin_amdgcn_s_setprio(0);
     } else if (mfma_team && p1_here) {
         const int x = p1x, beg = p1beg, end = p1end;
         unsigned epoch = 0;
@@ -1501,7 +1507,7 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     // phase 1 carried by the light workgroups (see the kernel): one round, whole images per XCD, a workgroup on every CU, and what the
     // light ones cannot take fits one pass (16 rows at C = 384, 8 at 768) of the others
     {
-        const int G = prm.C <= 384 ? 2 : 1, rowsL = 24 * G, rowsH = 8 * G;
+        const int G = prm.C <= 384 ? 2 : 1, rowsL = 24 * G + (prm.C <= 384 ? 16 : 0), rowsH = 8 * G;
         const int per_x = prm.B / 8, slots = all / 8, tile_slots = n_tiles / 8;
         const int n_light = per_x + (slots - tile_slots), n_heavy = slots - n_light;
         const int R = per_x * TP, rest = R - n_light * rowsL;
