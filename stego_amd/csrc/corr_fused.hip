@@ -233,6 +233,28 @@ __device__ __forceinline__ float blend4(const float4 w, float t0, float t1, floa
     return __builtin_fmaf(w.w, t3, __builtin_fmaf(w.z, t2, __builtin_fmaf(w.y, t1, w.x * t0)));
 }
 
+// Sum over the 32 lanes of a half-wave, in every lane: four DPP steps inside each 16-lane row + ONE exchange between the two rows.  The
+// butterfly of five __shfl_xor is five dependent ds_bpermute round trips through the LDS crossbar - with the split's lane swaps 32 per wave
+// and pass, 5.5 us between "taps landed" and "rows staged" under the load of phase 1 (stamps, profiles/r04h).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v, bool butterfly)
+{
+    if (butterfly) {                                  // (debug 4096: the reduction of rounds 2-3)
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    v += dpp_mov<0xB1>(v);                            // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                            // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);                           // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v += dpp_mov<0x140>(v);                           // row_mirror: the two halves of a row
+    return v + __shfl_xor(v, 16, 64);                 // the other row of the half-wave
+}
+
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
 template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false>
@@ -243,6 +265,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
     constexpr int ROWS = LY::ROWS;
     const int hl = lane & 31, hw = lane >> 5;
     const int crow = prm.LDK * 4;
+    const bool bfly = (prm.debug & 4096) != 0;
     unsigned char* lds_cf = lds + LY::CF;
     unsigned char* lds_cx = lds + LY::CX;
     const MapV mf = prm.feats, mc = prm.code;
@@ -318,8 +341,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
                 v[j][e] = x;
                 ss = __builtin_fmaf(x, x, ss);
             }
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        ss = half_wave_sum(ss, bfly);
         // F.normalize eps (modules.py:276); padding points (zero taps) are written as zeros
         const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(sqrtf(ss), 1e-10f)) : 0.f;
 #pragma unroll
@@ -334,8 +356,8 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
                 split_f16_pair(vn[0], vn[1], h0, l0);
                 split_f16_pair(vn[2], vn[3], h1, l1);
                 const bool odd = hl & 1;                          // even lanes collect the hi halves of a lane pair, odd the lo
-                const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64);
-                const unsigned r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+                const unsigned r0 = bfly ? __shfl_xor(odd ? h0 : l0, 1, 64) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? h0 : l0), 0xB1, 0xF, 0xF, true);
+                const unsigned r1 = bfly ? __shfl_xor(odd ? h1 : l1, 1, 64) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? h1 : l1), 0xB1, 0xF, 0xF, true);
                 const u32x4 d = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
                 const int c = 128 * j + 4 * (hl & ~1);
                 const int u = ((c & 31) >> 3) ^ ((qq >> 2) & 3);
@@ -357,8 +379,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         if (64 + hl >= prm.K) r1 = 0.f;
         if (96 + hl >= prm.K) r2 = 0.f;
         float cs2 = __builtin_fmaf(r2, r2, __builtin_fmaf(r1, r1, __builtin_fmaf(r0[1], r0[1], r0[0] * r0[0])));
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) cs2 += __shfl_xor(cs2, m, 64);
+        cs2 = half_wave_sum(cs2, bfly);
         const float nr = valid ? sqrtf(cs2) : 0.f;
         const float cinv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
         r0 = r0 * cinv;
@@ -789,7 +810,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     if (prm.p1_light) {
         const int tile_slots = (n_tiles - p1x + 7) >> 3;                 // slots of this XCD that hold a tile
         const int n_light = p1nb + (p1nslot - tile_slots), n_heavy = p1nslot - n_light;
-        const int R = (int)p1L, capL = n_light * LYL::ROWS;
+        const int rowsL = (prm.debug & 2048) ? 12 * 2 * LYL::G : LYL::ROWS;       // (debug 2048: no second chunk - the gathered tiles keep a few rows)
+        const int R = (int)p1L, capL = n_light * rowsL;
         p1_is_light = p1r < p1nb || p1r >= tile_slots;
         const int lr = p1r < p1nb ? p1r : p1nb + (p1r - tile_slots);     // rank among the light / the other workgroups of the XCD
         const int hr = p1r - p1nb;
@@ -797,8 +819,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             p1beg = p1_is_light ? R * lr / n_light : 0;
             p1end = p1_is_light ? R * (lr + 1) / n_light : 0;
         } else if (p1_is_light) {
-            p1beg = LYL::ROWS * lr;
-            p1end = p1beg + LYL::ROWS;
+            p1beg = rowsL * lr;
+            p1end = p1beg + rowsL;
         } else {
             p1beg = capL + (int)((long long)(R - capL) * hr / n_heavy);
             p1end = capL + (int)((long long)(R - capL) * (hr + 1) / n_heavy);
@@ -839,8 +861,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             const int n_extra = nrows > LY::MROWS ? (nrows - LY::MROWS + 1) >> 1 : 0;          // gather waves arriving at this barrier
             if (2 * LY::G * wave < min(nrows, LY::MROWS))       // (a wave without rows in this pass goes straight to the barrier)
                 p1_sample_rows<NJ, PREC, NKCT, LY::G>(prm, x, blk0, min(end, blk0 + LY::MROWS), 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
+            if (stamp_on && (prm.debug & 1024)) ts[12] = __builtin_amdgcn_s_memrealtime();
             epoch += 4 + n_extra;
             team_barrier(team_cnt, epoch, lane);
+            if (stamp_on && (prm.debug & 1024)) ts[13] = __builtin_amdgcn_s_memrealtime();
             // a run must stay inside one anchor: split the pass at an anchor boundary
             const int to_edge = (((blk0 >> 7) + 1) << 7) - blk0;
             const int n0 = min(nrows, to_edge);
@@ -848,6 +872,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             if (n0 < nrows) p1_copy_out<NJ, PREC>(prm, x, blk0, n0, nrows - n0, wave, 4, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
             if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have landed
+            if (stamp_on && (prm.debug & 1024)) ts[14] = __builtin_amdgcn_s_memrealtime();
             epoch += 4;
             team_barrier(team_cnt, epoch, lane);
             if (tid == 0) p1_publish(prm, x, blk0, nrows);
@@ -1285,10 +1310,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         if (lane == 0) red[wave] = s;
-        if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
-        if (stamp_on) ts[13] = __builtin_amdgcn_s_memrealtime();
+        if (stamp_on && !(prm.debug & 1024)) ts[12] = __builtin_amdgcn_s_memrealtime();
+        if (stamp_on && !(prm.debug & 1024)) ts[13] = __builtin_amdgcn_s_memrealtime();
         park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
-        if (stamp_on) ts[14] = __builtin_amdgcn_s_memrealtime();
+        if (stamp_on && !(prm.debug & 1024)) ts[14] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();                             // E1: Tfd and the four partial sums are complete
     if (tid == 0) {
@@ -1507,7 +1532,7 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     // phase 1 carried by the light workgroups (see the kernel): one round, whole images per XCD, a workgroup on every CU, and what the
     // light ones cannot take fits one pass (16 rows at C = 384, 8 at 768) of the others
     {
-        const int G = prm.C <= 384 ? 2 : 1, rowsL = 24 * G + (prm.C <= 384 ? 16 : 0), rowsH = 8 * G;
+        const int G = prm.C <= 384 ? 2 : 1, rowsL = 24 * G + ((prm.C <= 384 && !(prm.debug & 2048)) ? 16 : 0), rowsH = 8 * G;
         const int per_x = prm.B / 8, slots = all / 8, tile_slots = n_tiles / 8;
         const int n_light = per_x + (slots - tile_slots), n_heavy = slots - n_light;
         const int R = per_x * TP, rest = R - n_light * rowsL;

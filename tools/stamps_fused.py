@@ -55,6 +55,10 @@ for prec in (capi.PREC_F16X3,):
             if sel.any():
                 print("   %-28s" % cname + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
                       (("p1 landed", 9), ("p1 stores", 10), ("p1 done", 1), ("anchor", 2), ("E0", 3), ("end", 5))))
+        if dbg & 1024:      # diagnostic: the gathered tiles' phase 1 in detail (stamps 12-14 are phase-1 stamps in this mode)
+            sel = slot >= 4
+            print("   gathered slots, phase 1: " + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
+                  (("taps", 8), ("landed", 9), ("computed", 12), ("team barrier", 13), ("stores issued", 10), ("stores landed", 14), ("done", 1), ("tile assigned", 6), ("head start", 15))))
         last = int(np.argmax(rel[:, 5]))
         print("   last workgroup %d: end %.2f | tail start %.2f  granules in %.2f  sums done %.2f  tail end %.2f" %
               ((last, rel[last, 5]) + tuple(rel[last, 12:16])))
