@@ -89,6 +89,23 @@ __device__ __forceinline__ void knn_copy(const unsigned char* __restrict__ gsrc,
                                          (__attribute__((address_space(3))) void*)(lds_dst + pc * 1024), 16, 0, 0);
 }
 
+// Round 4: the AREG path (D <= 384) keeps KNN_NST database chunks in LDS and has three copies in flight.  With two stages the copy of
+// chunk g + 1 was issued when chunk g's MFMAs started (0.64 us of work) and awaited right after them: every chunk waited ~0.9 us for
+// its copy (MFMA-only run 22 ms against 9.2 ms of matrix-core time; copies-only 11 ms).  LDS-DMA from inline asm, as in the fused forward:
+// the compiler neither counts these copies nor drains them in front of a barrier; the waits are explicit and counted (9 pieces per wave
+// and chunk, completed in order).  And the sixth query chunk moved from registers to a resident LDS image: with all 192 fragment registers
+// the kernel sat at 255 VGPRs + 106 spilled to AGPRs and the compiler fetched the lo halves of the B fragments one by one through ONE
+// register quad, an LDS round trip in front of 4 of every 12 MFMAs (ISA: ds_read_b128 v[48:51] ; s_waitcnt lgkmcnt(0) ; v_mfma ...).
+constexpr int KNN_NST = 3;                          // + one resident A chunk: 4 x 36 KB of LDS
+constexpr int KNN_RCH = 5;                          // query chunks held in registers (160 VGPRs); the sixth lives in LDS
+__device__ __forceinline__ void knn_dma_piece(const unsigned char* gsrc_lane, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+}
+static_assert(KNN_SIDE % 4096 == 0, "whole 1 KB pieces per wave");
+
 // wave-row layout: this wave's 32 query rows x 128 columns: acc[ni] = 32x32 block of columns 32 ni .. 32 ni + 31
 __device__ __forceinline__ void knn_mma_chunk(const half_t* __restrict__ As, const half_t* __restrict__ Bs, f32x16 (&acc)[4],
                                               int lane, int wave)
@@ -146,51 +163,7 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-struct KnnRow { float v; int i; };
-
-// Slow path of the selection for one register row pair: insert every candidate of the 4 column blocks into the two
-// sorted lists (one per half-wave).  Deliberately NOT inlined: 16 inlined copies per tile made the kernel ~75 KB of
-// code (the instruction cache is 64 KB per CU pair); the fast path (one compare + ballot) stays inline.
-__device__ __attribute__((noinline)) KnnRow knn_insert_rows(float a0, float a1, float a2, float a3, int cvmask, float lv, int li,
-                                                           int k, int col0)
-{
-    const int lane = threadIdx.x & 63, slot = lane & 31;
-    const bool upper = lane >= 32;
-    float thr = upper ? readlane_f(lv, 32 + k - 1) : readlane_f(lv, k - 1);
-#pragma unroll 1
-    for (int ni = 0; ni < 4; ++ni) {
-        const float a = ni == 0 ? a0 : (ni == 1 ? a1 : (ni == 2 ? a2 : a3));
-        const bool cvn = (cvmask >> ni) & 1;
-        unsigned long long done = 0ull;
-        unsigned long long m = __ballot(cvn && a > thr);
-        while (m != 0ull) {
-            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            const int c0 = mlo ? __builtin_ctz(mlo) : 0, c1 = mhi ? __builtin_ctz(mhi) : 0;    // first candidate per half
-            const float x0 = readlane_f(a, c0), x1 = readlane_f(a, 32 + c1);
-            const bool have = upper ? mhi != 0u : mlo != 0u;
-            const float x = upper ? x1 : x0;
-            const int cl = upper ? c1 : c0;
-            const int xi = col0 + 32 * ni + cl;
-            // position = number of entries >= x in my half; everything behind it moves down one slot
-            const unsigned long long ge = __ballot(lv >= x);
-            const int pos = upper ? __builtin_popcount((unsigned)(ge >> 32)) : __builtin_popcount((unsigned)ge);
-            const float upv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lv), 0x138, 0xf, 0xf, false));
-            const int upi = __builtin_amdgcn_update_dpp(0, li, 0x138, 0xf, 0xf, false);             // wave_shr:1
-            if (have) {
-                if (slot == pos) { lv = x; li = xi; }
-                else if (slot > pos) { lv = upv; li = upi; }
-            }
-            done |= (mlo ? 1ull << c0 : 0ull) | (mhi ? 1ull << (32 + c1) : 0ull);
-            thr = upper ? readlane_f(lv, 32 + k - 1) : readlane_f(lv, k - 1);
-            m = __ballot(cvn && a > thr) & ~done;
-        }
-    }
-    KnnRow r;
-    r.v = lv; r.i = li;
-    return r;
-}
-
-constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 192 VGPRs
+constexpr int KNN_AREG_CHUNKS = 6;          // D <= 384: the query block's MFMA fragments live in 160 VGPRs + one resident LDS chunk
 
 // grid = (query blocks, NS); block = 256.  AREG: LDS = 2 stages x B chunk, A in registers (D <= 384);
 // otherwise 2 stages x (A chunk + B chunk).
@@ -228,17 +201,25 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
 
     const int nstage = (tile1 - tile0) * NCH;
     constexpr int STAGE = AREG ? KNN_SIDE : 2 * KNN_SIDE;
+    const unsigned smem_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)smem);
     auto issue = [&](int g) {
         const int t = tile0 + g / NCH, c = g - (g / NCH) * NCH;
-        unsigned char* dst = smem + (g & 1) * STAGE;
-        if constexpr (!AREG) knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
-        knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + (AREG ? 0 : KNN_SIDE), wave, lane);
+        if constexpr (AREG) {
+            const unsigned char* src = img + ((size_t)t * NCH + c) * KNN_SIDE + lane * 16;
+            const unsigned dst = smem_addr + (g % KNN_NST) * STAGE;
+#pragma unroll
+            for (int i = 0; i < KNN_SIDE / 4096; ++i) knn_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
+        } else {
+            unsigned char* dst = smem + (g & 1) * STAGE;
+            knn_copy(Aimg + (size_t)c * KNN_SIDE, dst, wave, lane);
+            knn_copy(img + ((size_t)t * NCH + c) * KNN_SIDE, dst + KNN_SIDE, wave, lane);
+        }
     };
-    f16x8 Ah[AREG ? KNN_AREG_CHUNKS : 1][KC / 16], Al[AREG ? KNN_AREG_CHUNKS : 1][KC / 16];
+    f16x8 Ah[AREG ? KNN_RCH : 1][KC / 16], Al[AREG ? KNN_RCH : 1][KC / 16];
     if constexpr (AREG) {
         const int r = lane & 31, half = lane >> 5;
 #pragma unroll
-        for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
+        for (int c = 0; c < KNN_RCH; ++c) {
             const half_t* ap = reinterpret_cast<const half_t*>(Aimg + (size_t)min(c, NCH - 1) * KNN_SIDE) + (32 * wave + r) * LDH + 8 * half;
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ++ks) {
@@ -247,7 +228,16 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
             }
         }
     }
-    if (nstage > 0) issue(0);
+    if constexpr (AREG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the query fragments: the counted waits below start from zero
+        if (NCH > KNN_RCH) {                                           // the resident query chunk (completed in front of stage 0)
+            const unsigned char* src = Aimg + (size_t)KNN_RCH * KNN_SIDE + lane * 16;
+            const unsigned dst = smem_addr + KNN_NST * STAGE;
+#pragma unroll
+            for (int i = 0; i < KNN_SIDE / 4096; ++i) knn_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
+        }
+        for (int s0 = 0; s0 < KNN_NST - 1 && s0 < nstage; ++s0) issue(s0);
+    } else if (nstage > 0) issue(0);
     f32x16 acc[4];
     int g = 0;
     for (int t = tile0; t < tile1; ++t) {
@@ -259,9 +249,21 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
 #pragma unroll
             for (int c = 0; c < KNN_AREG_CHUNKS; ++c) {
                 if (c < NCH) {
-                    sync_after_lds_dma();                 // stage g landed; stage g-1 is free
-                    if (g + 1 < nstage) issue(g + 1);
-                    if (!(prm.debug & 2)) knn_mma_chunk_areg(Ah[c], Al[c], reinterpret_cast<const half_t*>(smem + (g & 1) * STAGE), acc, lane);
+                    // my pieces of stage g have landed (the copies of g + 1 and g + 2 may still fly), then everybody's; the slot of stage
+                    // g - 1 - which everyone has finished reading - takes the copy of stage g + 3
+                    const int ahead = nstage - 1 - g;
+                    if (ahead >= 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (g + KNN_NST - 1 < nstage) issue(g + KNN_NST - 1);
+                    const half_t* Bst = reinterpret_cast<const half_t*>(smem + (g % KNN_NST) * STAGE);
+                    if (!(prm.debug & 2)) {
+                        // (c is a constant after unrolling; the index is clamped for the branch that is never taken)
+                        if (c < KNN_RCH) knn_mma_chunk_areg(Ah[c < KNN_RCH ? c : 0], Al[c < KNN_RCH ? c : 0], Bst, acc, lane);
+                        else knn_mma_chunk(reinterpret_cast<const half_t*>(smem + KNN_NST * STAGE), Bst, acc, lane, wave);
+                    }
                     ++g;
                 }
             }
@@ -279,19 +281,41 @@ __global__ void __launch_bounds__(NTHREADS) knn_tile_kernel(const KnnParams prm)
         bool cv[4];                                    // column of this lane in block ni exists (only the last tile has holes)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) cv[ni] = col0 + 32 * ni + slot < prm.N;
-        const int cvmask = (cv[0] ? 1 : 0) | (cv[1] ? 2 : 0) | (cv[2] ? 4 : 0) | (cv[3] ? 8 : 0);
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             // everything wave-uniform goes through SGPRs (v_readlane / s_ff1 / s_bcnt1): the first version used
             // ds_bpermute shuffles here and the selection cost more than the MFMAs (32 of 55 ms at N = 100 k)
             const float thr = upper ? readlane_f(lv[rr], 32 + k - 1) : readlane_f(lv[rr], k - 1);      // current k-th best of my row
-            const bool any4 = (cv[0] && acc[0][rr] > thr) || (cv[1] && acc[1][rr] > thr) || (cv[2] && acc[2][rr] > thr) ||
-                              (cv[3] && acc[3][rr] > thr);
-            if (__ballot(any4) == 0ull || (prm.debug & 8)) continue;       // the common case (debug 8: never insert)
+            // one candidate mask per column block (round 4: the insertion used to be a non-inlined call that walked the four blocks with
+            // fresh ballots and threshold reads per candidate: ~1600 cycles per entry with one wave per SIMD, 12 of the 36 ms at N = 100 k)
+            unsigned long long cm[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) cm[ni] = __ballot(cv[ni] && acc[ni][rr] > thr);
+            if ((cm[0] | cm[1] | cm[2] | cm[3]) == 0ull || (prm.debug & 8)) continue;       // the common case (debug 8: never insert)
             if ((prm.debug & 4) && lane == 0) atomicAdd(prm.counters, 1ull);
-            const KnnRow nr = knn_insert_rows(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], cvmask, lv[rr], li[rr], k, (int)col0);
-            lv[rr] = nr.v;
-            li[rr] = nr.i;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                unsigned long long m = cm[ni];
+                const float a = acc[ni][rr];
+                while (m != 0ull) {                                          // (uniform) one candidate per half-wave and turn
+                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+                    const int c0 = mlo ? __builtin_ctz(mlo) : 0, c1 = mhi ? __builtin_ctz(mhi) : 0;
+                    const float x0 = readlane_f(a, c0), x1 = readlane_f(a, 32 + c1);
+                    const bool have = upper ? mhi != 0u : mlo != 0u;
+                    const float x = upper ? x1 : x0;
+                    const int xi = (int)col0 + 32 * ni + (upper ? c1 : c0);
+                    // position = number of entries >= x in my half; beyond k - 1 the candidate has been overtaken meanwhile
+                    const unsigned long long ge = __ballot(lv[rr] >= x);
+                    const int pos = upper ? __builtin_popcount((unsigned)(ge >> 32)) : __builtin_popcount((unsigned)ge);
+                    const float upv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lv[rr]), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(0, li[rr], 0x138, 0xf, 0xf, false);      // wave_shr:1
+                    if (have && pos < k) {
+                        if (slot == pos) { lv[rr] = x; li[rr] = xi; }
+                        else if (slot > pos) { lv[rr] = upv; li[rr] = upi; }
+                    }
+                    m &= ~((mlo ? 1ull << c0 : 0ull) | (mhi ? 1ull << (32 + c1) : 0ull));
+                }
+            }
         }
     }
     // ---- write the partial lists of this segment (sorted descending)
@@ -391,7 +415,7 @@ hipError_t launch_knn(const float* X, long long N, int D, long long ldx, int k, 
 
     hipLaunchKernelGGL(knn_prep_kernel, dim3(prm.nblk), dim3(NTHREADS), 0, stream, prm);
     const bool areg = prm.NCH <= KNN_AREG_CHUNKS;
-    const int lds = areg ? 2 * KNN_SIDE : 4 * KNN_SIDE;
+    const int lds = areg ? (KNN_NST + 1) * KNN_SIDE : 4 * KNN_SIDE;
     hipError_t ea = ensure_dynamic_lds(areg ? reinterpret_cast<const void*>(&knn_tile_kernel<true>)
                                             : reinterpret_cast<const void*>(&knn_tile_kernel<false>), lds);
     if (ea != hipSuccess) return ea;
