@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define STEGO_ABI_VERSION 4   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
+#define STEGO_ABI_VERSION 5   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
                                 * 3: StegoCorrDesc.flags (STEGO_FLAG_SHARED_DEVICE is per call, no longer a process-wide knob)
-                                * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now */
+                                * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now
+                                * 5: stego_corr_event_counters */
 
 enum {
     STEGO_OK = 0,
@@ -216,6 +217,12 @@ int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_
 int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
                             const StegoMap* code, const StegoMap* code_pos);
 int stego_corr_workspace_prepare(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes, stego_stream_t stream);
+/* DEVICE address of two 32-bit event words inside a forward workspace, cumulative since it was prepared: [0] tiles of the single-launch
+ * forward that gave up waiting for their anchor set and sampled it themselves, [1] negative tiles whose old_mean rendezvous timed out
+ * and were finished by the launch's last workgroup.  Both are zero in normal operation; on a device shared with other kernels (or
+ * partitioned) they say why a launch was ~30 us slower - results are the same either way.  No launch, no synchronisation: the caller
+ * copies the words when it wants them.  NULL on a bad descriptor / workspace. */
+const uint32_t* stego_corr_event_counters(const StegoCorrDesc* desc, const void* workspace, size_t workspace_bytes);
 /* The same on a stream of the library's own, returning when the workspace IS prepared - without calling any HIP synchronisation API
  * (it watches a pinned flag word that a one-thread kernel sets behind the memset), so it is legal while the calling thread captures
  * a graph on another stream: there stego_corr_workspace_prepare(capture stream) would become a memset node that every replay repeats in

@@ -12,7 +12,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_SHARED_DEVICE = 1          # StegoCorrDesc.flags
 PREC_F32 = 0
 PREC_F16X3 = 1
@@ -76,6 +76,7 @@ SIGNATURES = {
     "stego_corr_workspace_prepare": (c_int32, [_D, _P, c_size_t, _P]),
     "stego_corr_workspace_prepare_now": (c_int32, [_D, _P, c_size_t]),
     "stego_corr_fwd_launches": (c_int32, [_D] + [_M] * 4),
+    "stego_corr_event_counters": (c_void_p, [_D, _P, c_size_t]),
     "stego_ref_draws": (c_int32, [ctypes.c_uint64, ctypes.c_uint64, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "stego_ref_draws_advance": (ctypes.c_uint64, [c_int64, c_int32, c_int32, c_int32]),
     "stego_tokens_from_cache": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
@@ -413,6 +414,18 @@ def fast_draws(seed, shape, n_neg, B):
     with _on_device(dev):
         _check(lib.stego_fast_draws(_ptr(seed), c1.numel(), n_neg, B, _ptr(c1), _ptr(c2), _ptr(perms), _stream()))
     return c1, c2, perms
+
+
+def event_counters(desc, ws):
+    """(tiles that gave up waiting for their anchor, negative tiles whose old_mean rendezvous timed out) since the forward workspace `ws`
+    was prepared (stego_corr_event_counters: two device words; this copies them - a synchronisation, tools and tests only)."""
+    lib = load()
+    p = lib.stego_corr_event_counters(byref(desc), _ptr(ws), ws.numel())
+    if not p:
+        raise RuntimeError("stego_corr_event_counters: bad descriptor or workspace")
+    off = int(p) - ws.data_ptr()
+    w = ws[off: off + 8].view(torch.int32).cpu()
+    return int(w[0]), int(w[1])
 
 
 def corr_fwd_launches(desc, feats, feats_pos, code, code_pos):

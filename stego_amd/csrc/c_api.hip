@@ -325,6 +325,15 @@ size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc)
     return geometry(desc, false).ws_bytes;
 }
 
+const uint32_t* stego_corr_event_counters(const StegoCorrDesc* desc, const void* workspace, size_t workspace_bytes)
+{
+    if (check_desc(desc, false) != STEGO_OK || !workspace) return nullptr;
+    const Geometry g = geometry(desc, false);
+    if (workspace_bytes < g.ws_bytes) return nullptr;
+    // the block of the done counter (plan_fwd: sync + sync_bytes - 256): word 0 is the counter, words 1-2 the events
+    return reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(workspace) + g.stats_bytes + g.sync_bytes - 256) + 1;
+}
+
 size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc)
 {
     if (check_desc(desc, false) != STEGO_OK) return 0;

@@ -982,6 +982,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 __builtin_amdgcn_s_sleep(10);
             }
             if (!ready) {
+                // (counted: a host reads the two event words through stego_corr_event_counters - a launch that keeps taking this path
+                // on a shared or partitioned device is ~30 us slower and says so nowhere else)
+                if (lane == 0) __hip_atomic_fetch_add(prm.done_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // The owners did not show up in time (not co-resident: a shared or over-subscribed device).  Sample the
                 // whole anchor here, this wave alone (staging in the A sides, which nothing touches before my own LDS-DMA below):
                 // identical inputs give identical bytes, so racing with a late owner is benign; nothing else in the
@@ -1466,6 +1469,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
         for (int w = 0; w < FUSED_WAVES; ++w) { s1 += red[16 + w * 2]; s2 += red[16 + w * 2 + 1]; }
+        if (gave_up) __hip_atomic_fetch_add(prm.done_cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (event word: see above)
         unsigned long long* g3 = gst + (size_t)tile * 3;
         __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

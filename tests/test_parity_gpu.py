@@ -56,7 +56,7 @@ def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None, preci
 def test_library_loaded_is_the_in_tree_hip_extension():
     lib = capi.load()
     assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
-    assert lib.stego_abi_version() == 4
+    assert lib.stego_abi_version() == 5
     assert torch.cuda.is_available()
 
 
@@ -1351,3 +1351,39 @@ def test_lazy_loss_sum_gives_the_plain_gradients_eagerly_and_inside_a_captured_g
     torch.cuda.synchronize()
     assert torch.allclose(c.grad, res["plain"][1], rtol=1e-5, atol=1e-6 * float(res["plain"][1].abs().max()))
     assert torch.allclose(cp.grad, res["plain"][2], rtol=1e-5, atol=1e-6 * float(res["plain"][2].abs().max()))
+
+
+def test_event_counters_report_the_give_up_and_repair_paths():
+    """stego_corr_event_counters (ABI 5): zero in normal operation; every tile that gives up on its anchor (debug 64 forces all of
+    them) and every negative tile whose old_mean rendezvous does not happen (debug 32) is counted - so a host on a shared or
+    partitioned device can tell why a launch was slow."""
+    import bench
+    dev = torch.device("cuda:0")
+    C, H, W, K = bench.WORKLOADS["vits8_224"]
+    B, S, n_neg = 32, 11, 5
+    cfg = bench.Cfg()
+    d = bench.make_inputs(B, C, H, W, K, S, n_neg, 77, dev)
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
+    lib = capi.load()
+
+    def run():
+        capi.corr_fwd(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], True)
+        torch.cuda.synchronize()
+        return capi.event_counters(desc, capi._prepared_ws(lib, desc, dev))
+
+    try:
+        # (cumulative since the workspace was prepared, and the workspace cache hands out the one an earlier test with this descriptor
+        # used: deltas)
+        base = run()
+        assert run() == base, "normal launches add nothing"
+        n_tiles = (2 + n_neg) * B
+        capi.debug_set("STEGO_DEBUG", 64)
+        a = run()
+        assert (a[0] - base[0], a[1] - base[1]) == (n_tiles, 0), (base, a)
+        capi.debug_set("STEGO_DEBUG", 32)
+        b = run()
+        assert (b[0] - a[0], b[1] - a[1]) == (0, n_neg * B), (a, b)
+        capi.debug_set("STEGO_DEBUG", 0)
+        assert run() == b
+    finally:
+        capi.debug_set("STEGO_DEBUG", 0)
