@@ -188,6 +188,154 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
         }
 }
 
+// ---------------------------------------------------------------------------------------------- round 4: row-block kernel
+// dense_rowblock_kernel (channels-last A maps, C <= 384): one PERSISTENT workgroup per (image, 128-pixel block of A).  The tile kernel
+// above stages both operands of every 128 x 128 tile through LDS with one chunk of look-ahead (6.1 rounds of one-tile workgroups, each
+// chunk waiting for its copy: ~20 us per tile slot) after a prep pass over BOTH maps.  Here the A block never touches LDS or the
+// workspace: the workgroup reads its 128 pixels straight from the fp32 map (each row by the two lanes that will own it in the MFMA A
+// layout), normalises, applies the power-of-two row scale and splits into fp16 hi / lo MFMA fragments IN REGISTERS (192 VGPRs, as the
+// KNN kernel's query block), then walks the B blocks of its image: chunks of the prepared B image through a three-stage LDS ring with
+// two copies in flight (LDS-DMA from inline asm, counted waits), 48 MFMAs per chunk and wave, the 32 x 128 slab of a wave stored from
+// the accumulators while the next block's copies fly.  Workgroups of image n sit on XCD n % 8 (they stream the same B image).  The prep
+// kernel runs for the B side only.
+constexpr int DR_NST = 3;
+constexpr int DR_MAXCH = 6;
+static_assert(DC_SIDE % 4096 == 0, "whole 1 KB pieces per wave");
+__device__ __forceinline__ void dense_dma_piece(const unsigned char* gsrc_lane, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+}
+
+__global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DenseParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ra_s = reinterpret_cast<float*>(smem + DR_NST * DC_SIDE);        // [128] 1 / row scale of the A block
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NCH = prm.NCH, C = prm.C;
+    // image n on XCD n % 8 (block b runs on XCD b % 8: observed, speed only)
+    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int n = (sl / prm.nbA) * 8 + x, mi = sl % prm.nbA;
+    if (n >= prm.B) return;
+    const int r = lane & 31, half = lane >> 5;
+
+    // ---- my row of the A block -> MFMA fragments (lane (r, half) holds channels 16 ks + 8 half .. + 7 of every 64-channel chunk)
+    const int pix = mi * TP + 32 * wave + r;
+    const bool rv = pix < prm.M;
+    const int hh = rv ? pix / prm.W1 : 0, ww = rv ? pix - hh * prm.W1 : 0;
+    const float* xrow = prm.a.p + (long long)n * prm.a.sn + (long long)hh * prm.a.sh + (long long)ww * prm.a.sw;
+    float ss = 0.f, mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < DR_MAXCH; ++c)
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int ch = 64 * c + 16 * ks + 8 * half;
+            if (c < NCH && rv && ch < C) {                    // (C % 8 == 0: a group of 8 is inside or outside)
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xrow + ch), v1 = *reinterpret_cast<const f32x4*>(xrow + ch + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ss += v0[e] * v0[e] + v1[e] * v1[e];
+                    mx = fmaxf(mx, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+                }
+            }
+        }
+    ss += __shfl_xor(ss, 32, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;            // norm(), modules.py:276
+    const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
+    inv *= rs;
+    if (half == 0) ra_s[32 * wave + r] = 1.f / rs;
+    f16x8 Ah[DR_MAXCH][KC / 16], Al[DR_MAXCH][KC / 16];
+#pragma unroll
+    for (int c = 0; c < DR_MAXCH; ++c)
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int ch = 64 * c + 16 * ks + 8 * half;
+            f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (c < NCH && rv && ch < C) { v0 = *reinterpret_cast<const f32x4*>(xrow + ch); v1 = *reinterpret_cast<const f32x4*>(xrow + ch + 4); }
+            unsigned h[4], l[4];
+            split_f16_pair(v0[0] * inv, v0[1] * inv, h[0], l[0]);
+            split_f16_pair(v0[2] * inv, v0[3] * inv, h[1], l[1]);
+            split_f16_pair(v1[0] * inv, v1[1] * inv, h[2], l[2]);
+            split_f16_pair(v1[2] * inv, v1[3] * inv, h[3], l[3]);
+            typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+            Ah[c][ks] = __builtin_bit_cast(f16x8, du32x4{h[0], h[1], h[2], h[3]});
+            Al[c][ks] = __builtin_bit_cast(f16x8, du32x4{l[0], l[1], l[2], l[3]});
+        }
+    __syncthreads();                                       // ra_s
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the counted waits below start from zero
+
+    // ---- the B blocks of image n: chunk stream g = nj * NCH + c
+    const unsigned char* Bimg = static_cast<const unsigned char*>(prm.imgB) + (size_t)n * prm.nbB * NCH * DC_SIDE;
+    const unsigned smem_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)smem);
+    const int nstage = prm.nbB * NCH;
+    auto issue = [&](int g) {
+        const unsigned char* src = Bimg + (size_t)g * DC_SIDE + lane * 16;
+        const unsigned dst = smem_addr + (g % DR_NST) * DC_SIDE;
+#pragma unroll
+        for (int i = 0; i < DC_SIDE / 4096; ++i) dense_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
+    };
+    for (int s0 = 0; s0 < DR_NST - 1 && s0 < nstage; ++s0) issue(s0);
+    float* outn = prm.out + (size_t)n * prm.M * prm.N;
+    constexpr int LO = TP * LDH;
+    int g = 0;
+    for (int nj = 0; nj < prm.nbB; ++nj) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < DR_MAXCH; ++c) {
+            if (c < NCH) {
+                if (nstage - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (g + DR_NST - 1 < nstage) issue(g + DR_NST - 1);
+                const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % DR_NST) * DC_SIDE) + r * LDH + 8 * half;
+#pragma unroll
+                for (int ks = 0; ks < KC / 16; ++ks) {
+                    f16x8 bh[4], bl[4];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                        bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                }
+                ++g;
+            }
+        }
+        // ---- my 32 x 128 slab.  C/D layout: col = lane & 31 (+ 32 ni), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+        const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cl = 32 * ni + (lane & 31);
+            const int col = nj * TP + cl;
+            const float sb = rb[cl];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rw = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int row = mi * TP + rw;
+                if (row < prm.M && col < prm.N) __builtin_nontemporal_store(acc[ni][e] * (ra_s[rw] * sb), outn + (size_t)row * prm.N + col);
+            }
+        }
+        // (the stores and the rb loads above are vector-memory operations too: they complete in order IN FRONT of the copies issued
+        // after them only if none of those is waited for by count - the copies of the next chunks were issued before them, so the
+        // counted waits stay valid once these are drained)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 size_t dense_workspace_bytes(int B, int C, int M, int N)
 {
     const size_t nbA = (M + TP - 1) / TP, nbB = (N + TP - 1) / TP, NCH = (C + KC - 1) / KC;
@@ -213,6 +361,17 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
                (reinterpret_cast<uintptr_t>(m.p) % 16) == 0;
     };
     const int vec = cl(a) && cl(b) ? 1 : 0;
+    if (vec && C % 8 == 0 && prm.NCH <= DR_MAXCH && !(knob(KNOB_DEBUG) & 8192)) {          // (debug 8192: the tile kernel)
+        // row-block kernel: the A map is consumed as it lies, only B is prepared (blocks [nbA, nbA + nbB) of every image)
+        DenseParams pb = prm;
+        pb.nbA = 0;                                    // the prep kernel's block index then runs over the B blocks only
+        hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * prm.nbB)), dim3(NTHREADS), 0, stream, pb, vec);
+        const int lds2 = DR_NST * DC_SIDE + 512;
+        hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel), lds2);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(dense_rowblock_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * prm.nbA)), dim3(NTHREADS), lds2, stream, prm);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * (prm.nbA + prm.nbB))), dim3(NTHREADS), 0, stream, prm, vec);
     const int lds = 4 * DC_SIDE;
     hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tile_kernel), lds);
