@@ -266,7 +266,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     const int variant = knob(KNOB_FWD_VARIANT);              // -1 (default) automatic, 1 three launches, 2 fused
     out->use_fused = !helper && variant != 1 && g.fs_bytes < ((size_t)1 << 31) && g.cs_bytes < ((size_t)1 << 31) &&
                      fused_supported(fp, d->precision);
-    // code dimensions above 72 exist on the fused path only (channels-last maps of the ViT widths, even K): the
+    // code dimensions above 72 exist on the fused path only (channels-last maps of the ViT widths): the
     // three-launch kernels hold both code operands in one LDS stage
     if (d->K > 72 && !out->use_fused) return STEGO_ERR_UNSUPPORTED;
     return STEGO_OK;
@@ -312,7 +312,7 @@ const char* stego_error_string(int code)
         case STEGO_OK: return "ok";
         case STEGO_ERR_NULL: return "required pointer is NULL";
         case STEGO_ERR_SHAPE: return "bad or inconsistent dimension";
-        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S*S<=128, K<=128 (K>72: even, channels-last maps with C = 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
+        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S*S<=128, K<=128 (K>72: channels-last maps with C = 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
         case STEGO_ERR_WORKSPACE: return "workspace too small";
         case STEGO_ERR_ALIGN: return "pointer not 4-byte aligned";
         default: return code >= STEGO_ERR_HIP ? "HIP runtime error (code - 1000 = hipError_t)" : "unknown error";

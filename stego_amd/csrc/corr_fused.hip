@@ -54,6 +54,7 @@ namespace stego {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_u __attribute__((aligned(4)));      // 16-byte gather of an 8-byte aligned code pixel (K % 4 == 2)
+typedef f32x2 f32x2_u __attribute__((aligned(4)));      // 8-byte gather of a code pixel that is only 4-byte aligned (odd K)
 
 constexpr int ANCHOR_CNT_STRIDE = 64;           // counters 256 bytes apart: pollers of different anchors hit different channels
 
@@ -292,6 +293,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
     const int c1 = 64 + hl < prm.K ? 64 + hl : 0;
     const int c2 = 96 + hl < prm.K ? 96 + hl : 0;
     const int c0 = 2 * hl < prm.K ? 2 * hl : 0;
+    const int cshift = (2 * hl < prm.K && 2 * hl + 1 >= prm.K) ? 1 : 0;        // my pair straddles the end of an odd-K pixel (K >= 3)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int4 of = taps_to_offsets(yx[g], mf.sh, mf.sw);
@@ -308,10 +310,16 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
     auto code_loads = [&](int g) {
         const int4 oc = taps_to_offsets(yx[g], mc.sh, mc.sw);
         const float* cimg = mc.p + (long long)ba[g] * mc.sn;
-        ct[g].a[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c0);
-        ct[g].a[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c0);
-        ct[g].a[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c0);
-        ct[g].a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
+        // (odd K: the last pair (K - 1, K) would read one float past the pixel - past the TENSOR for its last pixel: that lane loads
+        // (K - 2, K - 1) and keeps the second; pixels of an odd K are only 4-byte aligned)
+        ct[g].a[0] = *reinterpret_cast<const f32x2_u*>(cimg + oc.x + c0 - cshift);
+        ct[g].a[1] = *reinterpret_cast<const f32x2_u*>(cimg + oc.y + c0 - cshift);
+        ct[g].a[2] = *reinterpret_cast<const f32x2_u*>(cimg + oc.z + c0 - cshift);
+        ct[g].a[3] = *reinterpret_cast<const f32x2_u*>(cimg + oc.w + c0 - cshift);
+        if (cshift) {
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) ct[g].a[tq] = f32x2{ct[g].a[tq][1], 0.f};
+        }
         // (K > 64 needs three K-chunks, K > 96 four: the registers of the unused groups do not exist)
         if constexpr (NKCT > 2) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
         else { ct[g].b[0] = ct[g].b[1] = ct[g].b[2] = ct[g].b[3] = 0.f; }
@@ -1095,13 +1103,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // Issue the gathers of a stage into a register set: branch-free, a fixed number of loads, so that the compiler's
         // counted vmcnt waits stay exact (a conditional issue made every wait a near-drain).
-        // Code K-chunk m: this lane's 4 channels as two 8-byte halves (K is even; a pixel is only 8-byte aligned when
-        // K % 4 == 2); halves beyond K re-read channel 0 and are zeroed.
+        // Code K-chunk m: this lane's 4 channels as two 8-byte halves (a pixel is only 8-byte aligned when K % 4 == 2, 4-byte
+        // aligned when K is odd); channels beyond K re-read channel 0 and are zeroed.
         auto issue_code = [&](GSet& g, int m) {
             const int k = m * kper + 4 * g8;
             const bool in = 4 * g8 < kper;
-            const bool v0 = in && k + 1 < prm.K, v1 = in && k + 3 < prm.K;
-            const unsigned k0 = v0 ? 4u * k : 0u, k1 = v1 ? 4u * (k + 2) : 0u;      // byte offsets inside a pixel
+            // element validity; a pair that straddles the end of an odd-K pixel is fetched one channel lower and shifted (see phase 1)
+            const bool e0 = in && k < prm.K, e1 = in && k + 1 < prm.K, e2 = in && k + 2 < prm.K, e3 = in && k + 3 < prm.K;
+            const bool s0 = e0 && !e1, s1 = e2 && !e3;
+            const unsigned k0 = e0 ? 4u * (unsigned)(k - (s0 ? 1 : 0)) : 0u, k1 = e2 ? 4u * (unsigned)(k + 2 - (s1 ? 1 : 0)) : 0u;      // byte offsets inside a pixel
             const char* cb = reinterpret_cast<const char*>(cimgB);                  // wave-uniform base + 32-bit lane offsets
 #pragma unroll
             for (int j = 0; j < GI; ++j) {
@@ -1110,9 +1120,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 const unsigned co[4] = {(y0 + x0) * 4u, (y0 + x1) * 4u, (y1 + x0) * 4u, (y1 + x1) * 4u};
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq) {
-                    const f32x2 lo = *reinterpret_cast<const f32x2*>(cb + (co[tq] + k0));
-                    const f32x2 hi = *reinterpret_cast<const f32x2*>(cb + (co[tq] + k1));
-                    g.tv[j][tq] = f32x4{v0 ? lo[0] : 0.f, v0 ? lo[1] : 0.f, v1 ? hi[0] : 0.f, v1 ? hi[1] : 0.f};
+                    const f32x2 lo = *reinterpret_cast<const f32x2_u*>(cb + (co[tq] + k0));
+                    const f32x2 hi = *reinterpret_cast<const f32x2_u*>(cb + (co[tq] + k1));
+                    g.tv[j][tq] = f32x4{e0 ? (s0 ? lo[1] : lo[0]) : 0.f, e1 ? lo[1] : 0.f, e2 ? (s1 ? hi[1] : hi[0]) : 0.f, e3 ? hi[1] : 0.f};
                 }
             }
         };
@@ -1492,15 +1502,15 @@ bool fused_supported(const FusedParams& prm, int precision)
                (reinterpret_cast<uintptr_t>(m.p) % 16) == 0 &&
                ((long long)(prm.H - 1) * m.sh + (long long)(prm.W - 1) * m.sw + prm.C) * 4 < (1ll << 31);
     };
-    auto cl2 = [&](const MapV& m) {
-        return m.sc == 1 && (m.sn % 2) == 0 && (m.sh % 2) == 0 && (m.sw % 2) == 0 && (reinterpret_cast<uintptr_t>(m.p) % 8) == 0;
+    auto cl2 = [&](const MapV& m) {          // channels-last code map; 4-byte aligned pixels are enough (odd K), K >= 3 then (see code_loads)
+        return m.sc == 1 && (reinterpret_cast<uintptr_t>(m.p) % 4) == 0;
     };
     if (!(prm.C == 384 || prm.C == 768)) return false;                         // NJ instantiations below
     // One workgroup per compute unit at a time (136 KB of LDS): the in-launch hand-offs (anchors, old_mean) are between workgroups
     // that run at the same time.  More tiles than CUs run as rounds of whole pair-sets (see the kernel), so a pair-set must fit:
     if (prm.B > (device_cu_count() & ~7)) return false;                       // (one pair-set = B tiles per round at least)
     if (!cl4(prm.feats) || !cl4(prm.feats_pos) || !cl2(prm.code) || !cl2(prm.code_pos)) return false;
-    if (prm.K % 2 != 0 || prm.K > 128) return false;                            // four code K-chunks of <= 32 channels
+    if (prm.K > 128 || (prm.K % 2 != 0 && prm.K < 3)) return false;             // four code K-chunks of <= 32 channels
     if (prm.H > 256 || prm.W > 256) return false;                             // packed tap coordinates (8 bits each)
     if ((long long)(prm.H - 1) * prm.code.sh + (long long)(prm.W - 1) * prm.code.sw + prm.K >= (1ll << 29)) return false;
     if ((long long)(prm.H - 1) * prm.code_pos.sh + (long long)(prm.W - 1) * prm.code_pos.sw + prm.K >= (1ll << 29)) return false;

@@ -627,12 +627,12 @@ class ContrastiveCorrelationLoss(nn.Module):
     @staticmethod
     def fused_kernels_cover(B, C, K, H, W, S):
         """Does the hand-written loss path (stego_corr_fwd / _bwd, include/stego_corr.h "Limits of this build") take this shape?
-        S * S <= 128 sample points per image; K <= 72 on any layout; 72 < K <= 128 on the single-launch forward (K even, ViT widths,
+        S * S <= 128 sample points per image; K <= 72 on any layout; 72 < K <= 128 on the single-launch forward (any parity, ViT widths,
         B and the map within its bounds).  Everything else - e.g. cfg.feature_samples = 16 - is computed by generic_forward()."""
         if S * S > 128 or K > 128 or H > 32767 or W > 32767:
             return False
         if K > 72:
-            return K % 2 == 0 and C in (384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
+            return C in (384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
         return True
 
     def generic_helper(self, f1, f2, c1, c2, shift):

@@ -51,7 +51,7 @@ def load_config(path=None, overrides=()):
     return types.SimpleNamespace(**d)
 
 
-MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: even, channels-last ViT-width maps)
+MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
 MAX_CODE_DIM_ANY_PATH = 72       # above it: the single-launch forward only (its conditions are checked in __init__)
 
@@ -102,10 +102,11 @@ class LitUnsupervisedSegmenter(nn.Module):
                 # call, from the tensors): the same conditions here, with the cfg keys named, as a warning
                 from .modules import _pair_set_bound
                 why = []
-                if dim % 2:
-                    why.append("cfg.dim is odd")
                 if cfg.arch != "dino":
                     why.append("cfg.arch is not 'dino' (channels-last feature maps of width 384 / 768)")
+                elif getattr(self.net, "n_feats", 384) not in (384, 768):
+                    why.append("cfg.model_type=%s has feature width %d (the single-launch forward takes 384 / 768)"
+                               % (getattr(cfg, "model_type", "?"), self.net.n_feats))
                 if cfg.batch_size > _pair_set_bound():
                     why.append("cfg.batch_size = %d exceeds the %d compute units (the tiles of one pair-set run at the same time)"
                                % (cfg.batch_size, _pair_set_bound()))

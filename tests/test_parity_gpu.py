@@ -640,7 +640,7 @@ def test_backward_wide_map_fallback_is_order_nondeterministic_but_bounded():
         assert float(np.abs(r["d_code_pos"] - runs[0]["d_code_pos"]).max()) <= 1e-6 * scale
 
 
-@pytest.mark.parametrize("K", [96, 100, 128])
+@pytest.mark.parametrize("K", [96, 100, 128, 101, 127])
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_code_dimensions_above_72_forward_and_backward_against_fp64_oracle(K, precision):
     """cfg.dim beyond the 70 the reference ships (train_config.yml:39; its ViT-B models use ~100): the fused forward walks four
@@ -1387,3 +1387,32 @@ def test_event_counters_report_the_give_up_and_repair_paths():
         assert run() == b
     finally:
         capi.debug_set("STEGO_DEBUG", 0)
+
+
+@pytest.mark.parametrize("K", [3, 69, 71])
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_odd_code_dimensions_take_the_single_launch_forward(K, precision):
+    """cfg.dim is free in the reference (train_config.yml:39): odd code dimensions - pixels that are only 4-byte aligned, a last
+    channel pair that straddles the pixel's end - run on the single-launch kernel too (round 4), forward and backward against the
+    fp64 oracle; the last image's last pixel is the case where a careless pair load would leave the tensor."""
+    B, C, H, W, S, n_neg = 3, 384, 9, 10, 7, 2
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=50 + K)
+    d["coords1"][B - 1, 0, 0] = [1.0, 1.0]                   # the last pixel of the last image, by both sides
+    d["coords2"][B - 1, 0, 0] = [1.0, 1.0]
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    t = {k: _dev(v) for k, v in inputs.items()}
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3 if precision == "f16x3" else capi.PREC_F32)
+    cl = [_channels_last(t[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+    assert capi.corr_fwd_launches(desc, *cl) == 1
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    la = 5e-4
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=la, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=la, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=la, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=la, what="neg_cd")
+    g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * B * S ** 4))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")

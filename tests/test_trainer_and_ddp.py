@@ -335,8 +335,9 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
 
 def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():
     """cfg.dim > 128 / cfg.feature_samples > 11 are valid in the reference (train_config.yml:39,51 are free): they run on the generic
-    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 with an odd
-    dim (a shape only the single-launch kernel could take, and cannot): valid in the reference, it runs on the generic path too."""
+    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 on a
+    backbone whose feature width the single-launch kernel does not take (vit_tiny: 192): valid in the reference, it runs on the
+    generic path too.  (Odd code dimensions are served by the single-launch kernel since round 4.)"""
     for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=12"], "cfg.feature_samples=12")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.warns(UserWarning, match=key):
