@@ -258,7 +258,7 @@ __device__ __forceinline__ float half_wave_sum(float v, bool butterfly)
 
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
-template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false>
+template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false, bool ODDK = false>
 __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane,
                                                unsigned char* lds, unsigned long long* tsd)
 {
@@ -293,7 +293,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
     const int c1 = 64 + hl < prm.K ? 64 + hl : 0;
     const int c2 = 96 + hl < prm.K ? 96 + hl : 0;
     const int c0 = 2 * hl < prm.K ? 2 * hl : 0;
-    const int cshift = (2 * hl < prm.K && 2 * hl + 1 >= prm.K) ? 1 : 0;        // my pair straddles the end of an odd-K pixel (K >= 3)
+    const int cshift = (ODDK && 2 * hl < prm.K && 2 * hl + 1 >= prm.K) ? 1 : 0;        // my pair straddles the end of an odd-K pixel (K >= 3)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int4 of = taps_to_offsets(yx[g], mf.sh, mf.sw);
@@ -312,13 +312,20 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         const float* cimg = mc.p + (long long)ba[g] * mc.sn;
         // (odd K: the last pair (K - 1, K) would read one float past the pixel - past the TENSOR for its last pixel: that lane loads
         // (K - 2, K - 1) and keeps the second; pixels of an odd K are only 4-byte aligned)
-        ct[g].a[0] = *reinterpret_cast<const f32x2_u*>(cimg + oc.x + c0 - cshift);
-        ct[g].a[1] = *reinterpret_cast<const f32x2_u*>(cimg + oc.y + c0 - cshift);
-        ct[g].a[2] = *reinterpret_cast<const f32x2_u*>(cimg + oc.z + c0 - cshift);
-        ct[g].a[3] = *reinterpret_cast<const f32x2_u*>(cimg + oc.w + c0 - cshift);
-        if (cshift) {
+        if constexpr (ODDK) {
+            ct[g].a[0] = *reinterpret_cast<const f32x2_u*>(cimg + oc.x + c0 - cshift);
+            ct[g].a[1] = *reinterpret_cast<const f32x2_u*>(cimg + oc.y + c0 - cshift);
+            ct[g].a[2] = *reinterpret_cast<const f32x2_u*>(cimg + oc.z + c0 - cshift);
+            ct[g].a[3] = *reinterpret_cast<const f32x2_u*>(cimg + oc.w + c0 - cshift);
+            if (cshift) {
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) ct[g].a[tq] = f32x2{ct[g].a[tq][1], 0.f};
+                for (int tq = 0; tq < 4; ++tq) ct[g].a[tq] = f32x2{ct[g].a[tq][1], 0.f};
+            }
+        } else {
+            ct[g].a[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c0);
+            ct[g].a[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c0);
+            ct[g].a[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c0);
+            ct[g].a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
         }
         // (K > 64 needs three K-chunks, K > 96 four: the registers of the unused groups do not exist)
         if constexpr (NKCT > 2) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
@@ -732,7 +739,7 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <int PREC, int NJ, int NKCT>
+template <int PREC, int NJ, int NKCT, bool ODDK>
 __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -839,10 +846,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         const int lr0 = mfma_team ? 2 * LYL::G * wave : LYL::MROWS + 2 * LYL::G * (wave8 - 4);
         __builtin_amdgcn_s_setprio(3);
         if (p1beg + lr0 < p1end)
-            p1_sample_rows<NJ, PREC, NKCT, LYL::G, true>(prm, p1x, p1beg, p1end, lr0, lane, ring, (stamp_on && mfma_team) ? ts + 8 : nullptr);
+            p1_sample_rows<NJ, PREC, NKCT, LYL::G, true, ODDK>(prm, p1x, p1beg, p1end, lr0, lane, ring, (stamp_on && mfma_team) ? ts + 8 : nullptr);
         if constexpr (LYL::XB > 0) {
             const int lr1 = LYL::MROWS + 8 * 2 * LYL::G + 2 * (wave8 - 4);
-            if (!mfma_team && p1beg + lr1 < p1end) p1_sample_rows<NJ, PREC, NKCT, 1, true>(prm, p1x, p1beg, p1end, lr1, lane, ring, nullptr);
+            if (!mfma_team && p1beg + lr1 < p1end) p1_sample_rows<NJ, PREC, NKCT, 1, true, ODDK>(prm, p1x, p1beg, p1end, lr1, lane, ring, nullptr);
         }
         const int nrows = p1end - p1beg;
         team_barrier(team_cnt, FUSED_WAVES, lane);
@@ -868,7 +875,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             const int nrows = min(cap, end - blk0);
             const int n_extra = nrows > LY::MROWS ? (nrows - LY::MROWS + 1) >> 1 : 0;          // gather waves arriving at this barrier
             if (2 * LY::G * wave < min(nrows, LY::MROWS))       // (a wave without rows in this pass goes straight to the barrier)
-                p1_sample_rows<NJ, PREC, NKCT, LY::G>(prm, x, blk0, min(end, blk0 + LY::MROWS), 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
+                p1_sample_rows<NJ, PREC, NKCT, LY::G, false, ODDK>(prm, x, blk0, min(end, blk0 + LY::MROWS), 2 * LY::G * wave, lane, ring, stamp_on ? ts + 8 : nullptr);
             if (stamp_on && (prm.debug & 1024)) ts[12] = __builtin_amdgcn_s_memrealtime();
             epoch += 4 + n_extra;
             team_barrier(team_cnt, epoch, lane);
@@ -890,7 +897,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     } else if (p1_here && LY::XW > 0 && wave8 >= 8 && wave8 < 8 + LY::XW) {
         const int lr0 = LY::MROWS + 2 * (wave8 - 8);
         if (p1beg + lr0 < p1end) {
-            p1_sample_rows<NJ, PREC, NKCT, 1>(prm, p1x, p1beg, p1end, lr0, lane, ring, nullptr);
+            p1_sample_rows<NJ, PREC, NKCT, 1, false, ODDK>(prm, p1x, p1beg, p1end, lr0, lane, ring, nullptr);
             team_arrive(team_cnt, lane);
         }
     }
@@ -998,7 +1005,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 // identical inputs give identical bytes, so racing with a late owner is benign; nothing else in the
                 // launch depends on the counter being exact.
                 for (int q0 = 0; q0 < TP; q0 += 2 * LY::G) {
-                    p1_sample_rows<NJ, PREC, NKCT, LY::G>(prm, sA, q0, TP, 0, lane, ring, nullptr);
+                    p1_sample_rows<NJ, PREC, NKCT, LY::G, false, ODDK>(prm, sA, q0, TP, 0, lane, ring, nullptr);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     p1_copy_out<NJ, PREC>(prm, sA, q0, 0, 2 * LY::G, 0, 1, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 }
@@ -1108,11 +1115,28 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         auto issue_code = [&](GSet& g, int m) {
             const int k = m * kper + 4 * g8;
             const bool in = 4 * g8 < kper;
-            // element validity; a pair that straddles the end of an odd-K pixel is fetched one channel lower and shifted (see phase 1)
+            const char* cb = reinterpret_cast<const char*>(cimgB);                  // wave-uniform base + 32-bit lane offsets
+            if constexpr (!ODDK) {
+                const bool v0 = in && k + 1 < prm.K, v1 = in && k + 3 < prm.K;
+                const unsigned k0 = v0 ? 4u * k : 0u, k1 = v1 ? 4u * (k + 2) : 0u;  // byte offsets inside a pixel
+#pragma unroll
+                for (int j = 0; j < GI; ++j) {
+                    const unsigned y0 = (pk[j] & 0xff) * (unsigned)mcB.sh, x0 = ((pk[j] >> 8) & 0xff) * (unsigned)mcB.sw;
+                    const unsigned y1 = ((pk[j] >> 16) & 0xff) * (unsigned)mcB.sh, x1 = (pk[j] >> 24) * (unsigned)mcB.sw;
+                    const unsigned co[4] = {(y0 + x0) * 4u, (y0 + x1) * 4u, (y1 + x0) * 4u, (y1 + x1) * 4u};
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq) {
+                        const f32x2 lo = *reinterpret_cast<const f32x2*>(cb + (co[tq] + k0));
+                        const f32x2 hi = *reinterpret_cast<const f32x2*>(cb + (co[tq] + k1));
+                        g.tv[j][tq] = f32x4{v0 ? lo[0] : 0.f, v0 ? lo[1] : 0.f, v1 ? hi[0] : 0.f, v1 ? hi[1] : 0.f};
+                    }
+                }
+                return;
+            }
+            // odd K (its own instantiations: the masks below cost the even-K kernels registers they do not have): element validity; the pair that straddles the end of a pixel is fetched one channel lower and shifted (see phase 1)
             const bool e0 = in && k < prm.K, e1 = in && k + 1 < prm.K, e2 = in && k + 2 < prm.K, e3 = in && k + 3 < prm.K;
             const bool s0 = e0 && !e1, s1 = e2 && !e3;
-            const unsigned k0 = e0 ? 4u * (unsigned)(k - (s0 ? 1 : 0)) : 0u, k1 = e2 ? 4u * (unsigned)(k + 2 - (s1 ? 1 : 0)) : 0u;      // byte offsets inside a pixel
-            const char* cb = reinterpret_cast<const char*>(cimgB);                  // wave-uniform base + 32-bit lane offsets
+            const unsigned k0 = e0 ? 4u * (unsigned)(k - (s0 ? 1 : 0)) : 0u, k1 = e2 ? 4u * (unsigned)(k + 2 - (s1 ? 1 : 0)) : 0u;
 #pragma unroll
             for (int j = 0; j < GI; ++j) {
                 const unsigned y0 = (pk[j] & 0xff) * (unsigned)mcB.sh, x0 = ((pk[j] >> 8) & 0xff) * (unsigned)mcB.sw;
@@ -1562,9 +1586,15 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     const dim3 grid(n_tiles > prm.n_owner ? n_tiles : prm.n_owner), block(FUSED_THREADS);
 #define STEGO_FUSED_LAUNCH(PR, N, NK)                                                                  \
     do {                                                                                               \
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK>), lds);     \
-        if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK>), grid, block, lds, stream, prm);             \
+        if (prm.K & 1) {                                                                               \
+            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, true>), lds);  \
+            if (e != hipSuccess) return e;                                                             \
+            hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, true>), grid, block, lds, stream, prm);   \
+        } else {                                                                                       \
+            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, false>), lds); \
+            if (e != hipSuccess) return e;                                                             \
+            hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, false>), grid, block, lds, stream, prm);  \
+        }                                                                                              \
     } while (0)
 #define STEGO_FUSED_NK(PR, N)                                                                          \
     do {                                                                                               \

@@ -201,7 +201,9 @@ const float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>(
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-// mode 0: (pos_intra.mean(), pos_intra_cd, pos_inter.mean(), pos_inter_cd, neg_inter_loss, neg_inter_cd, neg_inter_loss.mean())
+// mode 0: (pos_intra.mean(), pos_intra_cd, pos_inter.mean(), pos_inter_cd, neg_inter_loss, neg_inter_cd, neg_inter_loss.mean(),
+//          means [3] = the three scalars as ONE autograd output: a weighted sum of them is differentiated from one root with one
+//          coefficient vector as its upstream, modules.py _LazyLoss.backward)
 // mode 1: (means [3], pos_intra_cd, pos_inter_cd, neg_inter_cd)
 struct CorrLoss : public torch::autograd::Function<CorrLoss> {
     static variable_list forward(AutogradContext* ctx, const at::Tensor& feats, const at::Tensor& feats_pos, const at::Tensor& code,
@@ -249,7 +251,7 @@ struct CorrLoss : public torch::autograd::Function<CorrLoss> {
         if (need_grad)
             ctx->save_for_backward({perms.defined() ? perms : at::Tensor(), intra_cd, inter_cd, neg_cd, saved_w, saved_mean, saved_ctx});
         if (mode == 1) return {means, intra_cd, inter_cd, neg_cd};
-        return {means.select(0, 0), intra_cd, means.select(0, 1), inter_cd, neg_loss, neg_cd, means.select(0, 2)};
+        return {means.select(0, 0), intra_cd, means.select(0, 1), inter_cd, neg_loss, neg_cd, means.select(0, 2), means};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g)
@@ -276,7 +278,14 @@ struct CorrLoss : public torch::autograd::Function<CorrLoss> {
             g_intra_cd = g[1]; g_inter_cd = g[2]; g_neg_cd = g[3];
         } else {
             g_intra = g[0]; g_intra_cd = g[1]; g_inter = g[2]; g_inter_cd = g[3]; g_neg = g[4]; g_neg_cd = g[5];
-            const at::Tensor& g_neg_mean = g[6];
+            at::Tensor g_neg_mean = g[6];
+            if (g.size() > 7 && g[7].defined()) {          // the three scalars differentiated through the vector output (added to the
+                const at::Tensor gm = dense_f32(g[7]);     // scalar outputs' own upstreams, should a caller have used both)
+                const at::Tensor m0 = gm.narrow(0, 0, 1), m1 = gm.narrow(0, 1, 1), m2 = gm.narrow(0, 2, 1);
+                g_intra = g_intra.defined() ? g_intra.reshape({1}) + m0 : m0;
+                g_inter = g_inter.defined() ? g_inter.reshape({1}) + m1 : m1;
+                if (d.n_neg > 0) g_neg_mean = g_neg_mean.defined() ? g_neg_mean.reshape({1}) + m2 : m2;
+            }
             bool neg_is_mean = false;
             if (g_neg_mean.defined() && d.n_neg > 0) {
                 if (!g_neg.defined()) { g_neg = g_neg_mean.reshape({1}); neg_is_mean = true; }       // the training case

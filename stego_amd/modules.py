@@ -221,9 +221,11 @@ class _LossFamily:
     """The three scalar outputs of ONE forward call - pos_intra_loss.mean(), pos_inter_loss.mean(), neg_inter_loss.mean(), as the
     autograd outputs of the loss op - and the device constants a weighted sum of them needs as upstream gradients."""
     _const = {}
+    __slots__ = ("outs", "means")
 
-    def __init__(self, o_intra, o_inter, o_neg):
+    def __init__(self, o_intra, o_inter, o_neg, means=None):
         self.outs = (o_intra, o_inter, o_neg)
+        self.means = means          # the same three scalars as the op's ONE vector output [3] (the C++ autograd function's), or None
 
     @classmethod
     def const(cls, value, like):
@@ -235,6 +237,19 @@ class _LossFamily:
             if len(cls._const) > 256:
                 cls._const.clear()
             t = cls._const[key] = torch.full((), float(value), device=like.device, dtype=like.dtype)
+        return t
+
+    @classmethod
+    def const3(cls, coeffs, like):
+        """The coefficient vector [3] as a device tensor (cached per value triple): the upstream of the vector output."""
+        key = (coeffs, like.device)
+        t = cls._const.get(key)
+        if t is None:
+            if like.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            if len(cls._const) > 256:
+                cls._const.clear()
+            t = cls._const[key] = torch.tensor(coeffs, device=like.device, dtype=like.dtype)
         return t
 
 
@@ -319,15 +334,21 @@ class _LazyLoss:
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         if gradient is None and not create_graph and self._value is None:
+            fam = self._fam
+            m = fam.means
+            if m is not None and m.requires_grad:      # one root, one upstream: the coefficient vector
+                g = _LossFamily.const3(tuple(0.0 if o is None else c for c, o in zip(self._c, fam.outs)), m)
+                if g is not None:
+                    return torch.autograd.backward(m, g, retain_graph=retain_graph, inputs=inputs)
             outs, grads = [], []
-            for c, o in zip(self._c, self._fam.outs):
+            for c, o in zip(self._c, fam.outs):
                 if o is None or c == 0.0 or not o.requires_grad:
                     continue
                 g = _LossFamily.const(c, o)
                 if g is None:
                     outs = None
                     break
-                outs.append(o.as_subclass(torch.Tensor))
+                outs.append(o)
                 grads.append(g)
             if outs:
                 return torch.autograd.backward(outs, grads, retain_graph=retain_graph, inputs=inputs)
@@ -390,6 +411,27 @@ class _LossScalar(torch.Tensor):
     def _lazy(self):
         return _LazyLoss(self._stego_fam, [1.0 if i == self._stego_idx else 0.0 for i in range(3)])
 
+    # The operators of the training step's expression, answered without the __torch_function__ dispatch (a few us each on the host);
+    # every case they do not take goes to the tensor's own operator, i.e. through __torch_function__ below - the same answers.
+    def __mul__(self, k):
+        if _is_number(k) and getattr(self, "_stego_fam", None) is not None:
+            c = [0.0, 0.0, 0.0]
+            c[self._stego_idx] = k
+            return _LazyLoss(self._stego_fam, c)
+        return torch.Tensor.__mul__(self, k)
+
+    def __rmul__(self, k):
+        if _is_number(k) and getattr(self, "_stego_fam", None) is not None:
+            c = [0.0, 0.0, 0.0]
+            c[self._stego_idx] = k
+            return _LazyLoss(self._stego_fam, c)
+        return torch.Tensor.__rmul__(self, k)
+
+    def mean(self, *args, **kwargs):
+        if not args and not kwargs and self.dim() == 0 and getattr(self, "_stego_fam", None) is not None:
+            return self
+        return torch.Tensor.mean(self, *args, **kwargs)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -420,12 +462,12 @@ class _LossScalar(torch.Tensor):
         return out
 
 
-def _lazy_scalars(o_intra, o_inter, o_neg):
+def _lazy_scalars(o_intra, o_inter, o_neg, means=None):
     """Wrap the op's three scalar outputs (any may be None) as _LossScalar siblings of one family.  The family holds the PLAIN outputs
     and the wrappers hold the family - no reference cycle through a tensor's __dict__ (torch.cuda.graph() runs gc.collect() on entry;
     collecting such a cycle crashed the interpreter)."""
-    plain = tuple(None if o is None else o.as_subclass(torch.Tensor) for o in (o_intra, o_inter, o_neg))
-    fam = _LossFamily(*plain)
+    plain = tuple(o if o is None or type(o) is torch.Tensor else o.as_subclass(torch.Tensor) for o in (o_intra, o_inter, o_neg))
+    fam = _LossFamily(*plain, means=means)
     members = []
     for i, o in enumerate(plain):
         if o is None:
@@ -444,6 +486,13 @@ class _NegLossMap(torch.Tensor):
     is answered with the kernel's scalar - no 9 MB reduction pass, and the backward gets one device scalar instead of a dense
     upstream (which would also push it onto the slower dense-upstream kernels).  Every other use behaves like the plain tensor
     (results are plain tensors; gradients flow to the same autograd node)."""
+
+    def mean(self, *args, **kwargs):           # (the training step's call, answered without the __torch_function__ dispatch)
+        if not args and not kwargs:
+            m = getattr(self, "_stego_mean", None)
+            if m is not None:
+                return m
+        return torch.Tensor.mean(self, *args, **kwargs)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -697,7 +746,8 @@ class ContrastiveCorrelationLoss(nn.Module):
             out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
         neg_loss = out[4]
         lazy = getattr(cfg, "lazy_loss_sums", True)               # (off: the three scalars are plain tensors)
-        o_intra, o_inter, o_neg = _lazy_scalars(out[0], out[2], out[6] if n_neg > 0 else None) if lazy else (out[0], out[2], out[6])
+        o_intra, o_inter, o_neg = _lazy_scalars(out[0], out[2], out[6] if n_neg > 0 else None, out[7] if len(out) > 7 else None) \
+            if lazy else (out[0], out[2], out[6])
         if n_neg > 0:
             neg_loss = neg_loss.as_subclass(_NegLossMap)          # (an alias: same storage, same autograd node)
             neg_loss._stego_mean = o_neg
