@@ -1099,6 +1099,23 @@ def test_nccl_world_size_one_dress_rehearsal_of_the_data_parallel_step():
         json.dump(b, f)
 
 
+def test_loss_kernels_beside_an_rccl_kernel_give_the_same_bits():
+    """STEGO_FLAG_SHARED_DEVICE next to a real RCCL device kernel (tests/rccl_beside_worker.py: a one-rank group's ReduceOp.AVG, the
+    collective that launches a kernel at world size 1), eagerly on two streams and as two branches of one captured graph: forward
+    outputs and both gradients bit for bit those of the quiet device."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29563", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_beside_worker.py")], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert rec["eager_equal"] and rec["graph_equal"] and rec["bucket_is_ones"] and rec["eager_rounds"] == 12 and rec["graph_rounds"] == 12, rec
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "rccl_beside.json"), "w") as f:
+        json.dump(rec, f)
+
+
 @pytest.mark.parametrize("B,S,n_neg", [(4, 11, 5), (16, 11, 5), (32, 11, 5), (36, 11, 5), (32, 7, 3), (300, 5, 2)])
 def test_one_launch_draws_are_the_torch_generator_s_rand_and_randperm(B, S, n_neg):
     """stego_ref_draws against the seven torch calls of the reference (modules.py:366-367 torch.rand x 2, :383 super_perm = torch.randperm
