@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define STEGO_ABI_VERSION 5   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
+#define STEGO_ABI_VERSION 6   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
                                 * 3: StegoCorrDesc.flags (STEGO_FLAG_SHARED_DEVICE is per call, no longer a process-wide knob)
                                 * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now
-                                * 5: stego_corr_event_counters */
+                                * 5: stego_corr_event_counters
+                                * 6: StegoVitDesc.precision (STEGO_VIT_F16X3: the backbone in the fp32 class) */
 
 enum {
     STEGO_OK = 0,

@@ -9,8 +9,10 @@
  * as called by DinoFeaturizer.forward (src/modules.py:83-107) and precompute_knns.get_feats (:15-21).
  *
  * Arithmetic: residual stream, LayerNorm statistics, softmax statistics and every accumulation are fp32; GEMM and
- * attention operands are fp16 on the matrix cores (the reference runs fp32 torch; SURVEY 8f asks for a 16-bit
- * matrix-core path).  Measured deviation from the fp32 torch model: see DESIGN.md 4.9 / tests/test_vit_native.py.
+ * attention operands go to the fp16 matrix cores - in precision STEGO_VIT_F16X3 as hi + lo pairs with three MFMAs per product
+ * (x = hi + lo to 2^-22: the fp32 class the reference's fp32 torch model computes in, and what the loss kernels and the
+ * segmentation head of this library use), in STEGO_VIT_F16 as plain fp16 operands (2 - 3 x faster, error at the level of
+ * torch's fp16 autocast).  Measured deviations from the fp32 / fp64 torch model: DESIGN.md 4.9 / tests/test_vit_native.py.
  * The attention maps and the qkv tensor the reference materialises at every block (:232-236) are never built.
  *
  * Conventions as in stego_corr.h: device pointers, nothing allocated / freed / synchronised, work enqueued on
@@ -33,7 +35,11 @@ typedef struct StegoVitDesc {
     int32_t depth;    /* blocks                                                              */
     int32_t heads;    /* D / heads must be 64                                                */
     int32_t hidden;   /* MLP hidden width (4 * D), multiple of 64                            */
+    int32_t precision;/* STEGO_VIT_F16 | STEGO_VIT_F16X3 (ABI 6); weights packed for one precision   */
+                      /* are read by forwards of the same precision only                            */
 } StegoVitDesc;
+
+enum { STEGO_VIT_F16 = 0, STEGO_VIT_F16X3 = 1 };
 
 /* Number of fp32 parameter tensors stego_vit_pack_weights() takes: 4 + 12 * depth + 2, in this order
  *   patch_embed.proj.weight [D, 3*patch*patch]   patch_embed.proj.bias [D]   cls_token [D]

@@ -12,7 +12,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_SHARED_DEVICE = 1          # StegoCorrDesc.flags
 PREC_F32 = 0
 PREC_F16X3 = 1
@@ -35,7 +35,10 @@ class StegoCorrDesc(Structure):
 _P = c_void_p
 class StegoVitDesc(Structure):
     """include/stego_vit.h"""
-    _fields_ = [(n, c_int32) for n in ("B", "H", "W", "patch", "D", "depth", "heads", "hidden")]
+    _fields_ = [(n, c_int32) for n in ("B", "H", "W", "patch", "D", "depth", "heads", "hidden", "precision")]
+
+
+VIT_F16, VIT_F16X3 = 0, 1
 
 
 class StegoHeadDesc(Structure):

@@ -27,6 +27,22 @@ constexpr int VP_KC = 64;
 constexpr int VP_LD = 72;
 constexpr int VP_BYTES = VP_ROWS * VP_LD * 2;        // 18432 = 18 x 1 KiB
 constexpr float LOG2E = 1.4426950408889634f;
+// Precision F16X3 (StegoVitDesc.precision = 1, the default of the Python host): every operand of every matrix product is the pair
+// (hi, lo) of fp16 values with x = hi + lo to 2^-22 (split_f16_pair, corr_common.h) and every product is hi*hi + hi*lo + lo*hi on the
+// fp16 matrix cores, fp32 accumulate: the fp32-class arithmetic of the loss kernels and of the segmentation head, three MFMAs per
+// product and twice the operand bytes.  A panel keeps its geometry and holds 32 k values instead of 64: halves [0, 32) of a row are
+// the hi parts, [32, 64) the lo parts - the copies, the fragment reads and the producers' addressing stay what they are.
+// Ranges: weights are packed times a power of two that puts the tensor's largest magnitude into [1024, 2048) (lo parts stay out of the
+// fp16 subnormals; the power is undone in the GEMM epilogue, exact), activation panels hold 16 x the value (same reason), the softmax
+// probabilities 1024 x.
+constexpr float VIT_ASCALE = 16.f;
+constexpr float VIT_PSCALE = 1024.f;
+
+__device__ __forceinline__ int amax_exp(unsigned bits)       // e with amax = m * 2^e, m in [0.5, 1); 11 for an all-zero tensor (scale 1)
+{
+    const float a = __builtin_bit_cast(float, bits);
+    return a > 0.f ? __builtin_amdgcn_frexp_expf(a) : 11;
+}
 
 enum { EPI_RESID = 0, EPI_EMBED = 1, EPI_GELU = 2, EPI_QKV = 3 };
 
@@ -45,6 +61,8 @@ struct GemmParams {
     int D, heads, ntok, ntok_pad, hw;
     float inv_ntok, inv_hw, qscale;
     const float* pos;            // EMBED: [ntok][D]
+    const unsigned* wamax;       // F16X3: max |w| of this GEMM's weight tensor (float bits) - the power of two it was packed with
+    size_t plane;                // F16X3, QKV: halves from the hi plane of q / k / vt to the lo plane
     int debug;                   // STEGO_DEBUG_VIT ablations: 1 = no MFMAs, 2 = no stage copies after the first, 4 = no epilogue
 };
 
@@ -55,9 +73,10 @@ __device__ __forceinline__ void lds_copy_kib(const unsigned char* __restrict__ g
 }
 
 // ------------------------------------------------------------------------------------------------- packing
-// fp32 [R][K] row-major -> panels [ceil(R/128)][K/64], rows beyond R zero.  One thread per 8 columns.
+// fp32 [R][K] row-major -> panels [ceil(R/128)][K/64] (F16X3: [..][K/32], scaled), rows beyond R zero.  One thread per 8 columns.
+template <bool X3>
 __global__ void __launch_bounds__(256) vit_pack_kernel(const float* __restrict__ src, int R, int K, unsigned char* __restrict__ dst,
-                                                       int nrb, int nkc)
+                                                       int nrb, int nkc, const unsigned* __restrict__ amax)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)nrb * 128 * nkc * 8;
@@ -70,16 +89,36 @@ __global__ void __launch_bounds__(256) vit_pack_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
     if (row < R) {
-        const float* s = src + (size_t)row * K + kc * 64 + g * 8;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+        const int col = X3 ? kc * 32 + (g & 3) * 8 : kc * 64 + g * 8;
+        const float* s = src + (size_t)row * K + col;
+        f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+        if constexpr (X3) {
+            const float sc = __builtin_ldexpf(1.f, 11 - amax_exp(*amax));
+            a = a * sc;
+            b = b * sc;
+        }
         v = f16x8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+        if (X3 && g >= 4)
+            v = f16x8{(half_t)(a[0] - (float)v[0]), (half_t)(a[1] - (float)v[1]), (half_t)(a[2] - (float)v[2]), (half_t)(a[3] - (float)v[3]),
+                      (half_t)(b[0] - (float)v[4]), (half_t)(b[1] - (float)v[5]), (half_t)(b[2] - (float)v[6]), (half_t)(b[3] - (float)v[7])};
     }
     unsigned char* d = dst + ((size_t)(row >> 7) * nkc + kc) * VP_BYTES + (((row & 127) * VP_LD) + g * 8) * 2;
     *reinterpret_cast<f16x8*>(d) = v;
 }
 
+// max |w| of a tensor as float bits (non-negative floats order like unsigned integers); *out zeroed by the caller
+__global__ void __launch_bounds__(256) vit_absmax_kernel(const float* __restrict__ src, long long n, unsigned* __restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
 // Patches as GEMM rows (the conv of PatchEmbed, vision_transformer.py:123-133, is a GEMM over k = (c, iy, ix)):
-// img fp32 [B][3][H][W] -> panels [ceil(B*hw/128)][3*ps*ps/64].  One thread per 8 consecutive ix.
+// img fp32 [B][3][H][W] -> panels [ceil(B*hw/128)][3*ps*ps/64] (F16X3: [..][3*ps*ps/32], 16 x the pixel).  One thread per 8 consecutive ix.
+template <bool X3>
 __global__ void __launch_bounds__(256) vit_im2col_kernel(const float* __restrict__ img, int B, int H, int W, int ps,
                                                          unsigned char* __restrict__ dst, int nrb, int nkc)
 {
@@ -96,11 +135,18 @@ __global__ void __launch_bounds__(256) vit_im2col_kernel(const float* __restrict
     for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
     if (row < B * hw) {
         const int b = row / hw, pi = row - b * hw, py = pi / w, px = pi - py * w;
-        const int k0 = kc * 64 + g * 8, pp = ps * ps;
+        const int k0 = X3 ? kc * 32 + (g & 3) * 8 : kc * 64 + g * 8, pp = ps * ps;
         const int c = k0 / pp, rem = k0 - c * pp, iy = rem / ps, ix = rem - iy * ps;
         const float* s = img + (((size_t)b * 3 + c) * H + (size_t)py * ps + iy) * W + (size_t)px * ps + ix;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(s), bb = *reinterpret_cast<const f32x4*>(s + 4);
+        f32x4 a = *reinterpret_cast<const f32x4*>(s), bb = *reinterpret_cast<const f32x4*>(s + 4);
+        if constexpr (X3) {
+            a = a * VIT_ASCALE;
+            bb = bb * VIT_ASCALE;
+        }
         v = f16x8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)bb[0], (half_t)bb[1], (half_t)bb[2], (half_t)bb[3]};
+        if (X3 && g >= 4)
+            v = f16x8{(half_t)(a[0] - (float)v[0]), (half_t)(a[1] - (float)v[1]), (half_t)(a[2] - (float)v[2]), (half_t)(a[3] - (float)v[3]),
+                      (half_t)(bb[0] - (float)v[4]), (half_t)(bb[1] - (float)v[5]), (half_t)(bb[2] - (float)v[6]), (half_t)(bb[3] - (float)v[7])};
     }
     unsigned char* d = dst + ((size_t)(row >> 7) * nkc + kc) * VP_BYTES + (((row & 127) * VP_LD) + g * 8) * 2;
     *reinterpret_cast<f16x8*>(d) = v;
@@ -118,7 +164,7 @@ __global__ void __launch_bounds__(256) vit_cls_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------- LayerNorm
 // One wave per token row (D <= 768: up to 12 values per lane), fp32 statistics, biased variance (nn.LayerNorm).
-template <bool TO_PANEL>
+template <bool TO_PANEL, bool X3>
 __global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int M, int D, float eps,
                                                             unsigned char* __restrict__ outp, float* __restrict__ outf)
@@ -152,7 +198,13 @@ __global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restr
         if (i < ni) {
             const int n = lane + 64 * i;
             const float y = (v[i] - mean) * rstd * gamma[n] + beta[n];
-            if constexpr (TO_PANEL) {
+            if constexpr (TO_PANEL && X3) {           // column n = 64 i + lane: k chunk 2 i + (lane >> 5), hi at lane & 31, lo 32 further
+                const float ys = y * VIT_ASCALE;
+                const half_t hi = (half_t)ys;
+                unsigned char* d = outp + ((size_t)(m >> 7) * (2 * ni) + 2 * i + (lane >> 5)) * VP_BYTES + (((m & 127) * VP_LD) + (lane & 31)) * 2;
+                *reinterpret_cast<half_t*>(d) = hi;
+                *reinterpret_cast<half_t*>(d + 64) = (half_t)(ys - (float)hi);
+            } else if constexpr (TO_PANEL) {
                 unsigned char* d = outp + ((size_t)(m >> 7) * ni + i) * VP_BYTES + (((m & 127) * VP_LD) + lane) * 2;
                 *reinterpret_cast<half_t*>(d) = (half_t)y;
             } else {
@@ -177,7 +229,7 @@ constexpr int GT_STAGE = (GT_M + GT_N) * VP_LD * 2;       // 64512
 constexpr int GT_LDS = GT_STAGE;                         // ONE stage per workgroup, two workgroups per CU (see below)
 constexpr int GT_THREADS = 512;
 
-template <int EPI>
+template <int EPI, bool X3>
 __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParams p, const int mtiles, const int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -225,31 +277,82 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
         const half_t* Bs = As + GT_M * VP_LD;
         const half_t* ap = As + (64 * wr + r) * VP_LD + 8 * half;
         const half_t* bp = Bs + (96 * wc + r) * VP_LD + 8 * half;
+        if constexpr (X3) {
+            // a chunk holds 32 k values: halves [kk, kk + 16) of a row are hi parts, 32 further their lo parts; lo*hi and hi*lo first,
+            // one term at a time over the six accumulators (no MFMA waits for the one issued before it)
 #pragma unroll
-        for (int kk = 0; kk < VP_KC; kk += 16) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap + kk), a1 = *reinterpret_cast<const f16x8*>(ap + 32 * VP_LD + kk);
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(bp + kk), b1 = *reinterpret_cast<const f16x8*>(bp + 32 * VP_LD + kk);
-            const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + 64 * VP_LD + kk);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b2, acc[0][2], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[1][2], 0, 0, 0);
+            for (int kk = 0; kk < 32; kk += 16) {
+                const f16x8 a0h = *reinterpret_cast<const f16x8*>(ap + kk), a1h = *reinterpret_cast<const f16x8*>(ap + 32 * VP_LD + kk);
+                const f16x8 a0l = *reinterpret_cast<const f16x8*>(ap + 32 + kk), a1l = *reinterpret_cast<const f16x8*>(ap + 32 * VP_LD + 32 + kk);
+                const f16x8 b0h = *reinterpret_cast<const f16x8*>(bp + kk), b1h = *reinterpret_cast<const f16x8*>(bp + 32 * VP_LD + kk);
+                const f16x8 b2h = *reinterpret_cast<const f16x8*>(bp + 64 * VP_LD + kk);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b2h, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b2h, acc[1][2], 0, 0, 0);
+                const f16x8 b0l = *reinterpret_cast<const f16x8*>(bp + 32 + kk), b1l = *reinterpret_cast<const f16x8*>(bp + 32 * VP_LD + 32 + kk);
+                const f16x8 b2l = *reinterpret_cast<const f16x8*>(bp + 64 * VP_LD + 32 + kk);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b2l, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b2l, acc[1][2], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b2h, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b2h, acc[1][2], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < VP_KC; kk += 16) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap + kk), a1 = *reinterpret_cast<const f16x8*>(ap + 32 * VP_LD + kk);
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(bp + kk), b1 = *reinterpret_cast<const f16x8*>(bp + 32 * VP_LD + kk);
+                const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + 64 * VP_LD + kk);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b2, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[1][2], 0, 0, 0);
+            }
         }
     }
     // ---- epilogue.  C/D layout of the accumulators: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     if ((p.debug & 4) && acc[0][0][0] != 12345.678f) return;
+    // F16X3: the accumulators hold (16 x activation) . (2^s x weight): one exact power of two puts them back
+    const float osc = X3 ? __builtin_ldexpf(1.f / VIT_ASCALE, amax_exp(*p.wamax) - 11) : 1.f;
     if constexpr (EPI == EPI_GELU || EPI == EPI_QKV) {
         // fp16 outputs go through LDS (the stage buffer is free now) and leave in the layout of their consumer with
         // wide, coalesced stores, 128 rows per pass.  Storing straight from the accumulators (a lane owns one column:
         // 2-byte stores, 64 B runs, or fully scattered for V^T) cost more than the whole k loop.
+        // F16X3 has twice the bytes to park and the same LDS: four passes - GELU by column half (three 32-column chunk panels, hi |
+        // lo in one row), QKV by plane (the hi values of all three 64-column groups, then the lo values into the lo arrays).
         half_t* T = reinterpret_cast<half_t*>(smem);
         constexpr int GRP = VP_ROWS * VP_LD;            // halves per 64-column group region of one pass (18 KiB)
         constexpr int LDV = VP_ROWS + 8;                // V^T rows: 128 tokens + pad
-        for (int pass = 0; pass < 2; ++pass) {
+        auto gelu = [](float v) {
+            if constexpr (X3) {
+                return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+            } else {
+                // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far
+                // below the fp16 rounding of the result; ocml erff is ~3x the instructions)
+                const float x = fabsf(v) * 0.70710678118654752f;
+                const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
+                const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+                const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
+                return 0.5f * v * (1.f + copysignf(erfa, v));
+            }
+        };
+        for (int pass = 0; pass < (X3 ? 4 : 2); ++pass) {
+            const int rh = X3 ? pass >> 1 : pass;       // row half of the tile
+            const int sub = pass & 1;                   // F16X3: column half (GELU) / plane (QKV)
             __syncthreads();                            // stage buffer / previous pass's park region is free
-            if ((wr >> 1) == pass) {
+            if ((wr >> 1) == rh && !(X3 && EPI == EPI_GELU && wc != sub)) {
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni) {
                     const int col = 96 * wc + 32 * ni + r, cg = col >> 6, cl = col & 63;
@@ -264,20 +367,20 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
                                 const int lrow = 64 * (wr & 1) + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
-                                const float v = acc[mi][ni][e] + bias;
-                                if constexpr (EPI == EPI_GELU) {
-                                    // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far
-                                    // below the fp16 rounding of the result; ocml erff is ~3x the instructions)
-                                    const float x = fabsf(v) * 0.70710678118654752f;
-                                    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
-                                    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-                                    const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
-                                    const float g = 0.5f * v * (1.f + copysignf(erfa, v));
-                                    T[cg * GRP + lrow * VP_LD + cl] = (half_t)g;
-                                } else if constexpr (decltype(transposed)::value) {
-                                    T[cg * GRP + cl * LDV + lrow] = (half_t)v;               // V^T
+                                const float v = acc[mi][ni][e] * osc + bias;
+                                if constexpr (EPI == EPI_GELU && X3) {
+                                    const float g = gelu(v) * VIT_ASCALE;
+                                    const half_t hi = (half_t)g;
+                                    T[ni * GRP + lrow * VP_LD + r] = hi;
+                                    T[ni * GRP + lrow * VP_LD + 32 + r] = (half_t)(g - (float)hi);
+                                } else if constexpr (EPI == EPI_GELU) {
+                                    T[cg * GRP + lrow * VP_LD + cl] = (half_t)gelu(v);
                                 } else {
-                                    T[cg * GRP + lrow * VP_LD + cl] = (half_t)(v * oscale);   // Q (pre-scaled), K
+                                    const float w = v * oscale;
+                                    half_t o = (half_t)w;
+                                    if (X3 && sub) o = (half_t)(w - (float)o);
+                                    if constexpr (decltype(transposed)::value) T[cg * GRP + cl * LDV + lrow] = o;       // V^T
+                                    else T[cg * GRP + lrow * VP_LD + cl] = o;                                       // Q (pre-scaled), K
                                 }
                             }
                     };
@@ -289,23 +392,24 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
             if constexpr (EPI == EPI_GELU) {
                 // the three [128][72] images are panels already: linear 16-byte copies
                 for (int cg = 0; cg < 3; ++cg) {
-                    const int kc = nt * 3 + cg;
+                    const int kc = X3 ? nt * 6 + sub * 3 + cg : nt * 3 + cg;
                     if (kc >= p.out_nkc) continue;
-                    unsigned char* dst = p.outp + ((size_t)(2 * mt + pass) * p.out_nkc + kc) * VP_BYTES;
+                    unsigned char* dst = p.outp + ((size_t)(2 * mt + rh) * p.out_nkc + kc) * VP_BYTES;
                     const unsigned char* src = smem + cg * VP_BYTES;
                     for (int i = tid; i < VP_BYTES / 16; i += GT_THREADS)
                         *reinterpret_cast<f32x4*>(dst + i * 16) = *reinterpret_cast<const f32x4*>(src + i * 16);
                 }
             } else {
+                const size_t po = X3 && sub ? p.plane : 0;
                 for (int cg = 0; cg < 3; ++cg) {
                     const int n0 = nt * GT_N + 64 * cg;
                     if (n0 >= p.N) continue;
                     const int which = n0 / p.D, head = (n0 - which * p.D) >> 6;
                     if (which < 2) {                     // Q / K: [b][head][token][64], one 128-byte row per token
-                        half_t* dstb = which == 0 ? p.q : p.k;
+                        half_t* dstb = (which == 0 ? p.q : p.k) + po;
                         for (int i = tid; i < VP_ROWS * 8; i += GT_THREADS) {
                             const int lrow = i >> 3, ch = i & 7;
-                            const int m = mt * GT_M + 128 * pass + lrow;
+                            const int m = mt * GT_M + 128 * rh + lrow;
                             if (m >= p.M) continue;
                             const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
                             const int t = m - b * p.ntok;
@@ -314,11 +418,11 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
                         }
                     } else {                             // V^T: [b][head][64][token]; lanes run along the tokens
                         const int lrow = tid & (VP_ROWS - 1);
-                        const int m = mt * GT_M + 128 * pass + lrow;
+                        const int m = mt * GT_M + 128 * rh + lrow;
                         if (m < p.M) {
                             const int b = (int)(((float)m + 0.5f) * p.inv_ntok);
                             const int t = m - b * p.ntok;
-                            half_t* dst = p.vt + (((size_t)b * p.heads + head) * 64) * p.ntok_pad + t;
+                            half_t* dst = p.vt + po + (((size_t)b * p.heads + head) * 64) * p.ntok_pad + t;
                             for (int d = tid >> 7; d < 64; d += GT_THREADS / VP_ROWS)
                                 dst[(size_t)d * p.ntok_pad] = T[cg * GRP + d * LDV + lrow];
                         }
@@ -350,7 +454,7 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int m = mbase + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
-                            if (m < p.M) p.resid[(size_t)m * p.ldr + n] = old[e] + acc[mi][ni][e0 + e] + bias;
+                            if (m < p.M) p.resid[(size_t)m * p.ldr + n] = old[e] + (acc[mi][ni][e0 + e] * osc + bias);
                         }
                     }
                 } else {                              // EPI_EMBED: patch rows -> token rows 1.. of their image, + pos_embed
@@ -360,7 +464,7 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
                         if (m >= p.M) continue;
                         const int b = (int)(((float)m + 0.5f) * p.inv_hw);
                         const int pi = m - b * p.hw;
-                        p.resid[((size_t)b * p.ntok + 1 + pi) * p.ldr + n] = acc[mi][ni][e] + bias + p.pos[(size_t)(1 + pi) * p.D + n];
+                        p.resid[((size_t)b * p.ntok + 1 + pi) * p.ldr + n] = acc[mi][ni][e] * osc + bias + p.pos[(size_t)(1 + pi) * p.D + n];
                     }
                 }
             }
@@ -385,6 +489,7 @@ struct AttnParams {
     unsigned char* outp;         // panels [mb][D/64]: row = b*ntok + query, k chunk = head
     int out_nkc, heads, ntok, ntok_pad;
     int nqb, units;              // query blocks per (image, head); number of (image, head) pairs
+    size_t plane;                // F16X3: halves from the hi plane of q / k / vt to the lo plane
 };
 
 __device__ __forceinline__ const unsigned char* swz16(const unsigned char* base, int row, int cb)
@@ -392,9 +497,11 @@ __device__ __forceinline__ const unsigned char* swz16(const unsigned char* base,
     return base + ((row * 8 + (cb ^ ((row >> 1) & 7))) << 4);
 }
 
+template <bool X3>
 __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][8192];       // [stage][K | V^T]
+    constexpr int NPL = X3 ? 2 : 1;                      // operand planes: hi (| lo)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * NPL][8192];       // [stage][K hi | V^T hi (| K lo | V^T lo)]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // The query blocks of one (image, head) run on ONE XCD (blockIdx % 8), next to each other in launch order, so its K / V^T
@@ -415,21 +522,26 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
         for (int pc = wave; pc < 8; pc += 4) {
             const int s = pc * 64 + lane;
             const int row = s >> 3, cb = (s & 7) ^ ((row >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + ((size_t)(kb * 64 + row)) * 64 + cb * 8),
-                                             (__attribute__((address_space(3))) void*)(&smem[kb & 1][0][pc * 1024]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (size_t)row * p.ntok_pad + kb * 64 + cb * 8),
-                                             (__attribute__((address_space(3))) void*)(&smem[kb & 1][1][pc * 1024]), 16, 0, 0);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + pl * p.plane + ((size_t)(kb * 64 + row)) * 64 + cb * 8),
+                                                 (__attribute__((address_space(3))) void*)(&smem[kb & 1][2 * pl][pc * 1024]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + pl * p.plane + (size_t)row * p.ntok_pad + kb * 64 + cb * 8),
+                                                 (__attribute__((address_space(3))) void*)(&smem[kb & 1][2 * pl + 1][pc * 1024]), 16, 0, 0);
+            }
         }
     };
     issue(0);
 
     // Q fragments (B operand of S^T): lane (query li, k half) holds Q[q][8*(2s+half) .. +7]
-    f16x8 qf[4];
+    f16x8 qf[NPL][4];
     {
         const int qrow = min(q0 + li, p.ntok_pad - 1);
         const half_t* qp = p.q + (bh * p.ntok_pad + qrow) * 64 + 8 * half;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qp + 16 * s);
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[pl][s] = *reinterpret_cast<const f16x8*>(qp + pl * p.plane + 16 * s);
     }
     f32x16 o[2];
 #pragma unroll
@@ -447,12 +559,28 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
         f32x16 st[2];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)                        // the two 32-key accumulators alternate: no MFMA waits for the
+        for (int s = 0; s < 4; ++s) {                      // the two 32-key accumulators alternate: no MFMA waits for the
+            if constexpr (X3) {                            // result of the one issued just before it
+                f16x8 ah[2], al[2];
 #pragma unroll
-            for (int kblk = 0; kblk < 2; ++kblk) {         // result of the one issued just before it
-                const f16x8 a = *reinterpret_cast<const f16x8*>(swz16(Ks, 32 * kblk + li, 2 * s + half));
-                st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], s == 0 ? zero16 : st[kblk], 0, 0, 0);
+                for (int kblk = 0; kblk < 2; ++kblk) {
+                    ah[kblk] = *reinterpret_cast<const f16x8*>(swz16(Ks, 32 * kblk + li, 2 * s + half));
+                    al[kblk] = *reinterpret_cast<const f16x8*>(swz16(Ks + 2 * 8192, 32 * kblk + li, 2 * s + half));
+                }
+#pragma unroll
+                for (int kblk = 0; kblk < 2; ++kblk) st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kblk], qf[0][s], s == 0 ? zero16 : st[kblk], 0, 0, 0);
+#pragma unroll
+                for (int kblk = 0; kblk < 2; ++kblk) st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kblk], qf[NPL - 1][s], st[kblk], 0, 0, 0);
+#pragma unroll
+                for (int kblk = 0; kblk < 2; ++kblk) st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kblk], qf[0][s], st[kblk], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kblk = 0; kblk < 2; ++kblk) {
+                    const f16x8 a = *reinterpret_cast<const f16x8*>(swz16(Ks, 32 * kblk + li, 2 * s + half));
+                    st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[0][s], s == 0 ? zero16 : st[kblk], 0, 0, 0);
+                }
             }
+        }
         if constexpr (decltype(last_tile)::value) {       // keys beyond the sequence (the padding of the last tile)
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk)
@@ -487,21 +615,44 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
             for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
         // ---- O^T += V^T P^T, 16 keys per MFMA; registers 8j..8j+7 of a 32-key block hold (per k half)
         //      keys 16j + {0..3} + 4*half and 16j + 8 + {0..3} + 4*half
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        auto vfrag = [&](const unsigned char* base, int drow, int step) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(swz16(base, drow, 2 * step) + 8 * half);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(swz16(base, drow, 2 * step + 1) + 8 * half);
+            const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};
+            return __builtin_bit_cast(f16x8, packed);
+        };
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             const int kblk = step >> 1, j = step & 1;
-            f16x8 pf;
+            f16x8 pf, pl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[kblk][8 * j + e];
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (X3) {
+                    const float ps = st[kblk][8 * j + e] * VIT_PSCALE;
+                    pf[e] = (half_t)ps;
+                    pl[e] = (half_t)(ps - (float)pf[e]);
+                } else {
+                    pf[e] = (half_t)st[kblk][8 * j + e];
+                }
+            }
+            if constexpr (X3) {
+                f16x8 vh[2], vl[2];
 #pragma unroll
-            for (int dblk = 0; dblk < 2; ++dblk) {
-                const int drow = 32 * dblk + li;
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(swz16(Vs, drow, 2 * step) + 8 * half);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(swz16(Vs, drow, 2 * step + 1) + 8 * half);
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};
-                const f16x8 a = __builtin_bit_cast(f16x8, packed);
-                o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dblk], 0, 0, 0);
+                for (int dblk = 0; dblk < 2; ++dblk) {
+                    vh[dblk] = vfrag(Vs, 32 * dblk + li, step);
+                    vl[dblk] = vfrag(Vs + 2 * 8192, 32 * dblk + li, step);
+                }
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[dblk], pf, o[dblk], 0, 0, 0);
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[dblk], pl, o[dblk], 0, 0, 0);
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[dblk], pf, o[dblk], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk)
+                    o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfrag(Vs, 32 * dblk + li, step), pf, o[dblk], 0, 0, 0);
             }
         }
     };
@@ -509,20 +660,36 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const AttnParams p)
     tile(nkb - 1, std::true_type{});
     // ---- normalise and store: O^T[d][q], this lane's query, 4 consecutive d per register group
     lrun += __shfl_xor(lrun, 32, 64);
-    const float inv = 1.f / lrun;
+    const float inv = X3 ? VIT_ASCALE / (lrun * VIT_PSCALE) : 1.f / lrun;
     const int qi = q0 + li;
     if (qi < p.ntok) {
         const int m = b * p.ntok + qi;
-        unsigned char* orow = p.outp + ((size_t)(m >> 7) * p.out_nkc + h) * VP_BYTES + ((m & 127) * VP_LD) * 2;
+        if constexpr (X3) {       // head h = k chunks 2h, 2h + 1 of the proj GEMM's operand: hi at the channel's slot, lo 32 halves further
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+            for (int dblk = 0; dblk < 2; ++dblk) {
+                unsigned char* orow = p.outp + ((size_t)(m >> 7) * p.out_nkc + 2 * h + dblk) * VP_BYTES + ((m & 127) * VP_LD) * 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * dblk + 8 * g + 4 * half;
-                const f16x2 v01 = {(half_t)(o[dblk][4 * g] * inv), (half_t)(o[dblk][4 * g + 1] * inv)};
-                const f16x2 v23 = {(half_t)(o[dblk][4 * g + 2] * inv), (half_t)(o[dblk][4 * g + 3] * inv)};
-                *reinterpret_cast<u32x2*>(orow + d0 * 2) = u32x2{__builtin_bit_cast(unsigned, v01), __builtin_bit_cast(unsigned, v23)};
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 8 * g + 4 * half;
+                    unsigned h01, l01, h23, l23;
+                    split_f16_pair(o[dblk][4 * g] * inv, o[dblk][4 * g + 1] * inv, h01, l01);
+                    split_f16_pair(o[dblk][4 * g + 2] * inv, o[dblk][4 * g + 3] * inv, h23, l23);
+                    *reinterpret_cast<u32x2*>(orow + c0 * 2) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(orow + (32 + c0) * 2) = u32x2{l01, l23};
+                }
             }
+        } else {
+            unsigned char* orow = p.outp + ((size_t)(m >> 7) * p.out_nkc + h) * VP_BYTES + ((m & 127) * VP_LD) * 2;
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dblk + 8 * g + 4 * half;
+                    const f16x2 v01 = {(half_t)(o[dblk][4 * g] * inv), (half_t)(o[dblk][4 * g + 1] * inv)};
+                    const f16x2 v23 = {(half_t)(o[dblk][4 * g + 2] * inv), (half_t)(o[dblk][4 * g + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(orow + d0 * 2) = u32x2{__builtin_bit_cast(unsigned, v01), __builtin_bit_cast(unsigned, v23)};
+                }
+        }
     }
 }
 
@@ -535,7 +702,8 @@ struct Layout {                    // byte offsets inside the packed weight blob
     struct Blk { size_t ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b; };
     size_t blk0, blk_stride;       // blocks are identical in size
     Blk rel;                       // offsets relative to a block's start
-    size_t norm_w, norm_b, total;
+    size_t norm_w, norm_b, amax, total;      // amax: F16X3, 1 + 4 * depth words - max |w| of the patch GEMM, then qkv / proj / fc1 / fc2 per block
+    int kw;                        // k values per panel chunk: 64, F16X3 32
 };
 
 int nblk128(int n) { return (n + 127) / 128; }
@@ -552,7 +720,8 @@ Layout make_layout(const StegoVitDesc& d)
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
     // weight panels cover whole 192-row column tiles of the GEMM (rows beyond the matrix are zero)
-    auto panels = [&](int rows, int K) { return (size_t)wpanels(rows) * (K / 64) * VP_BYTES; };
+    L.kw = d.precision == STEGO_VIT_F16X3 ? 32 : 64;
+    auto panels = [&](int rows, int K) { return (size_t)wpanels(rows) * (K / L.kw) * VP_BYTES; };
     L.patch_w = take(panels(d.D, L.Kp));
     L.patch_b = take((size_t)d.D * 4);
     L.cls = take((size_t)d.D * 4);
@@ -575,13 +744,14 @@ Layout make_layout(const StegoVitDesc& d)
     o = start + L.blk_stride * (size_t)d.depth;
     L.norm_w = take((size_t)d.D * 4);
     L.norm_b = take((size_t)d.D * 4);
+    L.amax = take((size_t)(1 + 4 * d.depth) * 4);
     L.total = o;
     return L;
 }
 
 struct Workspace {
     int M, mb, ntok_pad;
-    size_t resid, xa, ya, ha, q, k, vt, qkv_bytes, total;
+    size_t resid, xa, ya, ha, q, k, vt, qkv_bytes, plane, total;      // plane: halves between the hi and the lo plane of q / k / vt (F16X3)
 };
 
 Workspace make_workspace(const StegoVitDesc& d, const Layout& L)
@@ -593,15 +763,17 @@ Workspace make_workspace(const StegoVitDesc& d, const Layout& L)
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
     w.resid = take((size_t)w.M * d.D * 4);
-    w.xa = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
-    w.ya = take((size_t)w.mb * (d.D / 64) * VP_BYTES);
-    const size_t ha_bytes = (size_t)w.mb * (d.hidden / 64) * VP_BYTES;
-    const size_t im_bytes = (size_t)apanels(d.B * L.hw) * (L.Kp / 64) * VP_BYTES;       // im2col panels alias the MLP buffer
+    w.xa = take((size_t)w.mb * (d.D / L.kw) * VP_BYTES);
+    w.ya = take((size_t)w.mb * (d.D / L.kw) * VP_BYTES);
+    const size_t ha_bytes = (size_t)w.mb * (d.hidden / L.kw) * VP_BYTES;
+    const size_t im_bytes = (size_t)apanels(d.B * L.hw) * (L.Kp / L.kw) * VP_BYTES;     // im2col panels alias the MLP buffer
     w.ha = take(ha_bytes > im_bytes ? ha_bytes : im_bytes);
-    const size_t one = (size_t)d.B * d.heads * w.ntok_pad * 64 * 2;
-    w.q = take(one);
-    w.k = take(one);
-    w.vt = take(one);
+    const size_t one = up256((size_t)d.B * d.heads * w.ntok_pad * 64 * 2);
+    const int npl = d.precision == STEGO_VIT_F16X3 ? 2 : 1;
+    w.plane = one / 2;
+    w.q = take(one * npl);
+    w.k = take(one * npl);
+    w.vt = take(one * npl);
     w.qkv_bytes = o - w.q;
     w.total = o;
     return w;
@@ -612,6 +784,7 @@ int check_desc(const StegoVitDesc* d)
     if (!d) return STEGO_ERR_NULL;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->D <= 0 || d->depth <= 0 || d->heads <= 0 || d->hidden <= 0) return STEGO_ERR_SHAPE;
     if (d->patch != 8 && d->patch != 16) return STEGO_ERR_UNSUPPORTED;
+    if (d->precision != STEGO_VIT_F16 && d->precision != STEGO_VIT_F16X3) return STEGO_ERR_UNSUPPORTED;
     if (d->H % d->patch || d->W % d->patch || d->W % 8) return STEGO_ERR_SHAPE;
     if (d->D % 64 || d->D > 768 || d->hidden % 64 || d->heads * 64 != d->D) return STEGO_ERR_UNSUPPORTED;
     const long long ntok = (long long)(d->H / d->patch) * (d->W / d->patch) + 1;
@@ -619,21 +792,32 @@ int check_desc(const StegoVitDesc* d)
     return STEGO_OK;
 }
 
-template <int EPI> hipError_t launch_gemm(const GemmParams& p, hipStream_t stream)
+template <int EPI, bool X3> hipError_t launch_gemm_p(const GemmParams& p, hipStream_t stream)
 {
-    hipError_t ea = stego::ensure_dynamic_lds(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI>), GT_LDS);
+    hipError_t ea = stego::ensure_dynamic_lds(reinterpret_cast<const void*>(&vit_gemm_kernel<EPI, X3>), GT_LDS);
     if (ea != hipSuccess) return ea;
     const int mtiles = (p.M + GT_M - 1) / GT_M, ntiles = ntiles192(p.N);
     const int grid = 8 * ((mtiles + 7) / 8) * ntiles;
-    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(grid), dim3(GT_THREADS), GT_LDS, stream, p, mtiles, ntiles);
+    hipLaunchKernelGGL((vit_gemm_kernel<EPI, X3>), dim3(grid), dim3(GT_THREADS), GT_LDS, stream, p, mtiles, ntiles);
     return hipGetLastError();
 }
 
-hipError_t pack(const float* src, int R, int K, unsigned char* dst, hipStream_t stream)
+template <int EPI> hipError_t launch_gemm(const GemmParams& p, bool x3, hipStream_t stream)
 {
-    const int nrb = wpanels(R), nkc = K / 64;
+    return x3 ? launch_gemm_p<EPI, true>(p, stream) : launch_gemm_p<EPI, false>(p, stream);
+}
+
+// weight [R][K] -> panels; F16X3: its max |w| to *amax first (zeroed by the caller), the panels scaled by the power of two it implies
+hipError_t pack(const float* src, int R, int K, unsigned char* dst, bool x3, unsigned* amax, hipStream_t stream)
+{
+    const int nrb = wpanels(R), nkc = K / (x3 ? 32 : 64);
     const long long total = (long long)nrb * 128 * nkc * 8;
-    hipLaunchKernelGGL(vit_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, R, K, dst, nrb, nkc);
+    if (x3) {
+        hipLaunchKernelGGL(vit_absmax_kernel, dim3(256), dim3(256), 0, stream, src, (long long)R * K, amax);
+        hipLaunchKernelGGL((vit_pack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, R, K, dst, nrb, nkc, amax);
+    } else {
+        hipLaunchKernelGGL((vit_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, R, K, dst, nrb, nkc, amax);
+    }
     return hipGetLastError();
 }
 
@@ -679,8 +863,11 @@ int stego_vit_pack_weights(const StegoVitDesc* d, const float* const* params, in
         return hipMemcpyAsync(base + off, src, count * 4, hipMemcpyDeviceToDevice, stream);
     };
     const int D = d->D;
+    const bool x3 = d->precision == STEGO_VIT_F16X3;
+    unsigned* amax = reinterpret_cast<unsigned*>(base + L.amax);
+    VIT_TRY(hipMemsetAsync(amax, 0, (size_t)(1 + 4 * d->depth) * 4, stream));
     int i = 0;
-    VIT_TRY(pack(params[i++], D, L.Kp, base + L.patch_w, stream));
+    VIT_TRY(pack(params[i++], D, L.Kp, base + L.patch_w, x3, amax, stream));
     VIT_TRY(vec(params[i++], L.patch_b, D));
     VIT_TRY(vec(params[i++], L.cls, D));
     VIT_TRY(vec(params[i++], L.pos, (size_t)L.ntok * D));
@@ -688,15 +875,15 @@ int stego_vit_pack_weights(const StegoVitDesc* d, const float* const* params, in
         const size_t s = L.blk0 + L.blk_stride * (size_t)l;
         VIT_TRY(vec(params[i++], s + L.rel.ln1_w, D));
         VIT_TRY(vec(params[i++], s + L.rel.ln1_b, D));
-        VIT_TRY(pack(params[i++], 3 * D, D, base + s + L.rel.qkv_w, stream));
+        VIT_TRY(pack(params[i++], 3 * D, D, base + s + L.rel.qkv_w, x3, amax + 1 + 4 * l, stream));
         VIT_TRY(vec(params[i++], s + L.rel.qkv_b, (size_t)3 * D));
-        VIT_TRY(pack(params[i++], D, D, base + s + L.rel.proj_w, stream));
+        VIT_TRY(pack(params[i++], D, D, base + s + L.rel.proj_w, x3, amax + 2 + 4 * l, stream));
         VIT_TRY(vec(params[i++], s + L.rel.proj_b, D));
         VIT_TRY(vec(params[i++], s + L.rel.ln2_w, D));
         VIT_TRY(vec(params[i++], s + L.rel.ln2_b, D));
-        VIT_TRY(pack(params[i++], d->hidden, D, base + s + L.rel.fc1_w, stream));
+        VIT_TRY(pack(params[i++], d->hidden, D, base + s + L.rel.fc1_w, x3, amax + 3 + 4 * l, stream));
         VIT_TRY(vec(params[i++], s + L.rel.fc1_b, d->hidden));
-        VIT_TRY(pack(params[i++], D, d->hidden, base + s + L.rel.fc2_w, stream));
+        VIT_TRY(pack(params[i++], D, d->hidden, base + s + L.rel.fc2_w, x3, amax + 4 + 4 * l, stream));
         VIT_TRY(vec(params[i++], s + L.rel.fc2_b, D));
     }
     VIT_TRY(vec(params[i++], L.norm_w, D));
@@ -720,6 +907,9 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     const unsigned char* wb = static_cast<const unsigned char*>(packed);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     const int D = d->D, M = w.M;
+    const bool x3 = d->precision == STEGO_VIT_F16X3;
+    const int kw = L.kw;
+    const unsigned* amax = reinterpret_cast<const unsigned*>(wb + L.amax);
     const float eps = 1e-6f;                                 // norm_layer = partial(nn.LayerNorm, eps=1e-6) (vision_transformer.py:243)
     auto fvec = [&](size_t off) { return reinterpret_cast<const float*>(wb + off); };
     float* resid = reinterpret_cast<float*>(ws + w.resid);
@@ -742,13 +932,18 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     g.q = reinterpret_cast<half_t*>(ws + w.q);
     g.k = reinterpret_cast<half_t*>(ws + w.k);
     g.vt = reinterpret_cast<half_t*>(ws + w.vt);
+    g.plane = w.plane;
 
     // ---- prepare_tokens
     {
-        const int Mp = d->B * L.hw, nrb = apanels(Mp), nkc = L.Kp / 64;
+        const int Mp = d->B * L.hw, nrb = apanels(Mp), nkc = L.Kp / kw;
         const long long total = (long long)nrb * 128 * nkc * 8;
-        hipLaunchKernelGGL(vit_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, d->B, d->H, d->W,
-                           d->patch, ws + w.ha, nrb, nkc);
+        if (x3)
+            hipLaunchKernelGGL((vit_im2col_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, d->B, d->H, d->W,
+                               d->patch, ws + w.ha, nrb, nkc);
+        else
+            hipLaunchKernelGGL((vit_im2col_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, d->B, d->H, d->W,
+                               d->patch, ws + w.ha, nrb, nkc);
         VIT_TRY(hipGetLastError());
         GemmParams e = g;
         e.A = ws + w.ha;
@@ -758,7 +953,8 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         e.N = D;
         e.nkc = nkc;
         e.pos = fvec(L.pos);
-        VIT_TRY(launch_gemm<EPI_EMBED>(e, stream));
+        e.wamax = amax;
+        VIT_TRY(launch_gemm<EPI_EMBED>(e, x3, stream));
         hipLaunchKernelGGL(vit_cls_kernel, dim3((d->B * D + 255) / 256), dim3(256), 0, stream, fvec(L.cls), fvec(L.pos), resid, d->B,
                            D, L.ntok);
         VIT_TRY(hipGetLastError());
@@ -768,7 +964,8 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     a.k = g.k;
     a.vt = g.vt;
     a.outp = ws + w.ya;
-    a.out_nkc = D / 64;
+    a.out_nkc = D / kw;
+    a.plane = w.plane;
     a.heads = d->heads;
     a.ntok = L.ntok;
     a.ntok_pad = w.ntok_pad;
@@ -777,8 +974,12 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
     const dim3 ln_grid((M + 3) / 4);
     for (int l = 0; l < d->depth; ++l) {
         const size_t s = L.blk0 + L.blk_stride * (size_t)l;
-        hipLaunchKernelGGL(vit_layernorm_kernel<true>, ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln1_w),
-                           fvec(s + L.rel.ln1_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        if (x3)
+            hipLaunchKernelGGL((vit_layernorm_kernel<true, true>), ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln1_w),
+                               fvec(s + L.rel.ln1_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        else
+            hipLaunchKernelGGL((vit_layernorm_kernel<true, false>), ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln1_w),
+                               fvec(s + L.rel.ln1_b), M, D, eps, ws + w.xa, (float*)nullptr);
         VIT_TRY(hipGetLastError());
         GemmParams p1 = g;
         p1.A = ws + w.xa;
@@ -786,9 +987,11 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p1.bias = fvec(s + L.rel.qkv_b);
         p1.M = M;
         p1.N = 3 * D;
-        p1.nkc = D / 64;
-        VIT_TRY(launch_gemm<EPI_QKV>(p1, stream));
-        hipLaunchKernelGGL(vit_attn_kernel, dim3(8 * ((a.units + 7) / 8) * a.nqb), dim3(256), 0, stream, a);
+        p1.nkc = D / kw;
+        p1.wamax = amax + 1 + 4 * l;
+        VIT_TRY(launch_gemm<EPI_QKV>(p1, x3, stream));
+        if (x3) hipLaunchKernelGGL((vit_attn_kernel<true>), dim3(8 * ((a.units + 7) / 8) * a.nqb), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((vit_attn_kernel<false>), dim3(8 * ((a.units + 7) / 8) * a.nqb), dim3(256), 0, stream, a);
         VIT_TRY(hipGetLastError());
         GemmParams p2 = g;
         p2.A = ws + w.ya;
@@ -796,10 +999,15 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p2.bias = fvec(s + L.rel.proj_b);
         p2.M = M;
         p2.N = D;
-        p2.nkc = D / 64;
-        VIT_TRY(launch_gemm<EPI_RESID>(p2, stream));
-        hipLaunchKernelGGL(vit_layernorm_kernel<true>, ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln2_w),
-                           fvec(s + L.rel.ln2_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        p2.nkc = D / kw;
+        p2.wamax = amax + 2 + 4 * l;
+        VIT_TRY(launch_gemm<EPI_RESID>(p2, x3, stream));
+        if (x3)
+            hipLaunchKernelGGL((vit_layernorm_kernel<true, true>), ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln2_w),
+                               fvec(s + L.rel.ln2_b), M, D, eps, ws + w.xa, (float*)nullptr);
+        else
+            hipLaunchKernelGGL((vit_layernorm_kernel<true, false>), ln_grid, dim3(256), 0, stream, resid, fvec(s + L.rel.ln2_w),
+                               fvec(s + L.rel.ln2_b), M, D, eps, ws + w.xa, (float*)nullptr);
         VIT_TRY(hipGetLastError());
         GemmParams p3 = g;
         p3.A = ws + w.xa;
@@ -807,20 +1015,22 @@ int stego_vit_forward(const StegoVitDesc* d, const void* packed, const float* im
         p3.bias = fvec(s + L.rel.fc1_b);
         p3.M = M;
         p3.N = d->hidden;
-        p3.nkc = D / 64;
+        p3.nkc = D / kw;
         p3.outp = ws + w.ha;
-        p3.out_nkc = d->hidden / 64;
-        VIT_TRY(launch_gemm<EPI_GELU>(p3, stream));
+        p3.out_nkc = d->hidden / kw;
+        p3.wamax = amax + 3 + 4 * l;
+        VIT_TRY(launch_gemm<EPI_GELU>(p3, x3, stream));
         GemmParams p4 = g;
         p4.A = ws + w.ha;
         p4.W = wb + s + L.rel.fc2_w;
         p4.bias = fvec(s + L.rel.fc2_b);
         p4.M = M;
         p4.N = D;
-        p4.nkc = d->hidden / 64;
-        VIT_TRY(launch_gemm<EPI_RESID>(p4, stream));
+        p4.nkc = d->hidden / kw;
+        p4.wamax = amax + 4 + 4 * l;
+        VIT_TRY(launch_gemm<EPI_RESID>(p4, x3, stream));
     }
-    hipLaunchKernelGGL(vit_layernorm_kernel<false>, ln_grid, dim3(256), 0, stream, resid, fvec(L.norm_w), fvec(L.norm_b), M, D, eps,
+    hipLaunchKernelGGL((vit_layernorm_kernel<false, false>), ln_grid, dim3(256), 0, stream, resid, fvec(L.norm_w), fvec(L.norm_b), M, D, eps,
                        (unsigned char*)nullptr, tokens_out);
     VIT_TRY(hipGetLastError());
     return STEGO_OK;

@@ -224,19 +224,19 @@ class DinoFeaturizer(nn.Module):
                              nn.Conv2d(in_channels, self.dim, (1, 1)))
 
     def _tokens(self, img, n):
-        """feat[0] (and qkv[0]) of get_intermediate_feat (modules.py:88-89).  On a HIP device the frozen backbone runs
-        on the hand-written kernels of include/stego_vit.h (fp16 matrix-core operands, fp32 accumulate); the torch
-        module is kept for the variants that path does not build: n > 1, feat_type 'KK' (needs the block's qkv), or CPU
-        tensors.  OPT-IN (cfg.native_backbone = True; default False): the north_star tolerance is 1e-3 in fp32, and the
-        native backbone computes its GEMMs with fp16 operands - 7.5e-4 relative L2 on the reference golden, i.e. inside
-        the bar as a whole but with single elements off by up to 4e-2 absolute (tests/test_vit_native.py), and training
-        steps 5e-3 away from the fp32 reference step.  The fp32 torch backbone is therefore what runs unless the user
-        trades that accuracy for 3.4x backbone throughput (tools/bench_vit.py)."""
+        """feat[0] (and qkv[0]) of get_intermediate_feat (modules.py:88-89).  On a HIP device the frozen backbone runs on the
+        hand-written kernels of include/stego_vit.h - DEFAULT (cfg.native_backbone, True unless set False) in precision
+        cfg.backbone_precision = "f16x3": split-fp16 operands with three MFMAs per product, fp32 accumulation, statistics and
+        residual stream; its error against the fp64 model is at or below the fp32 torch model's own (tests/test_vit_native.py:
+        4e-7 .. 4e-5 depending on the network), at half the fp32 torch module's time.  "f16" (opt-in) is the plain fp16-operand
+        path: another 2x faster, 5e-4 .. 1e-3 relative L2 with single elements up to 4e-2 off - outside the fp32 class.  The torch
+        module is kept for the variants the kernels do not build: n > 1, feat_type 'KK' (needs the block's qkv), CPU tensors,
+        geometries outside include/stego_vit.h."""
         native_ok = (img.is_cuda and n == 1 and self.feat_type == "feat" and img.dtype == torch.float32
-                     and getattr(self.cfg, "native_backbone", False) and vit_native.supported(self.model))
+                     and getattr(self.cfg, "native_backbone", True) and vit_native.supported(self.model))
         if native_ok:
             if self._native is None:
-                self._native = vit_native.NativeViT(self.model)
+                self._native = vit_native.NativeViT(self.model, precision=getattr(self.cfg, "backbone_precision", "f16x3"))
             if self._native.shape_supported(*[int(img.shape[i]) for i in (0, 2, 3)]):      # (else: the torch module below)
                 self.backbone_path = "native"
                 return self._native.forward_tokens(img), None

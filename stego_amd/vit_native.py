@@ -39,12 +39,21 @@ def supported(model):
             model.patch_embed.patch_size in (8, 16) and blk.mlp.fc1.out_features % 64 == 0)
 
 
-class NativeViT:
-    """Packed weights + workspace cache around stego_vit_forward for one frozen ``dino_vit.VisionTransformer``."""
+PRECISIONS = {"f16x3": capi.VIT_F16X3, "f16": capi.VIT_F16}
 
-    def __init__(self, model):
+
+class NativeViT:
+    """Packed weights + workspace cache around stego_vit_forward for one frozen ``dino_vit.VisionTransformer``.
+
+    precision "f16x3" (default): split-fp16 operands, three MFMAs per product - the fp32 class of the reference's torch model;
+    "f16": plain fp16 operands, 2 - 3 x faster, error at the level of torch's fp16 autocast (include/stego_vit.h)."""
+
+    def __init__(self, model, precision="f16x3"):
         if not supported(model):
             raise RuntimeError("stego_vit: unsupported ViT geometry (need head_dim 64, qkv bias, patch 8/16, D <= 768)")
+        if precision not in PRECISIONS:
+            raise ValueError("stego_vit: unknown precision %r (f16x3 | f16)" % (precision,))
+        self.precision = precision
         self.model = model
         self._packed = {}         # (H, W, device) -> uint8 blob
         self._ws = {}             # (B, H, W, device) -> uint8 workspace
@@ -52,7 +61,7 @@ class NativeViT:
     def _desc(self, B, H, W):
         m = self.model
         return capi.StegoVitDesc(B, H, W, m.patch_embed.patch_size, m.embed_dim, len(m.blocks), m.blocks[0].attn.num_heads,
-                                 m.blocks[0].mlp.fc1.out_features)
+                                 m.blocks[0].mlp.fc1.out_features, PRECISIONS[self.precision])
 
     def shape_supported(self, B, H, W):
         """Does this build have kernels for a [B,3,H,W] batch through this backbone?  (include/stego_vit.h: H, W multiples of the patch

@@ -56,7 +56,7 @@ def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None, preci
 def test_library_loaded_is_the_in_tree_hip_extension():
     lib = capi.load()
     assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
-    assert lib.stego_abi_version() == 5
+    assert lib.stego_abi_version() == 6
     assert torch.cuda.is_available()
 
 
@@ -500,9 +500,9 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
     ov = ["model_type=vit_tiny", "dino_patch_size=16", "res=64", "batch_size=4", "feature_samples=5", "neg_samples=2",
           "dim=10", "dropout=False", "native_backbone=%s" % native_backbone]
     cfg = load_config(overrides=ov)
-    # native_backbone=False isolates the loss path (fp32 torch backbone on both sides: 1e-3 bars); True runs the whole
-    # device step on the native kernels, whose fp16-operand backbone moves the features by ~5e-4 (tests/test_vit_native.py)
-    tol = 5.0 if native_backbone else 1.0
+    # native_backbone=False isolates the loss path (fp32 torch backbone on both sides); True (the default) runs the whole device step
+    # on the native kernels, backbone included (precision f16x3: the fp32 class, tests/test_vit_native.py) - the same 1e-3 bars
+    tol = 1.0
     torch.manual_seed(0)
     ref = LitUnsupervisedSegmenter(27, cfg).cpu()            # DinoFeaturizer puts its backbone on the GPU when one exists (modules.py:32)
     ref.net.dropout.p = 0.0                                   # no dropout noise: CPU and GPU RNG streams differ
@@ -536,12 +536,9 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
         assert abs(float(dev_model.logged[k]) - float(ref.logged[k])) < tol * 1e-3 * max(0.05, abs(float(ref.logged[k]))), k
     w_ref = ref.net.cluster1[0].weight.detach()
     w_dev = dev_model.net.cluster1[0].weight.detach().cpu()
-    if not native_backbone:
-        assert torch.allclose(w_dev, w_ref, rtol=1e-3, atol=2e-4)      # one Adam step on the head, same direction
-    else:                                                              # Adam normalises the step: compare directions
-        d_ref = w_ref - ref_w0
-        d_dev = w_dev - ref_w0
-        assert float(torch.nn.functional.cosine_similarity(d_dev.flatten(), d_ref.flatten(), dim=0)) > 0.98
+    assert torch.allclose(w_dev, w_ref, rtol=1e-3, atol=2e-4)          # one Adam step on the head, same direction
+    d_ref, d_dev = w_ref - ref_w0, w_dev - ref_w0
+    assert float(torch.nn.functional.cosine_similarity(d_dev.flatten(), d_ref.flatten(), dim=0)) > 0.999
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])

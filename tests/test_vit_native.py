@@ -1,7 +1,8 @@
 """Native DINO ViT forward (include/stego_vit.h) against (i) the golden vector produced by the
 UNMODIFIED reference src/dino/vision_transformer.py (oracle/make_golden.py: vit_case) and (ii) the fp32 torch mirror
-stego_amd/dino_vit.py at the BASELINE backbone shapes.  GEMM / attention operands are fp16 on the matrix cores with
-fp32 accumulation, statistics and residual stream, so the bar is a relative L2 error, stated per test."""
+stego_amd/dino_vit.py - and its fp64 twin - at the BASELINE backbone shapes.  Precision "f16x3" (the default: split-fp16 operands,
+three MFMAs per product) is held to the fp32 class: its error against the fp64 model may not exceed twice the fp32 torch model's own.
+Precision "f16" (plain fp16 operands) is held to a relative L2 error, stated per test."""
 import ctypes
 import os
 
@@ -49,19 +50,21 @@ def test_torch_mirror_reproduces_reference_golden_cpu():
 
 def test_vit_abi_validates_on_host():
     lib = capi.load()
-    d = capi.StegoVitDesc(4, 224, 224, 8, 384, 12, 6, 1536)
-    assert lib.stego_vit_param_count(ctypes.byref(d)) == 4 + 12 * 12 + 2
-    wb, ws = lib.stego_vit_weights_bytes(ctypes.byref(d)), lib.stego_vit_workspace_bytes(ctypes.byref(d))
-    # fp16 panels: every weight matrix once (+ padding), fp32 vectors; workspace: residual + panels + q/k/v
     n_w = 384 * 192 + 12 * (3 * 384 * 384 + 384 * 384 + 2 * 384 * 1536)
-    assert 2 * n_w <= wb <= 2 * n_w * 1.2 + 785 * 384 * 4 + (1 << 16)
-    assert ws >= 4 * 785 * 384 * 4
+    for prec, planes in ((capi.VIT_F16, 1), (capi.VIT_F16X3, 2)):
+        d = capi.StegoVitDesc(4, 224, 224, 8, 384, 12, 6, 1536, prec)
+        assert lib.stego_vit_param_count(ctypes.byref(d)) == 4 + 12 * 12 + 2
+        wb, ws = lib.stego_vit_weights_bytes(ctypes.byref(d)), lib.stego_vit_workspace_bytes(ctypes.byref(d))
+        # fp16 panels: every weight matrix once per plane (+ padding), fp32 vectors; workspace: residual + panels + q/k/v
+        assert 2 * planes * n_w <= wb <= 2 * planes * n_w * 1.2 + 785 * 384 * 4 + (1 << 16)
+        assert ws >= 4 * 785 * 384 * 4
+    assert lib.stego_vit_weights_bytes(ctypes.byref(capi.StegoVitDesc(4, 224, 224, 8, 384, 12, 6, 1536, 7))) == 0     # unknown precision
     assert lib.stego_vit_forward(None, None, None, None, None, 0, None) == 1               # STEGO_ERR_NULL
     assert lib.stego_vit_forward(ctypes.byref(d), None, None, None, None, 0, None) == 1
-    bad = capi.StegoVitDesc(4, 224, 224, 8, 384, 12, 12, 1536)                             # head_dim 32
+    bad = capi.StegoVitDesc(4, 224, 224, 8, 384, 12, 12, 1536, 0)                             # head_dim 32
     assert lib.stego_vit_weights_bytes(ctypes.byref(bad)) == 0
     assert lib.stego_vit_forward(ctypes.byref(bad), None, None, None, None, 0, None) == 3   # STEGO_ERR_UNSUPPORTED
-    odd = capi.StegoVitDesc(4, 220, 224, 8, 384, 12, 6, 1536)
+    odd = capi.StegoVitDesc(4, 220, 224, 8, 384, 12, 6, 1536, 0)
     assert lib.stego_vit_forward(ctypes.byref(odd), None, None, None, None, 0, None) == 2   # STEGO_ERR_SHAPE
     # argument checks come before any enqueue: (host) dummy pointers are never dereferenced
     raw = ctypes.create_string_buffer(4096)
@@ -82,24 +85,23 @@ def test_native_vit_refuses_cpu_tensors():
 
 # ------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-def test_native_matches_reference_golden():
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_native_matches_reference_golden(precision):
     """Reference-generated vector: non-square input (bicubic pos-embed resize), peaked softmax, biases everywhere."""
     model, img, feat = _golden_model()
     model = model.cuda()
-    got = vit_native.NativeViT(model).forward_tokens(img.cuda()).cpu()
+    got = vit_native.NativeViT(model, precision=precision).forward_tokens(img.cuda()).cpu()
     assert got.shape == feat.shape
     err = _rel(got, feat)
-    assert err < 1e-3, err                                # the north_star bar (measured 7.5e-4): fp16 operands, fp32 everything else
-    assert float((got - feat).abs().max()) < 4e-2        # elementwise bound (absolute; |feat| is O(1..10)): why the path is opt-in
+    if precision == "f16x3":                              # the fp32 class: the golden itself is an fp32 evaluation
+        assert err < 5e-6, err
+        assert float((got - feat).abs().max()) < 1e-4
+    else:
+        assert err < 1e-3, err                            # the north_star bar (measured 7.5e-4): fp16 operands, fp32 everything else
+        assert float((got - feat).abs().max()) < 4e-2    # elementwise bound (absolute; |feat| is O(1..10)): why this mode is opt-in
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("arch,patch,size,B", [("vit_small", 8, 224, 3), ("vit_base", 8, 320, 1), ("vit_small", 16, 224, 2),
-                                                 ("vit_tiny", 16, 96, 5), ("vit_base", 16, 224, 2)])
-def test_native_matches_fp32_torch_at_baseline_shapes(arch, patch, size, B):
-    """Bar: relative L2 error vs the fp32 torch model below 2e-3, or - for networks that amplify rounding (a random
-    ViT-B with sharpened attention doubles any perturbation per block: torch fp32 itself is 7e-5 away from fp64) -
-    no worse than torch's own fp16 autocast of the same model, which is what 16-bit operands can deliver."""
+def _dino_like(arch, patch):
     torch.manual_seed(5)
     model = dino_vit.ARCHS[arch](patch_size=patch).cuda().eval()
     with torch.no_grad():
@@ -108,12 +110,47 @@ def test_native_matches_fp32_torch_at_baseline_shapes(arch, patch, size, B):
                 prm.add_(0.05 * torch.randn_like(prm))
             if "qkv.weight" in name:
                 prm.mul_(4.0)
+    return model
+
+
+SHAPES = [("vit_small", 8, 224, 3), ("vit_base", 8, 320, 1), ("vit_small", 16, 224, 2), ("vit_tiny", 16, 96, 5), ("vit_base", 16, 224, 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,patch,size,B", SHAPES)
+def test_native_f16x3_is_in_the_fp32_class_at_baseline_shapes(arch, patch, size, B):
+    """The default precision against the fp64 evaluation of the same network (torch, double): the native backbone's relative L2 error
+    may be at most TWICE that of the fp32 torch model the reference runs (measured: 0.65 - 1.04 x; a random ViT-B with sharpened
+    attention amplifies any rounding to 4e-5 .. 6e-5 for both), elementwise within three times its worst element."""
+    model = _dino_like(arch, patch)
+    img = torch.randn(B, 3, size, size, device="cuda")
+    with torch.no_grad():
+        ref32 = model.get_intermediate_feat(img, n=1)[0][0]
+        m64 = dino_vit.ARCHS[arch](patch_size=patch).cuda().double().eval()
+        m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+        ref64 = m64.get_intermediate_feat(img.double(), n=1)[0][0]
+        del m64
+    got = vit_native.NativeViT(model).forward_tokens(img)
+    assert got.shape == ref64.shape and torch.isfinite(got).all()
+    err, err32 = _rel(got.cpu(), ref64.cpu()), _rel(ref32.cpu(), ref64.cpu())
+    assert err <= 2.0 * err32 + 1e-7, (err, err32)
+    worst, worst32 = float((got.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
+    assert worst <= 3.0 * worst32 + 1e-6, (worst, worst32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,patch,size,B", SHAPES)
+def test_native_f16_matches_fp32_torch_at_baseline_shapes(arch, patch, size, B):
+    """Precision "f16".  Bar: relative L2 error vs the fp32 torch model below 2e-3, or - for networks that amplify rounding (a random
+    ViT-B with sharpened attention doubles any perturbation per block: torch fp32 itself is 7e-5 away from fp64) -
+    no worse than torch's own fp16 autocast of the same model, which is what 16-bit operands can deliver."""
+    model = _dino_like(arch, patch)
     img = torch.randn(B, 3, size, size, device="cuda")
     with torch.no_grad():
         ref = model.get_intermediate_feat(img, n=1)[0][0]
         with torch.autocast("cuda", dtype=torch.float16):
             half = model.get_intermediate_feat(img, n=1)[0][0].float()
-    got = vit_native.NativeViT(model).forward_tokens(img)
+    got = vit_native.NativeViT(model, precision="f16").forward_tokens(img)
     assert got.shape == ref.shape and torch.isfinite(got).all()
     err, err_half = _rel(got.cpu(), ref.cpu()), _rel(half.cpu(), ref.cpu())
     assert err < max(2e-3, 1.05 * err_half), (err, err_half)
@@ -123,10 +160,11 @@ def test_native_matches_fp32_torch_at_baseline_shapes(arch, patch, size, B):
 
 
 @pytest.mark.gpu
-def test_native_is_deterministic_and_batch_independent():
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_native_is_deterministic_and_batch_independent(precision):
     torch.manual_seed(6)
     model = dino_vit.vit_small(patch_size=8).cuda().eval()
-    nat = vit_native.NativeViT(model)
+    nat = vit_native.NativeViT(model, precision=precision)
     img = torch.randn(3, 3, 64, 96, device="cuda")
     a = nat.forward_tokens(img)
     b = nat.forward_tokens(img)
@@ -141,7 +179,7 @@ def test_featurizer_uses_native_backbone_and_feeds_the_loss_layout():
 
     class C:
         dino_patch_size = 8; dino_feat_type = "feat"; model_type = "vit_small"; projection_type = "nonlinear"
-        dropout = False; pretrained_weights = None; native_backbone = True        # opt-in (default: the fp32 torch backbone)
+        dropout = False; pretrained_weights = None                                 # (cfg.native_backbone defaults to True, f16x3)
     torch.manual_seed(7)
     fz = featurizers.DinoFeaturizer(70, C()).cuda().eval()
     img = torch.randn(2, 3, 224, 224, device="cuda")
@@ -150,7 +188,7 @@ def test_featurizer_uses_native_backbone_and_feeds_the_loss_layout():
     assert feats.shape == (2, 384, 28, 28) and feats.stride(1) == 1          # channels-last view: what the loss kernels read
     with torch.no_grad():
         ref = fz.model.get_intermediate_feat(img, n=1)[0][0][:, 1:, :].reshape(2, 28, 28, 384).permute(0, 3, 1, 2)
-    assert _rel(feats.cpu(), ref.cpu()) < 5e-3
+    assert _rel(feats.cpu(), ref.cpu()) < 1e-5
     cls = fz(img, return_class_feat=True)
     assert cls.shape == (2, 384, 1, 1)
     assert code.shape == (2, 70, 28, 28)
@@ -206,13 +244,18 @@ def test_featurizer_variants_the_native_path_does_not_build_use_the_torch_module
     a, _ = fz3(img)
     b, _ = fz2(img)
     assert fz3.backbone_path == "native"
-    assert _rel(a.cpu(), b.cpu()) < 5e-3
+    assert _rel(a.cpu(), b.cpu()) < 1e-5
+    C.backbone_precision = "f16"
+    fz4 = featurizers.DinoFeaturizer(70, C()).cuda().eval()
+    fz4.load_state_dict(fz2.state_dict())
+    assert 1e-5 < _rel(fz4(img)[0].cpu(), b.cpu()) < 5e-3 and fz4.backbone_path == "native"
+    del C.backbone_precision
     # new weights invalidate the packed copy
     with torch.no_grad():
         sd = {k: v * 1.5 if "blocks.0.attn.qkv.weight" in k else v for k, v in fz3.state_dict().items()}
     fz3.load_state_dict(sd)
     fz2.load_state_dict(sd)
-    assert _rel(fz3(img)[0].cpu(), fz2(img)[0].cpu()) < 5e-3
+    assert _rel(fz3(img)[0].cpu(), fz2(img)[0].cpu()) < 1e-5
 
 
 def test_parameter_order_and_shapes_match_the_header_contract():
@@ -222,7 +265,7 @@ def test_parameter_order_and_shapes_match_the_header_contract():
     model = dino_vit.vit_small(patch_size=8).eval()
     H, W = 224, 256                                               # not the training size: pos-embed gets interpolated
     ps = vit_native._params_of(model, H, W)
-    d = capi.StegoVitDesc(2, H, W, 8, 384, 12, 6, 1536)
+    d = capi.StegoVitDesc(2, H, W, 8, 384, 12, 6, 1536, capi.VIT_F16X3)
     assert len(ps) == lib.stego_vit_param_count(ctypes.byref(d)) == 150
     ntok = 1 + (H // 8) * (W // 8)
     assert [tuple(p.shape) for p in ps[:4]] == [(384, 192), (384,), (384,), (ntok, 384)]
