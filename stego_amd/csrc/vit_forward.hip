@@ -335,18 +335,16 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
         half_t* T = reinterpret_cast<half_t*>(smem);
         constexpr int GRP = VP_ROWS * VP_LD;            // halves per 64-column group region of one pass (18 KiB)
         constexpr int LDV = VP_ROWS + 8;                // V^T rows: 128 tokens + pad
+        // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7: below the fp16 rounding of the F16 result
+        // and - as an ABSOLUTE error of 0.75e-7 |v| on the product - inside the fp32 class of F16X3, tests/test_vit_native.py;
+        // ocml erff is ~3x the instructions and was a third of this kernel's time).  (Finishing all 96 values of a wave before the
+        // passes - so that no wave waits at a barrier while two compute - made the compiler spill 400 registers inside the k loop.)
         auto gelu = [](float v) {
-            if constexpr (X3) {
-                return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-            } else {
-                // nn.GELU (exact form) with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far
-                // below the fp16 rounding of the result; ocml erff is ~3x the instructions)
-                const float x = fabsf(v) * 0.70710678118654752f;
-                const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
-                const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-                const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
-                return 0.5f * v * (1.f + copysignf(erfa, v));
-            }
+            const float x = fabsf(v) * 0.70710678118654752f;
+            const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
+            const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+            const float erfa = 1.f - poly * __builtin_amdgcn_exp2f(-x * x * LOG2E);
+            return 0.5f * v * (1.f + copysignf(erfa, v));
         };
         for (int pass = 0; pass < (X3 ? 4 : 2); ++pass) {
             const int rh = X3 ? pass >> 1 : pass;       // row half of the tile
