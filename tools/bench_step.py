@@ -48,13 +48,17 @@ def step():
 
 
 res = {}
-for native in (True, False):
+for native, prec in ((True, "f16x3"), (True, "f16"), (False, None)):
     cfg.native_backbone = native
-    key = "native_backbone" if native else "torch_fp32_backbone"
+    cfg.backbone_precision = prec or "f16x3"
+    net._native = None                                    # (packed for one precision)
+    key = ("native_backbone" if prec == "f16x3" else "native_backbone_f16") if native else "torch_fp32_backbone"
     with torch.no_grad():
         bb = timed(lambda: net._tokens(both, 1))
-    res[key] = {"step_ms": timed(step), "backbone_ms": bb, "path": net.backbone_path}
+    res[key] = {"step_ms": timed(step), "backbone_ms": bb, "path": net.backbone_path, "precision": prec or "torch fp32"}
 cfg.native_backbone = True
+cfg.backbone_precision = "f16x3"
+net._native = None
 feats_all, code_all = net(both)
 code = code_all[:B].detach().requires_grad_(True); code_pos = code_all[B:].detach().requires_grad_(True)
 
