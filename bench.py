@@ -51,6 +51,7 @@ WORKLOADS = {
     # name: (C, H, W, K)   (BASELINE.json configs[1] and configs[3])
     "vits8_224": (384, 28, 28, 70),
     "vitb8_320": (768, 40, 40, 70),
+    "vitt16_224": (192, 14, 14, 70),       # vit_tiny/16 (src/dino/vision_transformer.py:259-263): not a BASELINE config, the third backbone width
 }
 
 

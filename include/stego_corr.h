@@ -93,7 +93,7 @@ enum {
 };
 
 /* Limits of this build: S*S <= 128 (S <= 11); K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
- * channels-last maps with C = 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
+ * channels-last maps with C = 192 / 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
  * helper()); every per-image element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
  * GEMMs are split-fp16 products in both precision modes (their fp32 operand images no longer fit LDS).
  * Determinism: every kernel sums in a fixed order (bitwise repeatable results), with ONE exception: the backward of maps
@@ -130,7 +130,7 @@ size_t stego_corr_helper_bwd_workspace_bytes(const StegoCorrDesc* desc);
  * Forward of ContrastiveCorrelationLoss.forward  (modules.py:349-398) with the RNG draws made by the
  * caller in the reference's order (coords1 :366, coords2 :367, super_perm x n_neg :383).
  *
- * Channels-last maps of the ViT widths (C = 384 / 768) with B <= the device's compute units (256) take the FUSED path:
+ * Channels-last maps of the ViT widths (C = 192 / 384 / 768) with B <= the device's compute units (256) take the FUSED path:
  * ONE kernel launch (corr_fused_kernel) in which every workgroup owns one (pair-set, image) tile; when there are more tiles
  * ((2 + n_neg) * B) than compute units, the grid is a sequence of windows of whole pair-sets (floor(CUs / B) pair-sets each: the
  * rendezvous of a pair-set never spans two windows, so a window that is resident never waits for one that is not):

@@ -102,6 +102,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     // fused forward: anchor operands as ring stages of 16 KB (32 channels: fp16 hi + lo, or fp32), codes as K-chunks
     g.NCH2 = (d->C + 31) / 32;
     g.NKC = (g.KQ + 31) / 32;
+    if (d->C == 192 && g.NKC < 2) g.NKC = 2;      // six feature stages: the forward's static stream head needs eight stages in all
     g.kper = (((g.KQ + g.NKC - 1) / g.NKC) + 7) & ~7;
     const size_t fs_ring = round_up((size_t)d->B * g.NCH2 * 16384 + 1024, 256);
     if (fs_ring > g.fs_bytes) g.fs_bytes = fs_ring;
@@ -312,7 +313,7 @@ const char* stego_error_string(int code)
         case STEGO_OK: return "ok";
         case STEGO_ERR_NULL: return "required pointer is NULL";
         case STEGO_ERR_SHAPE: return "bad or inconsistent dimension";
-        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S*S<=128, K<=128 (K>72: channels-last maps with C = 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
+        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S*S<=128, K<=128 (K>72: channels-last maps with C = 192 / 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
         case STEGO_ERR_WORKSPACE: return "workspace too small";
         case STEGO_ERR_ALIGN: return "pointer not 4-byte aligned";
         default: return code >= STEGO_ERR_HIP ? "HIP runtime error (code - 1000 = hipError_t)" : "unknown error";

@@ -202,7 +202,8 @@ __device__ __forceinline__ void point_taps(const FusedParams& prm, const f32x2 c
 // 0.4 TB/s chip-wide: 22 us for 8.6 MB).
 template <int NJ, int PREC, bool LIGHT = false>
 struct P1Layout {
-    static constexpr int NCH2 = 4 * NJ;
+    static constexpr int NCH2 = NJ == 2 ? 6 : 4 * NJ;          // feature stages of 32 channels: C / 32 (NJ = 2 is C = 192: the second 128-channel
+                                                               // group of a half-wave is half empty - lanes 16..31 carry zeros and store nothing)
     static constexpr int PLANES = PREC == PREC_F16X3 ? 2 : 1;
     static constexpr int RB = PREC == PREC_F16X3 ? 64 : 128;
     static constexpr int G = NJ <= 3 ? 2 : 1;                  // points per half-wave and pass (register budget: 48 NJ G)
@@ -304,7 +305,11 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         const f32x4* p3 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.w + 4 * hl) * 4));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {       // inactive points re-read pixel (0,0) of a valid image: harmless
-            t[g][j][0] = p0[32 * j]; t[g][j][1] = p1[32 * j]; t[g][j][2] = p2[32 * j]; t[g][j][3] = p3[32 * j];
+            if (NJ == 2 && j == 1 && hl >= 16) {      // C = 192: channels 192.. do not exist (the next pixel's, past the tensor for the last one)
+                t[g][j][0] = t[g][j][1] = t[g][j][2] = t[g][j][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                t[g][j][0] = p0[32 * j]; t[g][j][1] = p1[32 * j]; t[g][j][2] = p2[32 * j]; t[g][j][3] = p3[32 * j];
+            }
         }
     }
     auto code_loads = [&](int g) {
@@ -365,7 +370,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
             if constexpr (PREC == PREC_F32) {
                 const int c = 128 * j + 4 * hl;
                 const int u = ((c & 31) >> 2) ^ ((qq >> 1) & 7);
-                *reinterpret_cast<f32x4*>(lds + LY::feat_plane(c >> 5, 0) + lr * 128 + u * 16) = vn;
+                if (NJ != 2 || c < 32 * LY::NCH2) *reinterpret_cast<f32x4*>(lds + LY::feat_plane(c >> 5, 0) + lr * 128 + u * 16) = vn;
             } else {
                 unsigned h0, l0, h1, l1;
                 split_f16_pair(vn[0], vn[1], h0, l0);
@@ -376,7 +381,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
                 const u32x4 d = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
                 const int c = 128 * j + 4 * (hl & ~1);
                 const int u = ((c & 31) >> 3) ^ ((qq >> 2) & 3);
-                *reinterpret_cast<u32x4*>(lds + LY::feat_plane(c >> 5, odd ? 1 : 0) + lr * 64 + u * 16) = d;
+                if (NJ != 2 || c < 32 * LY::NCH2) *reinterpret_cast<u32x4*>(lds + LY::feat_plane(c >> 5, odd ? 1 : 0) + lr * 64 + u * 16) = d;
             }
         }
     };
@@ -1529,7 +1534,7 @@ bool fused_supported(const FusedParams& prm, int precision)
     auto cl2 = [&](const MapV& m) {          // channels-last code map; 4-byte aligned pixels are enough (odd K), K >= 3 then (see code_loads)
         return m.sc == 1 && (reinterpret_cast<uintptr_t>(m.p) % 4) == 0;
     };
-    if (!(prm.C == 384 || prm.C == 768)) return false;                         // NJ instantiations below
+    if (!(prm.C == 192 || prm.C == 384 || prm.C == 768)) return false;         // NJ instantiations below (ViT-T / ViT-S / ViT-B)
     // One workgroup per compute unit at a time (136 KB of LDS): the in-launch hand-offs (anchors, old_mean) are between workgroups
     // that run at the same time.  More tiles than CUs run as rounds of whole pair-sets (see the kernel), so a pair-set must fit:
     if (prm.B > (device_cu_count() & ~7)) return false;                       // (one pair-set = B tiles per round at least)
@@ -1603,8 +1608,16 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
         else if (prm.NKC == 3) STEGO_FUSED_LAUNCH(PR, N, 3);                                           \
         else STEGO_FUSED_LAUNCH(PR, N, 4);                                                             \
     } while (0)
-    if (precision == PREC_F32) { if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3); else STEGO_FUSED_NK(PREC_F32, 6); }
-    else { if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3); else STEGO_FUSED_NK(PREC_F16X3, 6); }
+#define STEGO_FUSED_NK2(PR)              /* C = 192: six feature stages, at least two code chunks (c_api.hip: geometry) */ \
+    do {                                                                                               \
+        if (prm.NKC == 2) STEGO_FUSED_LAUNCH(PR, 2, 2);                                                \
+        else if (prm.NKC == 3) STEGO_FUSED_LAUNCH(PR, 2, 3);                                           \
+        else if (prm.NKC == 4) STEGO_FUSED_LAUNCH(PR, 2, 4);                                           \
+        else return hipErrorInvalidValue;                                                              \
+    } while (0)
+    if (precision == PREC_F32) { if (prm.C == 192) STEGO_FUSED_NK2(PREC_F32); else if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3); else STEGO_FUSED_NK(PREC_F32, 6); }
+    else { if (prm.C == 192) STEGO_FUSED_NK2(PREC_F16X3); else if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3); else STEGO_FUSED_NK(PREC_F16X3, 6); }
+#undef STEGO_FUSED_NK2
 #undef STEGO_FUSED_NK
 #undef STEGO_FUSED_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -681,7 +681,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         if S * S > 128 or K > 128 or H > 32767 or W > 32767:
             return False
         if K > 72:
-            return C in (384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
+            return C in (192, 384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
         return True
 
     def generic_helper(self, f1, f2, c1, c2, shift):

@@ -103,9 +103,9 @@ class LitUnsupervisedSegmenter(nn.Module):
                 from .modules import _pair_set_bound
                 why = []
                 if cfg.arch != "dino":
-                    why.append("cfg.arch is not 'dino' (channels-last feature maps of width 384 / 768)")
-                elif getattr(self.net, "n_feats", 384) not in (384, 768):
-                    why.append("cfg.model_type=%s has feature width %d (the single-launch forward takes 384 / 768)"
+                    why.append("cfg.arch is not 'dino' (channels-last feature maps of width 192 / 384 / 768)")
+                elif getattr(self.net, "n_feats", 384) not in (192, 384, 768):
+                    why.append("cfg.model_type=%s has feature width %d (the single-launch forward takes 192 / 384 / 768)"
                                % (getattr(cfg, "model_type", "?"), self.net.n_feats))
                 if cfg.batch_size > _pair_set_bound():
                     why.append("cfg.batch_size = %d exceeds the %d compute units (the tiles of one pair-set run at the same time)"

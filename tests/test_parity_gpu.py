@@ -1403,6 +1403,41 @@ def test_event_counters_report_the_give_up_and_repair_paths():
         capi.debug_set("STEGO_DEBUG", 0)
 
 
+@pytest.mark.parametrize("shape", [(8, 14, 14, 70, 11, 5), (3, 6, 9, 101, 7, 2), (33, 14, 14, 24, 7, 5)])
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_vit_tiny_width_takes_the_single_launch_forward(shape, precision):
+    """C = 192 (vit_tiny, src/dino/vision_transformer.py:259-263): six feature stages of 32 channels - one and a half of the 128-channel
+    groups a half-wave samples at a time - on the single-launch kernel (round 4; the three-launch kernels before), forward and
+    backward against the fp64 oracle, incl. a code dimension above 72 and more tiles than compute units (33 x 7 = 231 ... one round)."""
+    B, H, W, K, S, n_neg = shape
+    C = 192
+    # (a seed whose cd has no element within fp32 rounding of the clamp bound: there the pass mask of ANY fp32 evaluation may differ from
+    # the fp64 oracle's, one whole term of a gradient sum - see tests/test_bwd_fused.py)
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=500 + K + B)
+    d["coords1"][B - 1, 0, 0] = [1.0, 1.0]                   # the last pixel of the last image: channels 192.. would be past the tensor
+    d["coords2"][B - 1, 0, 0] = [1.0, 1.0]
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    t = {k: _dev(v) for k, v in inputs.items()}
+    desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3 if precision == "f16x3" else capi.PREC_F32)
+    cl = [_channels_last(t[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+    assert capi.corr_fwd_launches(desc, *cl) == 1
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision=precision)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    la = 5e-4
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=la, what="intra_cd")
+    assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=la, what="inter_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=la, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=la, what="neg_cd")
+    scale = float(np.mean(np.abs(ref.neg_inter_loss)))
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_intra_loss))
+    assert abs(float(r["out"][2]) - float(ref.pos_inter_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_inter_loss))
+    g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * B * S ** 4))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
 @pytest.mark.parametrize("K", [3, 69, 71])
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_odd_code_dimensions_take_the_single_launch_forward(K, precision):

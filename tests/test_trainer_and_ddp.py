@@ -335,14 +335,20 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
 
 def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():
     """cfg.dim > 128 / cfg.feature_samples > 11 are valid in the reference (train_config.yml:39,51 are free): they run on the generic
-    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 on a
-    backbone whose feature width the single-launch kernel does not take (vit_tiny: 192): valid in the reference, it runs on the
-    generic path too.  (Odd code dimensions are served by the single-launch kernel since round 4.)"""
+    path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 on feature
+    maps the single-launch kernel does not take (the feature-pyramid arch: 2048 channels): valid in the reference, it runs on the
+    generic path too.  (Odd code dimensions and vit_tiny's 192 channels are served by the single-launch kernel since round 4.)"""
+    import warnings
     for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=12"], "cfg.feature_samples=12")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.warns(UserWarning, match=key):
             LitUnsupervisedSegmenter(5, cfg)
     cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32", "dim=99"])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        LitUnsupervisedSegmenter(5, cfg)
+    assert not [w for w in rec if "cfg.dim=99" in str(w.message)]
+    cfg = load_config(overrides=["arch=feature-pyramid", "model_type=resnet50", "granularity=2", "res=64", "allow_random_trunk=True", "dim=99"])
     with pytest.warns(UserWarning, match="cfg.dim=99"):
         LitUnsupervisedSegmenter(5, cfg)
 
