@@ -704,25 +704,44 @@ class ContrastiveCorrelationLoss(nn.Module):
 
     def generic_forward(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
         """modules.py:369-398 for any shape (any cfg.feature_samples, any cfg.dim): sample() with torch's grid_sample, the two
-        correlation tensors of every pair-set on the native dense kernel, the rest elementwise.  Same six return values."""
+        correlation tensors on the native dense kernel, the rest elementwise.  Same six return values.  All 2 + neg_samples pair-sets
+        go through ONE batch (their second operands stacked along the batch dimension, the per-set means of modules.py:331-333 taken
+        over a [sets, B, ...] view): a seventh of the launches of the reference's loop - the path is host-bound (7.9 ms per step as a
+        loop at B = 32, S = 12 .. 16; tools/exp/generic_time.py)."""
         cfg = self.cfg
+        B = orig_feats.shape[0]
+        n_neg = int(perms.shape[0]) if perms is not None else 0
+        n_sets = 2 + n_neg
         feats, code = sample(orig_feats, coords1), sample(orig_code, coords1)
-        feats_pos, code_pos = sample(orig_feats_pos, coords2), sample(orig_code_pos, coords2)
-        pos_intra_loss, pos_intra_cd = self.generic_helper(feats, feats, code, code, cfg.pos_intra_shift)
-        pos_inter_loss, pos_inter_cd = self.generic_helper(feats, feats_pos, code, code_pos, cfg.pos_inter_shift)
-        neg_losses, neg_cds = [], []
-        for i in range(int(perms.shape[0]) if perms is not None else 0):
-            perm_neg = perms[i]
-            feats_neg, code_neg = sample(orig_feats[perm_neg], coords2), sample(orig_code[perm_neg], coords2)
-            neg_inter_loss, neg_inter_cd = self.generic_helper(feats, feats_neg, code, code_neg, cfg.neg_inter_shift)
-            neg_losses.append(neg_inter_loss)
-            neg_cds.append(neg_inter_cd)
-        if neg_losses:
-            neg_inter_loss, neg_inter_cd = torch.cat(neg_losses, dim=0), torch.cat(neg_cds, dim=0)
+        f2, c2 = [feats, sample(orig_feats_pos, coords2)], [code, sample(orig_code_pos, coords2)]
+        if n_neg:
+            idx = perms.reshape(-1)                                       # [n_neg * B]: image perm_n[b] for pair (n, b)
+            c2_rep = coords2.repeat(n_neg, 1, 1, 1)
+            f2.append(sample(orig_feats[idx], c2_rep))
+            c2.append(sample(orig_code[idx], c2_rep))
+        f2, c2 = torch.cat(f2), torch.cat(c2)
+        f1, c1 = feats.repeat(n_sets, 1, 1, 1), code.repeat(n_sets, 1, 1, 1)
+        S1, S2 = feats.shape[2:]
+        per_set = lambda t: t.view(n_sets, B, S1, S2, S1, S2)            # noqa: E731
+        shift = torch.tensor([cfg.pos_intra_shift, cfg.pos_inter_shift] + [cfg.neg_inter_shift] * n_neg, dtype=feats.dtype,
+                             device=feats.device).view(n_sets, 1, 1, 1, 1, 1)
+        with torch.no_grad():
+            fd = per_set(tensor_correlation(norm(f1), norm(f2)))
+            if cfg.pointwise:                                            # helper(), modules.py:331-333, per pair-set
+                # (a set's mean as the mean of its row means - equal counts: the same number, and a reduction with B S^2 outputs per
+                # set instead of ONE, which torch runs on a handful of workgroups: 0.45 ms each at S = 16)
+                row = fd.mean([4, 5], keepdim=True)
+                old_mean = row.mean(dim=(1, 2, 3), keepdim=True)
+                fd -= row
+                fd = fd - fd.mean([4, 5], keepdim=True).mean(dim=(1, 2, 3), keepdim=True) + old_mean
+        cd = per_set(tensor_correlation(norm(c1), norm(c2)))
+        min_val = 0.0 if cfg.zero_clamp else -9999.0
+        loss = -(cd.clamp(min_val, .8) if cfg.stabalize else cd.clamp(min_val)) * (fd - shift)
+        if n_neg:
+            neg_inter_loss, neg_inter_cd = loss[2:].flatten(0, 1), cd[2:].flatten(0, 1)
         else:
-            S = cfg.feature_samples
-            neg_inter_loss = neg_inter_cd = pos_intra_cd.new_zeros(0, S, S, S, S)
-        return pos_intra_loss.mean(), pos_intra_cd, pos_inter_loss.mean(), pos_inter_cd, neg_inter_loss, neg_inter_cd
+            neg_inter_loss = neg_inter_cd = cd.new_zeros(0, S1, S2, S1, S2)
+        return loss[0].mean(), cd[0], loss[1].mean(), cd[1], neg_inter_loss, neg_inter_cd
 
     def forward_explicit(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
         """forward() with the RNG draws supplied by the caller (perms: int64 [neg_samples, B])."""
