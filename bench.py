@@ -405,6 +405,14 @@ def main():
                 graphs = None
                 launch = "eager (graph capture failed: %s)" % type(e).__name__
                 torch.cuda.synchronize()
+            if dist is not None and world > 1:
+                # every rank must step the same way: a rank that replays graphs holding the all-reduce and a rank that launches eagerly
+                # with its own all-reduce calls would wait for each other forever - if ANY rank's capture failed, all go eager
+                ok = torch.tensor([1 if graphs is not None else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and graphs is not None:
+                    graphs = None
+                    launch = "eager (graph capture failed on another rank)"
 
         pending = [None]
 
