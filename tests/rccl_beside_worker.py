@@ -38,7 +38,16 @@ def main():
     assert capi.corr_fwd_launches(desc, d["feats"], d["feats_pos"], d["code"], d["code_pos"]) == 1
     quiet = [t.clone() for t in step()]
     torch.cuda.synchronize()
-    rec = {"backend": "nccl", "world": 1, "eager_rounds": 0, "graph_rounds": 0, "eager_equal": True, "graph_equal": True}
+    rec = {"backend": "nccl", "world": 1, "eager_rounds": 0, "graph_rounds": 0, "eager_equal": True, "graph_equal": True, "diffs": []}
+    names = ("means", "intra_cd", "inter_cd", "neg_loss", "neg_cd", "d_code", "d_code_pos")
+
+    def same(got, mode, rnd):
+        ok = True
+        for n, a, b in zip(names, got, quiet):
+            if not torch.equal(a, b):       # (for the record of a failure: which output, by how much, in which round)
+                ok = False
+                rec["diffs"].append([mode, rnd, n, float((a.float() - b.float()).abs().max()), int((a != b).sum())])
+        return ok
     side = torch.cuda.Stream()
     for _ in range(12):                                 # eager: the collective on its own stream, the step beside it
         with torch.cuda.stream(side):
@@ -47,7 +56,7 @@ def main():
         got = step()
         w1.wait(); w2.wait()
         torch.cuda.synchronize()
-        rec["eager_equal"] = rec["eager_equal"] and all(torch.equal(a, b) for a, b in zip(got, quiet))
+        rec["eager_equal"] = same(got, "eager", rec["eager_rounds"]) and rec["eager_equal"]
         rec["eager_rounds"] += 1
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -67,7 +76,7 @@ def main():
     for _ in range(12):
         g.replay()
         torch.cuda.synchronize()
-        rec["graph_equal"] = rec["graph_equal"] and all(torch.equal(a, b) for a, b in zip(held, quiet))
+        rec["graph_equal"] = same(held, "graph", rec["graph_rounds"]) and rec["graph_equal"]
         rec["graph_rounds"] += 1
     rec["bucket_is_ones"] = bool((bucket == 1).all())   # (the mean over one rank)
     dist.destroy_process_group()

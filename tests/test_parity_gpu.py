@@ -1102,10 +1102,14 @@ def test_loss_kernels_beside_an_rccl_kernel_give_the_same_bits():
     outputs and both gradients bit for bit those of the quiet device."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT="29563", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port (a fixed one may still be held by an earlier test's group)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_beside_worker.py")], capture_output=True, text=True,
                          timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert rec["eager_equal"] and rec["graph_equal"] and rec["bucket_is_ones"] and rec["eager_rounds"] == 12 and rec["graph_rounds"] == 12, rec
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
