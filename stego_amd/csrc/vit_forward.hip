@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
         // wide, coalesced stores, 128 rows per pass.  Storing straight from the accumulators (a lane owns one column:
         // 2-byte stores, 64 B runs, or fully scattered for V^T) cost more than the whole k loop.
         // F16X3 has twice the bytes to park and the same LDS: four passes - GELU by column half (three 32-column chunk panels, hi |
-        // lo in one row), QKV by plane (the hi values of all three 64-column groups, then the lo values into the lo arrays).
+        // lo in one row) in two balanced sets, QKV by plane (the hi values of all three 64-column groups, then the lo values into the lo arrays).
         half_t* T = reinterpret_cast<half_t*>(smem);
         constexpr int GRP = VP_ROWS * VP_LD;            // halves per 64-column group region of one pass (18 KiB)
         constexpr int LDV = VP_ROWS + 8;                // V^T rows: 128 tokens + pad
@@ -350,9 +350,14 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
             const int rh = X3 ? pass >> 1 : pass;       // row half of the tile
             const int sub = pass & 1;                   // F16X3: column half (GELU) / plane (QKV)
             __syncthreads();                            // stage buffer / previous pass's park region is free
-            if ((wr >> 1) == rh && !(X3 && EPI == EPI_GELU && wc != sub)) {
+            if ((wr >> 1) == rh) {
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni) {
+                    // F16X3 GELU: the six 32-column chunk panels of a row half leave three per pass, and all four waves of the row
+                    // half work in both passes (two blocks and one, then one and two) - by column half only two of eight waves computed
+                    // at a time.  Slot of (wc, ni) in its pass: sub 0 = {(0,0) (0,1) (1,0)}, sub 1 = {(0,2) (1,1) (1,2)}
+                    const int gslot = sub == 0 ? (wc == 0 ? (ni < 2 ? ni : -1) : (ni == 0 ? 2 : -1)) : (wc == 0 ? (ni == 2 ? 0 : -1) : (ni >= 1 ? ni : -1));
+                    if (X3 && EPI == EPI_GELU && gslot < 0) continue;
                     const int col = 96 * wc + 32 * ni + r, cg = col >> 6, cl = col & 63;
                     const int n = nt * GT_N + col;
                     const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
@@ -369,8 +374,8 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
                                 if constexpr (EPI == EPI_GELU && X3) {
                                     const float g = gelu(v) * VIT_ASCALE;
                                     const half_t hi = (half_t)g;
-                                    T[ni * GRP + lrow * VP_LD + r] = hi;
-                                    T[ni * GRP + lrow * VP_LD + 32 + r] = (half_t)(g - (float)hi);
+                                    T[gslot * GRP + lrow * VP_LD + r] = hi;
+                                    T[gslot * GRP + lrow * VP_LD + 32 + r] = (half_t)(g - (float)hi);
                                 } else if constexpr (EPI == EPI_GELU) {
                                     T[cg * GRP + lrow * VP_LD + cl] = (half_t)gelu(v);
                                 } else {
@@ -390,7 +395,8 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
             if constexpr (EPI == EPI_GELU) {
                 // the three [128][72] images are panels already: linear 16-byte copies
                 for (int cg = 0; cg < 3; ++cg) {
-                    const int kc = X3 ? nt * 6 + sub * 3 + cg : nt * 3 + cg;
+                    // (F16X3: slot cg of pass sub holds chunk 3 wc + ni of the tile, see the park above)
+                    const int kc = X3 ? nt * 6 + (sub == 0 ? (cg < 2 ? cg : 3) : (cg == 0 ? 2 : 3 + cg)) : nt * 3 + cg;
                     if (kc >= p.out_nkc) continue;
                     unsigned char* dst = p.outp + ((size_t)(2 * mt + rh) * p.out_nkc + kc) * VP_BYTES;
                     const unsigned char* src = smem + cg * VP_BYTES;
