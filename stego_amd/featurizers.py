@@ -127,6 +127,9 @@ def _mask_variant(net, x, n, q):
     except (RuntimeError, AttributeError):
         v = -1
     _MASK_VARIANTS[key] = v
+    from .modules import _report_variant
+    _report_variant("the Dropout2d masks of the segmentation head (%d masks of %d channels)" % (n, key[1]), "stego_ref_dropout_masks", v,
+                    "%d bernoulli_ / div_ launches per step instead of one" % (2 * int(n)))
     return v
 
 

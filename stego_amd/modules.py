@@ -14,6 +14,9 @@ Same names, argument meaning and return values as the reference so that
 
 There is no CPU / pure-PyTorch fallback for the loss: non-HIP tensors raise.
 """
+import logging
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -169,7 +172,24 @@ def ref_draw_variant(shape, n, B, dev):
     except (RuntimeError, AttributeError):
         v = -1
     _REF_DRAW_VARIANTS[key] = v
+    _report_variant("the RNG draws of ContrastiveCorrelationLoss.forward (torch.rand x 2 + torch.randperm x %d, B = %d)" % (n, B),
+                    "stego_ref_draws", v, "~%d tiny launches per step instead of one" % (6 + 5 * int(n)))
     return v
+
+
+_REPORTED_FALLBACKS = set()
+
+
+def _report_variant(what, kernel, variant, cost):
+    """Says once per kind which restatement of the installed torch's generator arithmetic was selected - or, as a WARNING, that none
+    matched and the torch calls stay (a torch upgrade must not return the product path to dozens of launches per step silently)."""
+    log = logging.getLogger("stego_amd")
+    if variant >= 0:
+        log.info("%s: variant %d of %s reproduces torch %s bit for bit (checked once per size)", what, variant, kernel, torch.__version__)
+    elif (what, kernel) not in _REPORTED_FALLBACKS:
+        _REPORTED_FALLBACKS.add((what, kernel))
+        warnings.warn("stego_amd: no variant of %s reproduces torch %s for %s - the torch calls are kept (same numbers, %s)"
+                      % (kernel, torch.__version__, what, cost))
 
 
 def _usable_ref_draw_variant(shape, n, B, dev):

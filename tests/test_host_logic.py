@@ -389,3 +389,20 @@ def test_lazy_loss_sum_contract_every_use_equals_the_plain_expression():
     assert ("%.4f" % e) == ("%.4f" % float(e)) and bool(e > 0) and np.asarray(e.detach()).shape == () and e.item() == float(e)
     assert isinstance(e.detach(), torch.Tensor) and not isinstance(e.detach(), M._LossScalar)
     # with cfg.lazy_loss_sums = False nothing is wrapped (checked on the GPU path: tests/test_parity_gpu.py)
+
+
+def test_the_selected_generator_restatement_is_reported_and_a_fallback_warns_once(caplog):
+    """stego_ref_draws / stego_ref_dropout_masks restate ATen's generator arithmetic; the self-check that selects a
+    variant (or keeps the torch calls) must say which - a torch upgrade may not silently return the step to dozens of tiny launches."""
+    import logging
+    import warnings
+    from stego_amd import modules as M
+    with caplog.at_level(logging.INFO, logger="stego_amd"):
+        M._report_variant("the draws (test)", "stego_ref_draws", 3, "cost")
+    assert any("variant 3 of stego_ref_draws" in r.getMessage() for r in caplog.records)
+    M._REPORTED_FALLBACKS.discard(("the draws (test)", "stego_ref_draws"))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        M._report_variant("the draws (test)", "stego_ref_draws", -1, "~31 tiny launches per step instead of one")
+        M._report_variant("the draws (test)", "stego_ref_draws", -1, "~31 tiny launches per step instead of one")
+    assert len(rec) == 1 and "torch calls are kept" in str(rec[0].message) and "31 tiny launches" in str(rec[0].message)
