@@ -406,3 +406,37 @@ def test_the_selected_generator_restatement_is_reported_and_a_fallback_warns_onc
         M._report_variant("the draws (test)", "stego_ref_draws", -1, "~31 tiny launches per step instead of one")
         M._report_variant("the draws (test)", "stego_ref_draws", -1, "~31 tiny launches per step instead of one")
     assert len(rec) == 1 and "torch calls are kept" in str(rec[0].message) and "31 tiny launches" in str(rec[0].message)
+
+
+@pytest.mark.parametrize("S,n_neg,pointwise,stab", [(12, 2, True, False), (13, 0, True, True), (5, 3, False, False)])
+def test_generic_forward_as_one_batch_of_pair_sets_equals_the_oracle(S, n_neg, pointwise, stab):
+    """generic_forward (what feature_samples > 11 or dim > 128 run on) computes all 2 + neg_samples pair-sets in ONE batch, the per-set
+    means of modules.py:331-333 over a [sets, B, ...] view: forward values and the gradients into both code maps against the fp64
+    restatement of the reference's loop (torch on CPU tensors: grid_sample + einsum - the same code the device path runs with the
+    native dense kernel in place of the einsum)."""
+    from oracle import corr_oracle as O
+    B, C, H, W, K = 3, 16, 7, 6, 9
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=321 + S)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg, pointwise=pointwise, stabalize=stab)
+    t = {k: torch.from_numpy(np.asarray(d[k])) for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    perms = torch.from_numpy(np.asarray(d["perms"])) if n_neg else None
+    code, code_pos = t["code"].clone().requires_grad_(True), t["code_pos"].clone().requires_grad_(True)
+    out = M.ContrastiveCorrelationLoss(cfg).generic_forward(t["feats"], t["feats_pos"], code, code_pos, t["coords1"], t["coords2"], perms)
+    ref = O.corr_loss_forward(d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], cfg)
+    assert_close(out[1].detach().numpy(), ref.pos_intra_cd, rtol=1e-4, atol_frac=1e-4, what="intra_cd")
+    assert_close(out[3].detach().numpy(), ref.pos_inter_cd, rtol=1e-4, atol_frac=1e-4, what="inter_cd")
+    assert abs(float(out[0].detach()) - float(ref.pos_intra_loss)) < 1e-5 + 1e-4 * abs(float(ref.pos_intra_loss))
+    assert abs(float(out[2].detach()) - float(ref.pos_inter_loss)) < 1e-5 + 1e-4 * abs(float(ref.pos_inter_loss))
+    assert tuple(out[4].shape) == (n_neg * B, S, S, S, S) and tuple(out[5].shape) == (n_neg * B, S, S, S, S)
+    total = 0.67 * out[0] + 0.25 * out[2]
+    g_nl = None
+    if n_neg:
+        assert_close(out[4].detach().numpy(), ref.neg_inter_loss, rtol=1e-4, atol_frac=1e-4, what="neg_loss")
+        assert_close(out[5].detach().numpy(), ref.neg_inter_cd, rtol=1e-4, atol_frac=1e-4, what="neg_cd")
+        total = total + 0.63 * out[4].mean()
+        g_nl = np.full(ref.neg_inter_loss.shape, 0.63 / (n_neg * B * S ** 4))
+    total.backward()
+    dc, dcp = O.corr_loss_backward(d["feats"], d["feats_pos"], d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], cfg,
+                                   0.67, 0.25, g_nl)
+    assert_close(code.grad.numpy(), dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
+    assert_close(code_pos.grad.numpy(), dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
