@@ -743,8 +743,6 @@ class ContrastiveCorrelationLoss(nn.Module):
         f1, c1 = feats.repeat(n_sets, 1, 1, 1), code.repeat(n_sets, 1, 1, 1)
         S1, S2 = feats.shape[2:]
         per_set = lambda t: t.view(n_sets, B, S1, S2, S1, S2)            # noqa: E731
-        shift = torch.tensor([cfg.pos_intra_shift, cfg.pos_inter_shift] + [cfg.neg_inter_shift] * n_neg, dtype=feats.dtype,
-                             device=feats.device).view(n_sets, 1, 1, 1, 1, 1)
         with torch.no_grad():
             fd = per_set(tensor_correlation(norm(f1), norm(f2)))
             if cfg.pointwise:                                            # helper(), modules.py:331-333, per pair-set
@@ -754,9 +752,15 @@ class ContrastiveCorrelationLoss(nn.Module):
                 old_mean = row.mean(dim=(1, 2, 3), keepdim=True)
                 fd -= row
                 fd = fd - fd.mean([4, 5], keepdim=True).mean(dim=(1, 2, 3), keepdim=True) + old_mean
+            # fd - shift with the pair-set's own shift (Python numbers: no host-to-device copy, the step stays capturable in a graph)
+            fds = torch.empty_like(fd)
+            torch.sub(fd[0], cfg.pos_intra_shift, out=fds[0])
+            torch.sub(fd[1], cfg.pos_inter_shift, out=fds[1])
+            if n_neg:
+                torch.sub(fd[2:], cfg.neg_inter_shift, out=fds[2:])
         cd = per_set(tensor_correlation(norm(c1), norm(c2)))
         min_val = 0.0 if cfg.zero_clamp else -9999.0
-        loss = -(cd.clamp(min_val, .8) if cfg.stabalize else cd.clamp(min_val)) * (fd - shift)
+        loss = -(cd.clamp(min_val, .8) if cfg.stabalize else cd.clamp(min_val)) * fds
         if n_neg:
             neg_inter_loss, neg_inter_cd = loss[2:].flatten(0, 1), cd[2:].flatten(0, 1)
         else:
