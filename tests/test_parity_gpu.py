@@ -1107,9 +1107,12 @@ def test_loss_kernels_beside_an_rccl_kernel_give_the_same_bits():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_beside_worker.py")], capture_output=True, text=True,
-                         timeout=600, env=env)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    cmd = [sys.executable, os.path.join(root, "tests", "rccl_beside_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    if out.returncode != 0:       # the process group did not come up (rendezvous / RCCL init): once more - a MISMATCH is a zero exit code
+        first = out.stderr[-1500:]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, MASTER_PORT=str(port + 1)))
+        assert out.returncode == 0, (first, out.stdout[-1500:], out.stderr[-3000:])
     rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert rec["eager_equal"] and rec["graph_equal"] and rec["bucket_is_ones"] and rec["eager_rounds"] == 12 and rec["graph_rounds"] == 12, rec
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
