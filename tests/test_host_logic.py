@@ -440,3 +440,19 @@ def test_generic_forward_as_one_batch_of_pair_sets_equals_the_oracle(S, n_neg, p
                                    0.67, 0.25, g_nl)
     assert_close(code.grad.numpy(), dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
     assert_close(code_pos.grad.numpy(), dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+def test_bench_denominators_are_the_contract_s_numbers():
+    """The roofline fractions of bench.py divide by SURVEY.md 8(d)'s algorithmic bytes - every distinct tensor once, fp32.  The figures
+    the round verdicts recomputed (113 671 436 B forward, 48 543 488 B backward at BASELINE config 2) are pinned here: a changed
+    denominator would move every reported fraction without a kernel getting faster."""
+    import bench
+    B, C, H, W, K, S, n_neg = 32, 384, 28, 28, 70, 11, 5
+    fwd = bench.algorithmic_bytes_fwd(B, C, H, W, K, S, n_neg)
+    # inputs: two feature maps, two code maps, two coordinate sets, the permutations; outputs: cd of 2 + n_neg pair-sets, the negative loss
+    # tensor, three scalars
+    assert fwd == 4 * (2 * B * C * H * W + 2 * B * K * H * W + 2 * B * S * S * 2) + 8 * n_neg * B + 4 * (7 + 5) * B * S ** 4 + 12 == 113671436
+    assert bench.algorithmic_bytes_bwd(B, K, H, W, S, n_neg) == 48543488
+    assert bench.algorithmic_flops_fwd(B, C, K, S, n_neg) == 2 * 7 * B * S ** 4 * (C + K) == 2977862272
+    assert bench.WORKLOADS["vits8_224"] == (384, 28, 28, 70) and bench.WORKLOADS["vitb8_320"] == (768, 40, 40, 70)
+    assert bench.head_grad_numel(384, 70) == 384 * 70 + 70 + 384 * 384 + 384 + 384 * 70 + 70 + 70 * 27 + 27 + 27 * 70
