@@ -456,3 +456,30 @@ def test_bench_denominators_are_the_contract_s_numbers():
     assert bench.algorithmic_flops_fwd(B, C, K, S, n_neg) == 2 * 7 * B * S ** 4 * (C + K) == 2977862272
     assert bench.WORKLOADS["vits8_224"] == (384, 28, 28, 70) and bench.WORKLOADS["vitb8_320"] == (768, 40, 40, 70)
     assert bench.head_grad_numel(384, 70) == 384 * 70 + 70 + 384 * 384 + 384 + 384 * 70 + 70 + 70 * 27 + 27 + 27 * 70
+
+
+def test_the_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the package
+    itself must fail loudly without the HIP library rather than fall back to a CPU restatement."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "stego_amd", "**", "*.py"), recursive=True):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") or n == "oracle_backend" for n in names), (path, names)
+    # bench.py: the oracle appears in cpu_baseline() only; __graft_entry__: in smoke() only
+    for fname, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(root, fname)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            body = fn.body if isinstance(fn, ast.Module) else []
+            for node in (ast.walk(fn) if isinstance(fn, ast.FunctionDef) else body):
+                if isinstance(node, (ast.Import, ast.ImportFrom)):
+                    mod = node.module if isinstance(node, ast.ImportFrom) else node.names[0].name
+                    if mod and (mod == "oracle" or mod.startswith("oracle.")):
+                        assert isinstance(fn, ast.FunctionDef) and fn.name == allowed, (fname, getattr(fn, "name", "module level"))
