@@ -50,6 +50,13 @@
 #include "corr_tile.h"
 #include "host_util.h"
 
+// This file is compiled three times (the 44 instantiations of the kernel take two minutes in one translation unit): as itself - the host
+// side and the even-K kernels of C = 384 / 768 (the BASELINE configs) - and, included by corr_fused_odd.hip / corr_fused_c192.hip with
+// STEGO_FUSED_PART = 1 / 2, for the odd-K kernels and the C = 192 kernels with their two launch functions.  Same template, same code.
+#ifndef STEGO_FUSED_PART
+#define STEGO_FUSED_PART 0
+#endif
+
 namespace stego {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1524,6 +1531,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
 }
 
 // ------------------------------------------------------------------------------------------------------ launch
+#if STEGO_FUSED_PART == 0
 bool fused_supported(const FusedParams& prm, int precision)
 {
     auto cl4 = [&](const MapV& m) {
@@ -1552,6 +1560,32 @@ hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStre
 {
     return hipMemsetAsync(prm.anchor_cnt, 0, sync_bytes, stream);
 }
+
+hipError_t launch_fused_odd(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream);      // corr_fused_odd.hip
+hipError_t launch_fused_c192(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream);     // corr_fused_c192.hip
+
+// one instantiation: dynamic LDS attribute, launch
+#define STEGO_FUSED_ONE(PR, N, NK, ODD)                                                                \
+    do {                                                                                               \
+        hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, ODD>), lds); \
+        if (e_ != hipSuccess) return e_;                                                               \
+        hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, ODD>), grid, block, lds, stream, prm);        \
+        return hipSuccess;                                                                             \
+    } while (0)
+#define STEGO_FUSED_NK(PR, N, ODD)                                                                     \
+    do {                                                                                               \
+        if (prm.NKC == 1) STEGO_FUSED_ONE(PR, N, 1, ODD);                                              \
+        else if (prm.NKC == 2) STEGO_FUSED_ONE(PR, N, 2, ODD);                                         \
+        else if (prm.NKC == 3) STEGO_FUSED_ONE(PR, N, 3, ODD);                                         \
+        else STEGO_FUSED_ONE(PR, N, 4, ODD);                                                           \
+    } while (0)
+static hipError_t launch_fused_even(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream)
+{
+    if (precision == PREC_F32) { if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3, false); else STEGO_FUSED_NK(PREC_F32, 6, false); }
+    else { if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3, false); else STEGO_FUSED_NK(PREC_F16X3, 6, false); }
+}
+#undef STEGO_FUSED_NK
+#undef STEGO_FUSED_ONE
 
 hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sync_bytes, bool prepared, bool shared_device,
                              hipStream_t stream, hipEvent_t* ev /* null or [4]: before the memset, before / after the kernel, end */)
@@ -1589,40 +1623,61 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     if (!prepared && (e = prepare_corr_fused(prm, sync_bytes, stream)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], stream);
     const dim3 grid(n_tiles > prm.n_owner ? n_tiles : prm.n_owner), block(FUSED_THREADS);
-#define STEGO_FUSED_LAUNCH(PR, N, NK)                                                                  \
-    do {                                                                                               \
-        if (prm.K & 1) {                                                                               \
-            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, true>), lds);  \
-            if (e != hipSuccess) return e;                                                             \
-            hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, true>), grid, block, lds, stream, prm);   \
-        } else {                                                                                       \
-            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, false>), lds); \
-            if (e != hipSuccess) return e;                                                             \
-            hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, false>), grid, block, lds, stream, prm);  \
-        }                                                                                              \
-    } while (0)
-#define STEGO_FUSED_NK(PR, N)                                                                          \
-    do {                                                                                               \
-        if (prm.NKC == 1) STEGO_FUSED_LAUNCH(PR, N, 1);                                                \
-        else if (prm.NKC == 2) STEGO_FUSED_LAUNCH(PR, N, 2);                                           \
-        else if (prm.NKC == 3) STEGO_FUSED_LAUNCH(PR, N, 3);                                           \
-        else STEGO_FUSED_LAUNCH(PR, N, 4);                                                             \
-    } while (0)
-#define STEGO_FUSED_NK2(PR)              /* C = 192: six feature stages, at least two code chunks (c_api.hip: geometry) */ \
-    do {                                                                                               \
-        if (prm.NKC == 2) STEGO_FUSED_LAUNCH(PR, 2, 2);                                                \
-        else if (prm.NKC == 3) STEGO_FUSED_LAUNCH(PR, 2, 3);                                           \
-        else if (prm.NKC == 4) STEGO_FUSED_LAUNCH(PR, 2, 4);                                           \
-        else return hipErrorInvalidValue;                                                              \
-    } while (0)
-    if (precision == PREC_F32) { if (prm.C == 192) STEGO_FUSED_NK2(PREC_F32); else if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3); else STEGO_FUSED_NK(PREC_F32, 6); }
-    else { if (prm.C == 192) STEGO_FUSED_NK2(PREC_F16X3); else if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3); else STEGO_FUSED_NK(PREC_F16X3, 6); }
-#undef STEGO_FUSED_NK2
-#undef STEGO_FUSED_NK
-#undef STEGO_FUSED_LAUNCH
+    e = prm.C == 192 ? launch_fused_c192(prm, precision, grid, block, lds, stream)
+        : (prm.K & 1) ? launch_fused_odd(prm, precision, grid, block, lds, stream) : launch_fused_even(prm, precision, grid, block, lds, stream);
+    if (e != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
     return hipGetLastError();
 }
+
+
+#elif STEGO_FUSED_PART == 1
+// one instantiation: dynamic LDS attribute, launch
+#define STEGO_FUSED_ONE(PR, N, NK, ODD)                                                                \
+    do {                                                                                               \
+        hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, ODD>), lds); \
+        if (e_ != hipSuccess) return e_;                                                               \
+        hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, ODD>), grid, block, lds, stream, prm);        \
+        return hipSuccess;                                                                             \
+    } while (0)
+#define STEGO_FUSED_NK(PR, N, ODD)                                                                     \
+    do {                                                                                               \
+        if (prm.NKC == 1) STEGO_FUSED_ONE(PR, N, 1, ODD);                                              \
+        else if (prm.NKC == 2) STEGO_FUSED_ONE(PR, N, 2, ODD);                                         \
+        else if (prm.NKC == 3) STEGO_FUSED_ONE(PR, N, 3, ODD);                                         \
+        else STEGO_FUSED_ONE(PR, N, 4, ODD);                                                           \
+    } while (0)
+hipError_t launch_fused_odd(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream)
+{
+    if (precision == PREC_F32) { if (prm.C == 384) STEGO_FUSED_NK(PREC_F32, 3, true); else STEGO_FUSED_NK(PREC_F32, 6, true); }
+    else { if (prm.C == 384) STEGO_FUSED_NK(PREC_F16X3, 3, true); else STEGO_FUSED_NK(PREC_F16X3, 6, true); }
+}
+#undef STEGO_FUSED_NK
+#undef STEGO_FUSED_ONE
+#else
+// one instantiation: dynamic LDS attribute, launch
+#define STEGO_FUSED_ONE(PR, N, NK, ODD)                                                                \
+    do {                                                                                               \
+        hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_kernel<PR, N, NK, ODD>), lds); \
+        if (e_ != hipSuccess) return e_;                                                               \
+        hipLaunchKernelGGL((corr_fused_kernel<PR, N, NK, ODD>), grid, block, lds, stream, prm);        \
+        return hipSuccess;                                                                             \
+    } while (0)
+#define STEGO_FUSED_NK(PR, N, ODD)        /* C = 192: six feature stages, at least two code chunks (c_api.hip: geometry) */ \
+    do {                                                                                               \
+        if (prm.NKC == 2) STEGO_FUSED_ONE(PR, N, 2, ODD);                                              \
+        else if (prm.NKC == 3) STEGO_FUSED_ONE(PR, N, 3, ODD);                                         \
+        else if (prm.NKC == 4) STEGO_FUSED_ONE(PR, N, 4, ODD);                                         \
+        else return hipErrorInvalidValue;                                                              \
+    } while (0)
+hipError_t launch_fused_c192(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream)
+{
+    if (precision == PREC_F32) { if (prm.K & 1) STEGO_FUSED_NK(PREC_F32, 2, true); else STEGO_FUSED_NK(PREC_F32, 2, false); }
+    else { if (prm.K & 1) STEGO_FUSED_NK(PREC_F16X3, 2, true); else STEGO_FUSED_NK(PREC_F16X3, 2, false); }
+}
+#undef STEGO_FUSED_NK
+#undef STEGO_FUSED_ONE
+#endif
 
 }  // namespace stego

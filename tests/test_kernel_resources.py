@@ -14,22 +14,34 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_fused_forward_register_budget(tmp_path):
-    src = os.path.join(ROOT, "stego_amd", "csrc", "corr_fused.hip")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
-           "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "cf.o"), "-Rpass-analysis=kernel-resource-usage"]
-    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
-    assert res.returncode == 0, res.stderr[-2000:]
+    # the kernel is compiled as three translation units (corr_fused.hip: even K at C = 384 / 768; _odd: odd K; _c192: C = 192)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(name):
+        src = os.path.join(ROOT, "stego_amd", "csrc", name)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+               "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / (name + ".o")), "-Rpass-analysis=kernel-resource-usage"]
+        return subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+
+    with ThreadPoolExecutor(3) as ex:
+        results = list(ex.map(compile_one, ["corr_fused.hip", "corr_fused_odd.hip", "corr_fused_c192.hip"]))
     kernels = {}
-    name = None
-    for line in res.stderr.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-            kernels[name] = {}
-            continue
-        m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
-        if m and name:
-            kernels[name][m.group(1)] = int(m.group(2))
+    per_unit = []
+    for res in results:
+        assert res.returncode == 0, res.stderr[-2000:]
+        name = None
+        before = len(kernels)
+        for line in res.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                kernels[name] = {}
+                continue
+            m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+            if m and name:
+                kernels[name][m.group(1)] = int(m.group(2))
+        per_unit.append(len([k for k in list(kernels)[before:] if "corr_fused_kernel" in k]))
+    assert per_unit == [16, 16, 12], per_unit                   # even K: 2 precisions x 2 widths x 4 code-chunk counts; odd K: the same; C = 192: 2 x 3 x even / odd
     fused = {k: v for k, v in kernels.items() if "corr_fused_kernel" in k}
     assert len(fused) == 44, sorted(kernels)                    # 2 precisions x (2 widths x 4 + C = 192 x 3) code-chunk counts x even / odd K
     for k, v in fused.items():
