@@ -49,3 +49,35 @@ def test_fused_forward_register_budget(tmp_path):
         assert v["Occupancy [waves/SIMD]"] >= 3, (k, v)
     head = fused["_ZN5stego17corr_fused_kernelILi1ELi3ELi3ELb0EEEvNS_11FusedParamsE"]  # f16x3, C = 384, K <= 96, even: BASELINE config 2
     assert head["VGPRs Spill"] <= 24 and head["ScratchSize [bytes/lane]"] <= 96, head
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_backbone_gemm_register_budget(tmp_path):
+    """The ViT GEMM runs two 512-thread workgroups per CU on 128 registers per lane; its F16X3 k loop holds 96 accumulators + 40 operand
+    registers.  An epilogue that finished all 96 values of a wave before its passes made the compiler spill 400 registers INSIDE the k
+    loop (42 ms instead of 14 for the forward): the spill counts of today are pinned."""
+    src = os.path.join(ROOT, "stego_amd", "csrc", "vit_forward.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+           "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "vit.o"), "-Rpass-analysis=kernel-resource-usage"]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels, name = {}, None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1)] = int(m.group(2))
+    gemm = {k: v for k, v in kernels.items() if "vit_gemm_kernel" in k}
+    assert len(gemm) == 8, sorted(kernels)                       # 4 epilogues x 2 precisions
+    for k, v in gemm.items():
+        assert v["Occupancy [waves/SIMD]"] >= 4, (k, v)          # two workgroups per CU
+        qkv = "ILi3E" in k                                       # (the QKV epilogue has always spilled a few dozen registers: outside the k loop)
+        assert v["VGPRs Spill"] <= (48 if qkv else 8), (k, v)
+    attn = {k: v for k, v in kernels.items() if "vit_attn_kernel" in k}
+    assert len(attn) == 2
+    for k, v in attn.items():
+        assert v["VGPRs Spill"] == 0 and v["Occupancy [waves/SIMD]"] >= 2, (k, v)
