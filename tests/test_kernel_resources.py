@@ -81,3 +81,30 @@ def test_backbone_gemm_register_budget(tmp_path):
     assert len(attn) == 2
     for k, v in attn.items():
         assert v["VGPRs Spill"] == 0 and v["Occupancy [waves/SIMD]"] >= 2, (k, v)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_backward_kernels_do_not_spill(tmp_path):
+    """Every kernel of the loss backward (tiles with and without builders in both precisions, the list and the row unsample) keeps its
+    working set in registers today; the training pair - corr_bwd_tile_build_kernel<5> (K = 70) and corr_unsample_list_kernel<1, 1> - at the
+    occupancies the workgroup sizes of the launch need."""
+    src = os.path.join(ROOT, "stego_amd", "csrc", "corr_bwd.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+           "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "bwd.o"), "-Rpass-analysis=kernel-resource-usage"]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels, name = {}, None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1)] = int(m.group(2))
+    assert len(kernels) >= 40, sorted(kernels)
+    for k, v in kernels.items():
+        assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    assert kernels["_ZN5stego26corr_bwd_tile_build_kernelILi5EEEvNS_9BwdParamsE"]["Occupancy [waves/SIMD]"] >= 2        # 512 threads: one workgroup per CU
+    assert kernels["_ZN5stego25corr_unsample_list_kernelILi1ELi1EEEvNS_9BwdParamsE"]["Occupancy [waves/SIMD]"] >= 2     # 256 threads: two per CU
