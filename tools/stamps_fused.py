@@ -14,7 +14,7 @@ cfg = bench.Cfg()
 wl = os.environ.get("WL", "vits8_224")
 C, H, W, K = bench.WORKLOADS[wl]
 B, S, n_neg = int(os.environ.get("B", 32)), 11, 5
-sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 1000 + i, dev) for i in range(4)]
+sets = [bench.make_inputs(B, C, H, W, K, S, n_neg, 1000 + i, dev) for i in range(int(os.environ.get("SETS", 4)))]
 lib = capi.load()
 nt = (2 + n_neg) * B
 names = ["start", "phase1 done", "anchor ready", "main loop end (E0)", "parked+rowmean+om (E2)", "end", "tile assigned", "own codes done",
@@ -33,7 +33,7 @@ for prec in (capi.PREC_F16X3,):
         nws = lib.stego_corr_workspace_bytes(byref(desc))
         ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
         for rep in range(6):
-            d = sets[rep % 4]
+            d = sets[rep % len(sets)]
             maps = [capi._map(d[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
             rc = lib.stego_corr_fwd(byref(desc), *[byref(m) for m in maps], d["coords1"].data_ptr(), d["coords2"].data_ptr(),
                                     d["perms"].data_ptr(), *[o.data_ptr() for o in outs], ctx.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -55,6 +55,10 @@ for prec in (capi.PREC_F16X3,):
             if sel.any():
                 print("   %-28s" % cname + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
                       (("p1 landed", 9), ("p1 stores", 10), ("p1 done", 1), ("anchor", 2), ("E0", 3), ("end", 5))))
+        if dbg & 1024:      # round 5: the direct phase 1 of the light workgroups (stamps 12-14: last gather wave stores issued / acknowledged, block published)
+            sel = slot < 4
+            print("   light slots, direct phase 1: " + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
+                  (("wave 11 enters", 11), ("wave 11 taps", 8), ("w11 landed", 9), ("w11 first rows stored", 15), ("w11 all stores issued", 12), ("w11 acked", 13), ("published", 14), ("wave 0 stores issued", 10), ("wave 0 done", 1))))
         if dbg & 1024:      # diagnostic: the gathered tiles' phase 1 in detail (stamps 12-14 are phase-1 stamps in this mode)
             sel = slot >= 4
             print("   gathered slots, phase 1: " + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in

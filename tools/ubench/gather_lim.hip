@@ -37,6 +37,8 @@ struct GP {
     int linear;                  // 1: the same number of bytes as a linear stream
     int with_a;                  // 1: four more waves stream 16 KB per stage with LDS-DMA
     int barrier;                 // 1: one __syncthreads per stage (as the ring)
+    int pipe3;                   // 1 (round 5): three register sets, stage s + 2 issued BEFORE stage s is consumed
+    int heavy;                   // n: n extra dependent FMAs per consumed value pair (stands for the blend / split / LDS work of a commit)
 };
 
 __device__ __forceinline__ void dma_piece(const unsigned char* gsrc_lane, unsigned lds_addr)
@@ -86,13 +88,39 @@ __global__ void __launch_bounds__(768) gather_lim_kernel(GP p)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += 0.25f * g[j][0][e] + 0.5f * g[j][1][e] + 0.125f * g[j][2][e] + 0.0625f * g[j][3][e];
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.25f * g[j][0][e] + 0.5f * g[j][1][e] + 0.125f * g[j][2][e] + 0.0625f * g[j][3][e];
+                    for (int h = 0; h < p.heavy; ++h) v = __builtin_fmaf(v, 1.0001f, 0.5f);
+                    acc += v;
+                }
         };
         const int total = p.passes * NST;
         issue(ga, 0);
         issue(gb, 1);
         __syncthreads();
         t_start = __builtin_amdgcn_s_memrealtime();
+        if (p.pipe3) {
+            // three sets: after the barrier of stage s the loads of stage s + 2 go out FIRST (into the set stage s - 1 left), then stage s is consumed
+            f32x4 gc[2][4];
+            for (int s = 0; s < total; s += 3) {
+                if (BARRIER) __syncthreads();
+                issue(gc, s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(ga);
+                __builtin_amdgcn_sched_barrier(0);
+                if (BARRIER) __syncthreads();
+                issue(ga, s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(gb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (BARRIER) __syncthreads();
+                issue(gb, s + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(gc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 3 == NST) t_mid = __builtin_amdgcn_s_memrealtime();
+            }
+        } else
         for (int s = 0; s < total; s += 2) {          // (always issues: the last two land on stages 0 / 1 again and are drained below)
             if (BARRIER) __syncthreads();
             consume(ga);
@@ -247,6 +275,13 @@ int main(int argc, char** argv)
         p.with_a = 0; p.barrier = 0;
         run("gather_no_barrier", p);
         p.barrier = 1;
+        // round 5: the commit's work between barrier and issue (heavy), and the issue moved in front of it (pipe3)
+        p.heavy = 12; run("gather_heavy_commit", p);
+        p.pipe3 = 1; run("gather_heavy_commit_pipe3", p);
+        p.with_a = 1; run("gather_heavy_commit_pipe3_plus_anchor", p);
+        p.pipe3 = 0; run("gather_heavy_commit_plus_anchor", p);
+        p.with_a = 0; p.heavy = 0; p.pipe3 = 1; run("gather_pipe3", p);
+        p.pipe3 = 0;
     }
     return 0;
 }
