@@ -56,18 +56,6 @@
 #ifndef STEGO_FUSED_PART
 #define STEGO_FUSED_PART 0
 #endif
-#ifndef STEGO_G3
-#define STEGO_G3 0
-#endif
-#ifndef STEGO_BUFLOAD
-#define STEGO_BUFLOAD 0
-#endif
-#ifndef STEGO_P1D
-#define STEGO_P1D 0      // round 5: phase 1 of the light workgroups without the staging area (see p1_rows_direct)
-#endif
-#ifndef STEGO_ABL
-#define STEGO_ABL 0      // timing ablations of the ring loop (WRONG results): 1 no MFMAs, 2 no fragment reads either, 4 no commit, 8 no gathers, 16 no A-side DMA
-#endif
 
 namespace stego {
 
@@ -276,16 +264,6 @@ __device__ __forceinline__ float half_wave_sum(float v, bool butterfly)
     return v + __shfl_xor(v, 16, 64);                 // the other row of the half-wave
 }
 
-// The normalised values as opaque registers: split_f16_pair subtracts the fp16 rounding of x from x, and with x = v * inv in sight the
-// compiler contracts that subtraction into an fma in one inlined copy of this code and not in another (found by the bitwise test of the
-// fallback paths: lo halves one unit apart) - every statement of phase 1 must give the same bytes.
-__device__ __forceinline__ f32x4 pinned(const f32x4 v)
-{
-    float a = v[0], b = v[1], c = v[2], d = v[3];
-    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    return f32x4{a, b, c, d};
-}
-
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
 template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false, bool ODDK = false>
@@ -395,7 +373,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(sqrtf(ss), 1e-10f)) : 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const f32x4 vn = pinned(v[j] * inv);
+            const f32x4 vn = v[j] * inv;
             if constexpr (PREC == PREC_F32) {
                 const int c = 128 * j + 4 * hl;
                 const int u = ((c & 31) >> 2) ^ ((qq >> 1) & 7);
@@ -529,271 +507,6 @@ __device__ __forceinline__ void p1_publish(const FusedParams& prm, int xa, int f
     }
 }
 
-// ------------------------------------------------------------------------------------------ phase 1 without the staging area (round 5)
-// Stamps of round 4 (profiles/r04k_stamps_fused.txt): a light workgroup's first 48 rows have landed at 5.6 us, but its stores are issued at 17.2 and
-// its anchors are ready at 18.1 - what lies between is a SECOND load round trip (the 16 rows the registers of twelve waves cannot hold beside the
-// first 48) and the chain stage in LDS -> team barrier -> copy out -> acknowledge -> team barrier -> publish.  The store micro-benchmark of this
-// round (tools/ubench/wt_store.hip, profiles/r05a_ubench_wt_store.txt) says that the reason for staging no longer holds: 16-byte write-through stores
-// straight from the registers, four lanes per 64-byte row piece, leave a compute unit as fast as contiguous runs from LDS (120 KB issued in 1.6 us,
-// acknowledged at 2.0 us; 3.1 / 3.9 us beside a cold stream).  So:
-//   * every wave stores its rows itself, straight into the ring-format operand images (same bytes, same addresses as the copy out wrote);
-//   * the taps of the 16 extra rows do not wait for registers: the gather waves fetch them with LDS-DMA into the (idle) ring right behind
-//     their register loads - ONE round trip for all 64 rows - and blend them from LDS when the first rows are done;
-//   * no team barrier: a wave counts itself done (LDS counter) when its own stores are acknowledged; the last one publishes the rows.
-// The arithmetic is p1_sample_rows' statement by statement: the operand bytes do not depend on which path produced them (the give-up path of a
-// tile may race a late owner with identical bytes).
-constexpr int P1D_WAVE_AREA = 16384;             // landing area of one gather wave: [2 rows][4 taps][C floats] (12 KB at C = 384) ...
-constexpr int P1D_CODE_OFF = 12288;              // ... + the code taps [2 rows][4 taps][128 floats]
-
-__device__ __forceinline__ void dma_b128(const void* gsrc_lane, unsigned lds_addr)        // 64 lanes x 16 B -> LDS [lds_addr, + 1 KiB)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void dma_b32(const void* gsrc_lane, unsigned lds_addr)         // 64 lanes x 4 B -> LDS [lds_addr, + 256 B)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
-}
-
-// The taps of this wave's two extra rows (flat indices first, first + 1 of the list "anchors xa, xa + 8, ..") by LDS-DMA into its landing area.
-// cxy: the two rows' coordinates (loaded by the caller together with everything else).  C = 384 (96 16-byte units per tap).
-template <int NKCT>
-__device__ __forceinline__ void p1_dma_taps(const FusedParams& prm, int xa, int first, int end, const f32x2 (&cxy)[2], int lane, unsigned lds_area)
-{
-    const MapV mf = prm.feats, mc = prm.code;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int idx = first + r;
-        const int ba = min(xa + 8 * (idx >> 7), prm.B - 1), q = idx & (TP - 1);
-        int4 yx;
-        float4 w;
-        point_taps(prm, cxy[r], idx < end ? q : TP, yx, w);
-        const int4 of = taps_to_offsets(yx, mf.sh, mf.sw);
-        const int4 oc = taps_to_offsets(yx, mc.sh, mc.sw);
-        const float* fimg = mf.p + (long long)ba * mf.sn;
-        const float* cimg = mc.p + (long long)ba * mc.sn;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {                         // 6 x 64 units = 4 taps x 96 units
-            const int v = 64 * i + lane, tap = v / 96, cu = v - 96 * tap;
-            const int o = tap == 0 ? of.x : tap == 1 ? of.y : tap == 2 ? of.z : of.w;
-            dma_b128(fimg + o + 4 * cu, lds_area + (6 * r + i) * 1024);
-        }
-#pragma unroll
-        for (int tq = 0; tq < 4; ++tq) {
-            const int o = tq == 0 ? oc.x : tq == 1 ? oc.y : tq == 2 ? oc.z : oc.w;
-#pragma unroll
-            for (int i2 = 0; i2 < (NKCT > 2 ? 2 : 1); ++i2) {  // K <= 64: one instruction per tap, else two
-                const int ch = 64 * i2 + lane;
-                dma_b32(cimg + o + (ch < prm.K ? ch : 0), lds_area + P1D_CODE_OFF + (r * 4 + tq) * 512 + i2 * 256);
-            }
-        }
-    }
-}
-
-// Phase-1 PREFETCH by the workgroups that wait (round 5).  A light compute unit pulls 580 KB of taps that nobody has read before, and its
-// landing time (13 us for its last wave, stamps r5_10) is what a single compute unit gets out of a memory ~2 us away - 60 GB/s - not what the
-// memory can deliver: 64 units x 60 GB/s is half of the HBM rate, while the 192 units with a gathered tile have nothing in their memory
-// pipelines before their tile is known (~5 us).  Their MFMA waves touch the same lines - one lane per 128-byte line of a point's four taps,
-// 4-byte LDS-DMA loads into a dummy word each: no registers, nothing to wait for - so that the XCD's L2 holds (or is already fetching) them
-// when the light workgroup of the same XCD asks.  Rows [beg, end) of the list "anchors xa, xa + 8, ..", one row per instruction.
-__device__ __forceinline__ void p1_prefetch_rows(const FusedParams& prm, int xa, int beg, int end, int lane, unsigned lds_dummy)
-{
-    const MapV mf = prm.feats, mc = prm.code;
-    const int tap = lane / 15, line = lane - 15 * tap;              // 4 taps x (12 feature lines + 3 code lines); lanes 60..63 repeat tap 3
-    const int tq = tap > 3 ? 3 : tap;
-    constexpr int NR = 6;                                           // rows per call (all coordinate loads fly together: one round trip)
-    for (int i0 = beg; i0 < end; i0 += NR) {
-        f32x2 cxy[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int idx = min(i0 + i, end - 1);
-            const int ba = min(xa + 8 * (idx >> 7), prm.B - 1), q = min(idx & (TP - 1), prm.P - 1);
-            cxy[i] = *reinterpret_cast<const f32x2*>(prm.coords1 + (size_t)ba * prm.P * 2 + coord_index(prm, q));
-        }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int idx = i0 + i;
-            const int ba = min(xa + 8 * (idx >> 7), prm.B - 1), q = idx & (TP - 1);
-            if (idx >= end || q >= prm.P) continue;                  // (wave-uniform)
-            int4 yx;
-            float4 w;
-            make_taps(cxy[i][0], cxy[i][1], prm.H, prm.W, yx, w);
-            const int t = tq == 0 ? yx.x : tq == 1 ? yx.y : tq == 2 ? yx.z : yx.w;
-            const int ty = t >> 16, tx = t & 0xffff;
-            const float* src = line < 12 ? mf.p + (long long)ba * mf.sn + (ty * mf.sh + tx * mf.sw + 32 * line)
-                                         : mc.p + (long long)ba * mc.sn + (ty * mc.sh + tx * mc.sw + min(32 * (line - 12), prm.K - 1));
-            dma_b32(src, lds_dummy);
-        }
-    }
-}
-
-// Rows [lr0, lr0 + 2 G) of the block [blk0, end): sampled, normalised, split and stored straight into the operand images / the context.
-// FROM_LDS: G = 1, the taps of row hw wait in this wave's landing area.  mid(): called once, after this function's own loads have been issued.
-template <int NJ, int PREC, int NKCT, int G, bool FROM_LDS, typename Mid>
-__device__ __forceinline__ void p1_rows_direct(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane, const unsigned char* lds_taps,
-                                               const f32x2 (&cxy_in)[G] /* the rows' coordinates: loaded by the caller, see the kernel */,
-                                               __amdgpu_buffer_rsrc_t fs_rsrc, __amdgpu_buffer_rsrc_t csf_rsrc, unsigned long long* tsd, Mid&& mid)
-{
-    static_assert(NJ == 3, "C = 384");
-    static_assert(!FROM_LDS || G == 1, "one row per half-wave from LDS");
-    constexpr int NCH2 = 4 * NJ;
-    const int hl = lane & 31, hw = lane >> 5;
-    const bool bfly = false;
-    const MapV mf = prm.feats, mc = prm.code;
-    int4 yx[G];
-    float4 w[G];
-    int ba[G], q[G];
-    bool act[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int idx = blk0 + lr0 + 2 * g + hw;
-        act[g] = idx < end;
-        ba[g] = min(xa + 8 * (idx >> 7), prm.B - 1);
-        q[g] = idx & (TP - 1);
-        point_taps(prm, cxy_in[g], act[g] ? q[g] : TP, yx[g], w[g]);
-        if (act[g] && hl == 0) {                                  // tap table of the saved context (backward only)
-            prm.tapyx[(size_t)ba[g] * TP + q[g]] = yx[g];
-            prm.tapw[(size_t)ba[g] * TP + q[g]] = w[g];
-        }
-    }
-    if (tsd) tsd[0] = __builtin_amdgcn_s_memrealtime();
-    f32x4 t[G][NJ][4];
-    CodeTaps ct[G];
-    const int c1 = 64 + hl < prm.K ? 64 + hl : 0;
-    const int c2 = 96 + hl < prm.K ? 96 + hl : 0;
-    const int c0 = 2 * hl < prm.K ? 2 * hl : 0;
-    if constexpr (!FROM_LDS) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int4 of = taps_to_offsets(yx[g], mf.sh, mf.sw);
-            const char* fb = reinterpret_cast<const char*>(mf.p + (long long)ba[g] * mf.sn);
-            const f32x4* p0 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.x + 4 * hl) * 4));
-            const f32x4* p1 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.y + 4 * hl) * 4));
-            const f32x4* p2 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.z + 4 * hl) * 4));
-            const f32x4* p3 = reinterpret_cast<const f32x4*>(fb + (unsigned)((of.w + 4 * hl) * 4));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { t[g][j][0] = p0[32 * j]; t[g][j][1] = p1[32 * j]; t[g][j][2] = p2[32 * j]; t[g][j][3] = p3[32 * j]; }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int4 oc = taps_to_offsets(yx[g], mc.sh, mc.sw);
-            const float* cimg = mc.p + (long long)ba[g] * mc.sn;
-            ct[g].a[0] = *reinterpret_cast<const f32x2*>(cimg + oc.x + c0);
-            ct[g].a[1] = *reinterpret_cast<const f32x2*>(cimg + oc.y + c0);
-            ct[g].a[2] = *reinterpret_cast<const f32x2*>(cimg + oc.z + c0);
-            ct[g].a[3] = *reinterpret_cast<const f32x2*>(cimg + oc.w + c0);
-            if constexpr (NKCT > 2) { ct[g].b[0] = cimg[oc.x + c1]; ct[g].b[1] = cimg[oc.y + c1]; ct[g].b[2] = cimg[oc.z + c1]; ct[g].b[3] = cimg[oc.w + c1]; }
-            else { ct[g].b[0] = ct[g].b[1] = ct[g].b[2] = ct[g].b[3] = 0.f; }
-            if constexpr (NKCT > 3) { ct[g].c[0] = cimg[oc.x + c2]; ct[g].c[1] = cimg[oc.y + c2]; ct[g].c[2] = cimg[oc.z + c2]; ct[g].c[3] = cimg[oc.w + c2]; }
-            else { ct[g].c[0] = ct[g].c[1] = ct[g].c[2] = ct[g].c[3] = 0.f; }
-        }
-    }
-    mid();
-    if constexpr (!FROM_LDS) {
-        // LDS-DMA and register loads of one wave do not complete in order with respect to each other: nothing that was loaded is
-        // touched before everything has landed, and the compiler may not move a consumer above this wait.  (The rows from LDS follow a call
-        // of this kind by the same wave: their taps have landed, and a second wait would only sit out the first rows' store acknowledgements.)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (tsd) tsd[1] = __builtin_amdgcn_s_memrealtime();
-    if constexpr (FROM_LDS) {
-        const unsigned char* fr = lds_taps + hw * (4 * NJ * 512);             // [tap][C floats] of row hw
-        const unsigned char* cr = lds_taps + P1D_CODE_OFF + hw * (4 * 512);  // [tap][128 floats]
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t[0][j][k] = *reinterpret_cast<const f32x4*>(fr + k * (NJ * 512) + (32 * j + hl) * 16);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ct[0].a[k] = *reinterpret_cast<const f32x2*>(cr + k * 512 + 4 * c0);
-            ct[0].b[k] = NKCT > 2 ? *reinterpret_cast<const float*>(cr + k * 512 + 4 * c1) : 0.f;
-            ct[0].c[k] = NKCT > 3 ? *reinterpret_cast<const float*>(cr + k * 512 + 4 * c2) : 0.f;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        // ---- features (p1_sample_rows' feat_part; the store goes to the operand image instead of the staging area)
-        const int qq = q[g];
-        const bool valid = act[g] && qq < prm.P;
-        const float4 wg = w[g];
-        f32x4 v[NJ];
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = blend4(wg, t[g][j][0][e], t[g][j][1][e], t[g][j][2][e], t[g][j][3][e]);
-                v[j][e] = x;
-                ss = __builtin_fmaf(x, x, ss);
-            }
-        ss = half_wave_sum(ss, bfly);
-        const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(sqrtf(ss), 1e-10f)) : 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const f32x4 vn = pinned(v[j] * inv);
-            if constexpr (PREC == PREC_F32) {
-                const int c = 128 * j + 4 * hl;
-                const int u = ((c & 31) >> 2) ^ ((qq >> 1) & 7);
-                const unsigned off = (unsigned)(((size_t)ba[g] * NCH2 + (c >> 5)) * RS_SIDE + qq * 128 + u * 16);
-                if (act[g]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vn), fs_rsrc, off, 0, 16);
-            } else {
-                unsigned h0, l0, h1, l1;
-                split_f16_pair(vn[0], vn[1], h0, l0);
-                split_f16_pair(vn[2], vn[3], h1, l1);
-                const bool odd = hl & 1;                          // even lanes collect the hi halves of a lane pair, odd the lo
-                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? h0 : l0), 0xB1, 0xF, 0xF, true);
-                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? h1 : l1), 0xB1, 0xF, 0xF, true);
-                const u32x4 d = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
-                const int c = 128 * j + 4 * (hl & ~1);
-                const int u = ((c & 31) >> 3) ^ ((qq >> 2) & 3);
-                const unsigned off = (unsigned)(((size_t)ba[g] * NCH2 + (c >> 5)) * RS_SIDE + (odd ? 8192 : 0) + qq * 64 + u * 16);
-                if (act[g]) __builtin_amdgcn_raw_buffer_store_b128(d, fs_rsrc, off, 0, 16);
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        // ---- codes (p1_sample_rows' code_part)
-        const int qq = q[g];
-        const bool valid = act[g] && qq < prm.P;
-        const float4 wg = w[g];
-        f32x2 r0 = f32x2{blend4(wg, ct[g].a[0][0], ct[g].a[1][0], ct[g].a[2][0], ct[g].a[3][0]),
-                         blend4(wg, ct[g].a[0][1], ct[g].a[1][1], ct[g].a[2][1], ct[g].a[3][1])};
-        float r1 = blend4(wg, ct[g].b[0], ct[g].b[1], ct[g].b[2], ct[g].b[3]);
-        if (2 * hl >= prm.K) r0 = f32x2{0.f, 0.f};
-        float r2 = blend4(wg, ct[g].c[0], ct[g].c[1], ct[g].c[2], ct[g].c[3]);
-        if (64 + hl >= prm.K) r1 = 0.f;
-        if (96 + hl >= prm.K) r2 = 0.f;
-        float cs2 = __builtin_fmaf(r2, r2, __builtin_fmaf(r1, r1, __builtin_fmaf(r0[1], r0[1], r0[0] * r0[0])));
-        cs2 = half_wave_sum(cs2, bfly);
-        const float nr = valid ? sqrtf(cs2) : 0.f;
-        const float cinv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
-        r0 = r0 * cinv;
-        r1 = r1 * cinv;
-        r2 = r2 * cinv;
-        const int kall = prm.NKC * prm.kper;
-        auto cf_off = [&](int k) {
-            const int sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
-            return (unsigned)(((size_t)ba[g] * prm.NKC + sc) * RS_SIDE + qq * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4);
-        };
-        float* cx_row = prm.cs + ((size_t)ba[g] * TP + qq) * prm.LDK;          // context row: straight to memory (nobody reads it in this launch)
-        if (act[g]) {
-            if (2 * hl < kall) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r0), csf_rsrc, cf_off(2 * hl), 0, 16);
-            if (64 + hl < kall) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r1), csf_rsrc, cf_off(64 + hl), 0, 16);
-            if (96 + hl < kall) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r2), csf_rsrc, cf_off(96 + hl), 0, 16);
-            if (2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(cx_row + 2 * hl) = r0;
-            if (64 + hl < prm.KQ) cx_row[64 + hl] = r1;
-            if (96 + hl < prm.KQ) cx_row[96 + hl] = r2;
-            if (hl == 0) prm.nrm[(size_t)ba[g] * TP + qq] = nr;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ ring: MFMA side
 // LDS-DMA of one KiB from inline asm: the compiler neither counts it (no vmcnt(0) in front of the next ds_read or
 // barrier) nor reorders it; the waits are the explicit counted s_waitcnt below.  M0 = LDS byte address of the piece.
@@ -827,9 +540,6 @@ __device__ __forceinline__ void mma_stage_h(const unsigned char* __restrict__ As
 {
     const int r = lane & 31, half = lane >> 5;
     const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb0 = 64 * wc + r, rb1 = rb0 + 32;
-#if STEGO_ABL & 2
-    return;
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int u = 2 * ks + half;
@@ -837,10 +547,6 @@ __device__ __forceinline__ void mma_stage_h(const unsigned char* __restrict__ As
         const f16x8 ah1 = *reinterpret_cast<const f16x8*>(As + swz_h(ra1, u)), al1 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra1, u));
         const f16x8 bh0 = *reinterpret_cast<const f16x8*>(Bs + swz_h(rb0, u)), bl0 = *reinterpret_cast<const f16x8*>(Bs + 8192 + swz_h(rb0, u));
         const f16x8 bh1 = *reinterpret_cast<const f16x8*>(Bs + swz_h(rb1, u)), bl1 = *reinterpret_cast<const f16x8*>(Bs + 8192 + swz_h(rb1, u));
-#if STEGO_ABL & 1
-        asm volatile("" :: "v"(ah0), "v"(al0), "v"(ah1), "v"(al1), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));
-        continue;
-#endif
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
@@ -1102,6 +808,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
 
     // the gather waves that wait for the tile (5 .. 11) pull coords2 into this CU's L1 meanwhile: the tap tables are then built from
     // L1 hits instead of a cold round trip (the gather stream - the critical path - starts that much earlier: -1.0 us same box, r04d)
+    if (!helper && wave8 >= 5) {
+        const int idx = 32 * ((wave8 - 5) * 64 + lane);
+        if (idx < B * P * 2) { const float x = prm.coords2[idx]; asm volatile("" :: "v"(x)); }
+    }
     // ---- phase 1 (the MFMA team, 4 waves): my share of the anchor sets of my XCD, 2 G points per wave and pass.  The team
     // syncs through an LDS counter, not s_barrier: the gather team is not part of it - it works out the tile, builds its tap
     // table and fills the B sides of the first four ring slots meanwhile (none of which needs an anchor).
@@ -1143,56 +853,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             p1end = capL + (int)((long long)(R - capL) * (hr + 1) / n_heavy);
         }
     }
-    // the gather waves that wait for the tile (5 .. 11) pull coords2 into this CU's L1 meanwhile: the tap tables are then built from
-    // L1 hits instead of a cold round trip (the gather stream - the critical path - starts that much earlier: -1.0 us same box, r04d).
-    // (Not in a light workgroup: its gather team streams nothing, and the wait for this load kept its phase-1 loads 3 us behind the MFMA team's.)
-    if (!helper && wave8 >= 5 && !(STEGO_P1D != 0 && p1_is_light)) {
-        const int idx = 32 * ((wave8 - 5) * 64 + lane);
-        if (idx < B * P * 2) { const float x = prm.coords2[idx]; asm volatile("" :: "v"(x)); }
-    }
-    // (round 5) the light workgroups of the BASELINE shape (C = 384, even K) store straight from the registers, see p1_rows_direct
-    constexpr bool P1_DIRECT = STEGO_P1D != 0 && NJ == 3 && !ODDK;
-    if (P1_DIRECT && p1_here && p1_is_light) {
-        if constexpr (P1_DIRECT) {
-            __builtin_amdgcn_s_setprio(3);
-            if ((prm.debug & 1024) && (prm.debug & 256) && !helper && tid == FUSED_THREADS - 64) ts[11] = __builtin_amdgcn_s_memrealtime();
-            const int lr0 = 4 * wave8;                                   // chunk 1: rows lr0 .. lr0 + 3 of my block (two per half-wave)
-            const int lr1 = 48 + 2 * (wave8 - 4);                        // chunk 2 (gather waves): rows lr1, lr1 + 1 - their taps by LDS-DMA
-            const bool c2 = !mfma_team && p1beg + lr1 < p1end;
-            // Every wave's coordinate loads go out FIRST, and nobody's taps before all of them are in the queue (the barrier): the compute unit's
-            // memory pipeline is in order across waves - a wave that reached its 8-byte coordinate loads 0.3 us after the others had them queued
-            // behind 400 KB of the others' taps, built its own taps at 8.7 us instead of 2.3 and had its rows landed at 12.8 (stamps, r5_9).
-            auto coords_of = [&](int idx) {
-                const int ba = min(p1x + 8 * (idx >> 7), B - 1);
-                return *reinterpret_cast<const f32x2*>(prm.coords1 + (size_t)ba * P * 2 + coord_index(prm, idx & (TP - 1)));
-            };
-            const int hw_ = lane >> 5;
-            f32x2 cxy1[2] = {coords_of(p1beg + lr0 + hw_), coords_of(p1beg + lr0 + 2 + hw_)};
-            f32x2 cxy2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-            if (c2) { cxy2[0] = coords_of(p1beg + lr1); cxy2[1] = coords_of(p1beg + lr1 + 1); }
-            __builtin_amdgcn_s_barrier();
-            const f32x2 cxy2h[1] = {hw_ ? cxy2[1] : cxy2[0]};
-            const unsigned area = __builtin_amdgcn_readfirstlane(lds_address(ring) + (wave8 >= 4 ? wave8 - 4 : 0) * P1D_WAVE_AREA);
-            auto mid = [&]() { if (c2) p1_dma_taps<NKCT>(prm, p1x, p1beg + lr1, p1end, cxy2, lane, area); };
-            auto nothing = []() {};
-            const bool wstamp = (prm.debug & 1024) && (prm.debug & 256) && !helper && tid == FUSED_THREADS - 64;     // (diagnostic: the last gather wave)
-            unsigned long long* tsd = (prm.debug & 1024) ? (wstamp ? ts + 8 : nullptr) : (stamp_on && mfma_team) ? ts + 8 : nullptr;
-            if (p1beg + lr0 < p1end) p1_rows_direct<NJ, PREC, NKCT, 2, false>(prm, p1x, p1beg, p1end, lr0, lane, nullptr, cxy1, fs_rsrc, csf_rsrc, tsd, mid);
-            if (wstamp) ts[15] = __builtin_amdgcn_s_memrealtime();
-            if (c2) p1_rows_direct<NJ, PREC, NKCT, 1, true>(prm, p1x, p1beg, p1end, lr1, lane, ring + (wave8 - 4) * P1D_WAVE_AREA, cxy2h, fs_rsrc, csf_rsrc, nullptr, nothing);
-            if (stamp_on) ts[10] = __builtin_amdgcn_s_memrealtime();
-            if (wstamp) ts[12] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have landed
-            if (wstamp) ts[13] = __builtin_amdgcn_s_memrealtime();
-            if (lane == 0) {
-                // the LAST wave to get here publishes the block (everybody's stores were acknowledged before they counted themselves)
-                const unsigned done = __hip_atomic_fetch_add(team_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (done == FUSED_WAVES - 1 && p1end > p1beg) p1_publish(prm, p1x, p1beg, p1end - p1beg);
-                if ((prm.debug & 1024) && (prm.debug & 256) && !helper && done == FUSED_WAVES - 1) ts[14] = __builtin_amdgcn_s_memrealtime();
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-    } else if (p1_here && p1_is_light) {
+    if (p1_here && p1_is_light) {
         // ---- a light workgroup: every wave samples 2 G rows (the gather waves 2 more), all twelve copy out, one lane publishes
         const int lr0 = mfma_team ? 2 * LYL::G * wave : LYL::MROWS + 2 * LYL::G * (wave8 - 4);
         __builtin_amdgcn_s_setprio(3);
@@ -1252,16 +913,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             team_arrive(team_cnt, lane);
         }
     }
-#if STEGO_P1D >= 2
-    if (P1_DIRECT && prm.p1_light && p1_here && !p1_is_light && mfma_team) {
-        // my share of the XCD's anchor rows, a quarter per wave (see p1_prefetch_rows); the dummy words: the A side of ring slot 3
-        const int tile_slots = (n_tiles - p1x + 7) >> 3;
-        const int n_light = p1nb + (p1nslot - tile_slots), n_heavy = p1nslot - n_light, hr = p1r - p1nb;
-        const int R = (int)p1L;
-        const int b0 = (int)((long long)R * (4 * hr + wave) / (4 * n_heavy)), b1 = (int)((long long)R * (4 * hr + wave + 1) / (4 * n_heavy));
-        p1_prefetch_rows(prm, p1x, b0, b1, lane, __builtin_amdgcn_readfirstlane(lds_address(ring) + 3 * RS_STAGE + wave * 256));
-    }
-#endif
     if (stamp_on) ts[1] = __builtin_amdgcn_s_memrealtime();
     if (helper) {
         // a workgroup without a tile (the CUs the tiles leave free): phase 1 was all; it still takes a ticket, because the
@@ -1349,14 +1000,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         // stores and counter updates they were waiting for (phase 1 took 17-33 us instead of 9).  Wave 0 then issues the
         // first three stages alone; the other waves only need the anchor after the barrier wave 0 arrives at.
         if (wave == 0) {
-            if (P1_DIRECT && p1_here && p1_is_light) {
-                // (a light workgroup with a tile: its gather waves may still be blending taps out of the ring - my LDS-DMA below lands there)
-                while (__hip_atomic_load(team_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)FUSED_WAVES) __builtin_amdgcn_s_sleep(1);
-            }
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool ready = false;
             for (;;) {
-                if (prm.debug & 8192) { ready = true; break; }     // (timing experiment: the operand images of the PREVIOUS launch - right only when the inputs repeat)
                 const unsigned c = __hip_atomic_load(prm.anchor_cnt + (size_t)sA * ANCHOR_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_readfirstlane(c) >= (unsigned)TP) { ready = true; break; }
                 if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > ((prm.debug & 64) ? 100 : prm.timeout_ticks)) break;
@@ -1397,7 +1043,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             TL(n, 1);
             ring_barrier();                          // B(n): stage n complete in LDS; everyone is done with stage n - 1
             TL(n, 2);
-            if (n + 3 < NT && !((STEGO_ABL & 16) && n >= NKC)) {
+            if (n + 3 < NT) {
                 const unsigned char* s3 = stage_src(n + 3);
                 const unsigned dst = ring_addr + ((n + 3) & (RS_NS - 1)) * RS_STAGE;
 #pragma unroll
@@ -1516,13 +1162,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 }
             }
         };
-#if STEGO_BUFLOAD
-        // buffer loads: resource in scalar registers, the stage as the scalar offset, ONE 32-bit lane offset per tap - the compiler cannot turn
-        // them into eight 64-bit lane pointers (16 registers, which it then spilled around the unrolled ends of the stream: a scratch reload is a
-        // vmcnt(0) drain of the whole gather stream)
+        // Buffer loads (round 5): resource in scalar registers, the stage as the scalar offset, ONE 32-bit lane offset per tap.  With plain
+        // pointers the compiler is free to turn the eight taps into eight 64-bit lane pointers - 16 registers - and did so as soon as the
+        // stream was rearranged, spilling them around the unrolled ends of the stream (a scratch reload there is a vmcnt(0) drain of the
+        // whole gather stream: 51 -> 67 us, profiles/r05d_experiments.txt); as the kernel stands: 24 -> 20 spilled registers, same time.
         const __amdgpu_buffer_rsrc_t imgB_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(imgB), 0, 0x7fffffff, 0x00020000);
         auto issue_feat = [&](GSet& g, int f) {
-            if ((STEGO_ABL & 8) && f >= 1) return;
             const int so = __builtin_amdgcn_readfirstlane(f * KC2 * 4);
 #pragma unroll
             for (int j = 0; j < GI; ++j)
@@ -1530,16 +1175,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                 for (int tq = 0; tq < 4; ++tq)
                     g.tv[j][tq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(imgB_rsrc, (int)fo[j][tq], so, 0));
         };
-#else
-        auto issue_feat = [&](GSet& g, int f) {
-            if ((STEGO_ABL & 8) && f >= 1) return;
-            const char* cb = reinterpret_cast<const char*>(imgB + f * KC2);       // wave-uniform
-#pragma unroll
-            for (int j = 0; j < GI; ++j)
-#pragma unroll
-                for (int tq = 0; tq < 4; ++tq) g.tv[j][tq] = *reinterpret_cast<const f32x4*>(cb + fo[j][tq]);
-        };
-#endif
         auto blend = [&](const GSet& g, int j, float (&v)[4]) {
             const float4 w = tw[j];
 #pragma unroll
@@ -1551,13 +1186,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         // column scale divides the prescale out again; fp16 leaves 2^15 of headroom for channels beyond those stages).
         auto commit_feat = [&](const GSet& g, int m, bool decide) {
             unsigned char* dst = ring + (m & (RS_NS - 1)) * RS_STAGE + RS_SIDE;
-            if ((STEGO_ABL & 4) && m - NKC >= 2) {
-#pragma unroll
-                for (int j = 0; j < GI; ++j)
-#pragma unroll
-                    for (int tq = 0; tq < 4; ++tq) asm volatile("" :: "v"(g.tv[j][tq]));
-                return;
-            }
 #pragma unroll
             for (int j = 0; j < GI; ++j) {
                 const int q = GP * j + prow;
@@ -1636,71 +1264,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-#if STEGO_G3
-        // Round 5: THREE register sets, and the loads of stage n + 4 leave right after B(n), BEFORE stage n + 2 is committed: with two sets
-        // the texture path sat idle from the barrier to the end of the commit (blend + split + LDS stores, 0.3-0.8 us of every 1.2 us stage,
-        // profiles/r04a_timeline_fused.txt) and every load had one stage less to land.  Stage k lives in set k % 3: at B(n) set (n + 2) % 3
-        // holds stage n + 2 (issued after B(n - 2), landed), set n % 3 stage n + 3 (in flight), set (n + 1) % 3 is free (committed after B(n - 1)).
-        GSet gs[3];
-        auto issue = [&](GSet& g, int m) {
-            if (m < NKC) issue_code(g, m);
-            else issue_feat(g, m - NKC);
-        };
-        auto commit = [&](GSet& g, int m) {
-            if (m < NKC) { commit_code(g, m); if (m == NKC - 1) finish_codes(); }
-            else commit_feat(g, m, m - NKC < 2);
-        };
-        static_assert(NT >= 8, "the static head covers the code chunks and the first feature stages");
-        const bool gstamp = (prm.debug & 256) && tid == NTHREADS;
-        if (gstamp) ts[15] = __builtin_amdgcn_s_memrealtime();
-        // Head (static): the B sides of stages 0..3 fill the four (still free) ring slots before the first barrier
-        issue(gs[0], 0);
-        issue(gs[1], 1);
-        issue(gs[2], 2);
-        commit(gs[0], 0);
-        issue(gs[0], 3);
-        commit(gs[1], 1);
-#if STEGO_G3 >= 2
-        issue(gs[1], 4);                             // (variant: stages 4 and 5 already fly while the tile waits for its anchor)
-#endif
-        commit(gs[2], 2);
-#if STEGO_G3 >= 2
-        issue(gs[2], 5);
-#endif
-        commit(gs[0], 3);
-        if (gstamp) ts[11] = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            ring_barrier();                          // B(n)
-            if (STEGO_G3 < 2 || n >= 2) issue(gs[(n + 1) % 3], n + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            if (n >= 2) commit(gs[(n + 2) % 3], n + 2);
-        }
-        constexpr int IT3 = (NT - 8) / 3;            // iterations of three stages in which every stage issues and commits
-        constexpr int TAIL0 = 4 + 3 * IT3;
-#pragma unroll 1
-        for (int n = 4; n < TAIL0; n += 3) {         // n = 1 (mod 3): issue sets 2, 0, 1 - commit sets 0, 1, 2
-            ring_barrier();                          // B(n)
-            issue_feat(gs[2], n + 4 - NKC);
-            __builtin_amdgcn_sched_barrier(0);
-            commit_feat(gs[0], n + 2, false);
-            ring_barrier();                          // B(n + 1)
-            issue_feat(gs[0], n + 5 - NKC);
-            __builtin_amdgcn_sched_barrier(0);
-            commit_feat(gs[1], n + 3, false);
-            ring_barrier();                          // B(n + 2)
-            issue_feat(gs[1], n + 6 - NKC);
-            __builtin_amdgcn_sched_barrier(0);
-            commit_feat(gs[2], n + 4, false);
-        }
-#pragma unroll
-        for (int n = TAIL0; n < NT; ++n) {          // the last stages: nothing left to issue, then nothing left to commit
-            ring_barrier();                          // B(n)
-            if (n + 4 < NT) issue_feat(gs[(n + 1) % 3], n + 4 - NKC);
-            __builtin_amdgcn_sched_barrier(0);
-            if (n + 2 < NT) commit_feat(gs[(n + 2) % 3], n + 2, false);
-        }
-#else
         GSet ga, gb;
         // stage m of the stream (compile-time m after unrolling): a code K-chunk or a feature stage
         auto issue = [&](GSet& g, int m) {
@@ -1767,7 +1330,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
             if (n + 2 < NT) { if (n & 1) commit_feat(gb, n + 2, false); else commit_feat(ga, n + 2, false); }
             if (n + 4 < NT) { if (n & 1) issue_feat(gb, n + 4 - NKC); else issue_feat(ga, n + 4 - NKC); }
         }
-#endif
         // ---- 1 / ||b_j|| of the gathered feature side (F.normalize eps, modules.py:276); the anchor side is pre-normalised
 #pragma unroll
         for (int j = 0; j < GI; ++j) {

@@ -55,10 +55,6 @@ for prec in (capi.PREC_F16X3,):
             if sel.any():
                 print("   %-28s" % cname + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
                       (("p1 landed", 9), ("p1 stores", 10), ("p1 done", 1), ("anchor", 2), ("E0", 3), ("end", 5))))
-        if dbg & 1024:      # round 5: the direct phase 1 of the light workgroups (stamps 12-14: last gather wave stores issued / acknowledged, block published)
-            sel = slot < 4
-            print("   light slots, direct phase 1: " + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
-                  (("wave 11 enters", 11), ("wave 11 taps", 8), ("w11 landed", 9), ("w11 first rows stored", 15), ("w11 all stores issued", 12), ("w11 acked", 13), ("published", 14), ("wave 0 stores issued", 10), ("wave 0 done", 1))))
         if dbg & 1024:      # diagnostic: the gathered tiles' phase 1 in detail (stamps 12-14 are phase-1 stamps in this mode)
             sel = slot >= 4
             print("   gathered slots, phase 1: " + "  ".join("%s %.2f/%.2f" % (n, *np.percentile(rel[sel, k], [50, 100])) for n, k in
