@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level table
+HBM_ACHIEVABLE = 6.3e12    # B/s a streaming kernel reaches on this part (same guide: copy / read micro-benchmarks); reported beside the peak fraction
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-input MFMA (same table)
 MFMA_F16_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA
 
@@ -327,6 +328,8 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    last_local = [0.0]                       # this rank's own seconds of the last timed_run (before the MAX over ranks)
+
     def timed_run(precision, steps, warmup, fwd_only=args.fwd_only, collective=True, use_graph=True):
         """W untimed + K timed steps of the whole job in one precision mode; returns (seconds, launch mode, desc)."""
         collective_on = collective
@@ -461,6 +464,7 @@ def main():
         drain()
         barrier()
         dt = time.perf_counter() - t0
+        last_local[0] = dt
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -485,14 +489,15 @@ def main():
             trial = {"eager": float(tt[0]), "graph": float(tt[1])}
         mode = "graph" if trial["graph"] < trial["eager"] else "eager"
     dt, launch, desc = timed_run(args.precision, args.steps, args.warmup, use_graph=(mode == "graph"))
+    dt_local = last_local[0]
     use_graph = mode == "graph"
     alt = None
     if not args.no_alt:                     # the other arithmetic mode, shorter, for the record (all ranks take part)
         other = "f32" if args.precision == "f16x3" else "f16x3"
         steps_alt = max(20, args.steps // 4)
-        dt_alt, _, _ = timed_run(other, steps_alt, max(4, args.warmup // 4), use_graph=use_graph)
+        dt_alt, _, desc_alt = timed_run(other, steps_alt, max(4, args.warmup // 4), use_graph=use_graph)
         alt = {"precision": other, "value": world * B * steps_alt / dt_alt, "unit": "image-pairs/s",
-               "ms_per_step": dt_alt / steps_alt * 1e3, "steps": steps_alt}
+               "ms_per_step": dt_alt / steps_alt * 1e3, "steps": steps_alt, "desc": desc_alt}
 
     # ---- the forward alone (same graphs without the backward): the backward's share is the difference
     split = None
@@ -510,35 +515,39 @@ def main():
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
     roof = roof_mfma = roof_bwd = None
     fin_us = None
-    if rank == 0 and not dry:
-        ms_samp = ms_main = ms_fin = 0.0
+
+    def forward_launch_ms(desc_):
+        """(ms in front of, of, behind the main forward kernel) per launch: HIP events on the launch stream around single launches."""
+        ms = [0.0, 0.0, 0.0]
         rounds = 5
         for r in range(rounds + 1):
-            a = b = c = 0.0
+            acc = [0.0, 0.0, 0.0]
             for i in range(args.sets):
                 d = sets[i]
                 # the same host-side layout policy as the timed loop (a no-op for channels-last views): the kernels profiled
                 # are the kernels the timed steps ran
-                k0, k1, k2 = capi.corr_fwd_profile(desc, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
-                                                   as_channels_last(d["code"]), as_channels_last(d["code_pos"]),
-                                                   d["coords1"], d["coords2"], d["perms"], not args.fwd_only, 1)
-                a += k0
-                b += k1
-                c += k2
+                k = capi.corr_fwd_profile(desc_, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]),
+                                          as_channels_last(d["code"]), as_channels_last(d["code_pos"]),
+                                          d["coords1"], d["coords2"], d["perms"], not args.fwd_only, 1)
+                acc = [x + y for x, y in zip(acc, k)]
             if r > 0:
-                ms_samp += a / args.sets
-                ms_main += b / args.sets
-                ms_fin += c / args.sets
-        ms_samp /= rounds
-        ms_main /= rounds
-        ms_fin /= rounds
+                ms = [x + y / args.sets for x, y in zip(ms, acc)]
+        return [x / rounds for x in ms]
+
+    if rank == 0 and not dry:
+        ms_samp, ms_main, ms_fin = forward_launch_ms(desc)
         ab = algorithmic_bytes_fwd(B, C, H, W, K, S, n_neg)
         fl = algorithmic_flops_fwd(B, C, K, S, n_neg)
-        traffic = None
+        # HBM / fabric bytes per launch: NOT measured by this run (rocprofv3 counter passes cannot run inside the timed process) - the
+        # constant that the builder's counter passes of this kernel produced, with where it comes from
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_%s_B%d" % (args.workload, args.precision, B))
+                tj = json.load(open(tpath))
+                traffic = tj.get("%s_%s_B%d" % (args.workload, args.precision, B))
+                if traffic is not None:
+                    traffic_source = "static: profiles/traffic.json (%s) - builder-run rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE per launch; not measured in this run" % tj.get("_source", "see its _note")
             except Exception:       # noqa: BLE001
                 traffic = None
         d0 = sets[0]
@@ -551,7 +560,9 @@ def main():
             t_fwd = ms_main * 1e-3
             ach = ab / t_fwd
             roof = dict(bound="hbm", kernel="corr_fused_kernel (the whole forward, one launch)", dominant_kernel="corr_fused_kernel",
-                        achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
+                        achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                        frac_of_achievable=ach / HBM_ACHIEVABLE, achievable_peak=HBM_ACHIEVABLE / 1e9,
+                        traffic=traffic, traffic_source=traffic_source,
                         algorithmic_bytes=ab, us_per_launch={"corr_fused_kernel": ms_main * 1e3},
                         timing="HIP events on the launch stream around single launches, input sets rotated")
             roof_mfma = dict(bound="mfma", kernel="corr_fused_kernel", achieved=fl / t_fwd / 1e12, peak=peak / 1e12,
@@ -568,7 +579,8 @@ def main():
             ach = ab / t_fwd
             roof = dict(bound="hbm", kernel="forward = sample_norm_kernel + corr_tile_kernel + corr_finalize_kernel",
                         dominant_kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=ach / HBM_PEAK, traffic=traffic, algorithmic_bytes=ab, us_per_launch=kernels,
+                        frac=ach / HBM_PEAK, frac_of_achievable=ach / HBM_ACHIEVABLE, achievable_peak=HBM_ACHIEVABLE / 1e9,
+                        traffic=traffic, traffic_source=traffic_source, algorithmic_bytes=ab, us_per_launch=kernels,
                         per_kernel={"sample_norm_kernel": dict(algorithmic_bytes=ab_in, achieved_GBps=ab_in / (ms_samp * 1e-3) / 1e9,
                                                                frac=ab_in / (ms_samp * 1e-3) / HBM_PEAK),
                                     "corr_tile_kernel": dict(algorithmic_bytes=ab_out, achieved_GBps=ab_out / (ms_main * 1e-3) / 1e9,
@@ -576,6 +588,15 @@ def main():
             roof_mfma = dict(bound="mfma", kernel="corr_tile_kernel", achieved=fl / (ms_main * 1e-3) / 1e12,
                              peak=peak / 1e12, unit="TFLOP/s", frac=fl / (ms_main * 1e-3) / peak, algorithmic_flops=fl,
                              note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
+        if alt is not None and alt.get("desc") is not None:
+            # the other arithmetic mode's forward, measured the same way (the strict like-for-like number when the headline is f16x3)
+            d0a = alt.pop("desc")
+            _, ms_alt, _ = forward_launch_ms(d0a)
+            if fused and ms_alt > 0:
+                ach_alt = ab / (ms_alt * 1e-3)
+                alt["roofline"] = dict(bound="hbm", kernel="corr_fused_kernel", achieved=ach_alt / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                                       frac=ach_alt / HBM_PEAK, frac_of_achievable=ach_alt / HBM_ACHIEVABLE, algorithmic_bytes=ab,
+                                       us_per_launch={"corr_fused_kernel": ms_alt * 1e3})
         if split is not None:
             abb = algorithmic_bytes_bwd(B, K, H, W, S, n_neg)
             tb = split["backward_ms"] * 1e-3
@@ -592,6 +613,36 @@ def main():
         # after the last step's averaged all-reduce every rank holds mean(rank + 1) = (world + 1) / 2
         check = {"grad_mean_after_allreduce": float(grad_buf[0]), "expected": (world + 1) / 2.0,
                  "bucket_numel": int(grad_buf.numel())}
+    if alt is not None:
+        alt.pop("desc", None)
+    # ---- N > 1 (and --force-collective): what each rank saw, and the gradient all-reduce on its own, so that a scaling run explains itself
+    coll_stats = None
+    if dist is not None:
+        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+        per_rank[rank] = dt_local / args.steps * 1e3
+        dist.all_reduce(per_rank)
+        for _ in range(5):
+            reducer.allreduce_mean(async_op=False, single_rank_ok=True)
+        barrier()
+        n_ar = 50
+        if dry:                                  # (CPU / gloo: the protocol only - wall clock)
+            t_ar = time.perf_counter()
+        else:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for _ in range(n_ar):
+            reducer.allreduce_mean(async_op=False, single_rank_ok=True)      # (the stream waits for RCCL's stream: back-to-back collectives)
+        if dry:
+            ar_us = (time.perf_counter() - t_ar) / n_ar * 1e6
+        else:
+            ev1.record()
+            torch.cuda.synchronize()
+            ar_us = ev0.elapsed_time(ev1) / n_ar * 1e3
+        ar = torch.tensor([ar_us], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        coll_stats = {"ms_per_step_by_rank": [float(x) for x in per_rank.tolist()], "ms_per_step_rank_min": float(per_rank.min()),
+                      "ms_per_step_rank_max": float(per_rank.max()),
+                      "allreduce_us": float(ar.item()), "allreduce_what": "%d back-to-back FlatGradReducer.allreduce_mean calls of the %d-float bucket, HIP events on the compute stream (which waits for RCCL's), max over ranks" % (n_ar, grad_buf.numel())}
     if rank == 0:
         value = world * B * args.steps / dt
         rec = {
@@ -608,7 +659,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "launch": launch,
                        "launch_trial_ms_per_step": trial,
                        "input_sets_rotated": args.sets, "layout": "channels-last strided views (as DinoFeaturizer)" if args.layout == "cl" else "NCHW contiguous",
-                       "collective": ("all_reduce(%d f32 head grads)/step, FlatGradReducer.allreduce_mean(async)" % grad_buf.numel())
+                       "collective": ({"what": "all_reduce(%d f32 head grads)/step, FlatGradReducer.allreduce_mean(async)" % grad_buf.numel(),
+                                       **(coll_stats or {})})
                        if dist is not None else None,
                        "shared_device": (args.shared_device == "1" or (args.shared_device == "auto" and dist is not None)) and not dry},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,

@@ -431,6 +431,26 @@ def event_counters(desc, ws):
     return int(w[0]), int(w[1])
 
 
+def event_counters_total():
+    """Sum of event_counters() over every forward workspace this process keeps (the Python wrapper's and the C++ autograd function's):
+    (tiles that sampled their anchor themselves, old_mean rendezvous that timed out) since those workspaces were prepared.  Both are zero
+    in normal operation; non-zero = the single-launch forward keeps taking its fallback paths (device shared or partitioned without
+    cfg.shared_device / STEGO_FLAG_SHARED_DEVICE): correct, ~30 us slower per step.  A synchronisation: call it every few hundred steps."""
+    g = r = 0
+    seen = []
+    for key, ws in list(_WS_CACHE.items()):
+        seen.append((key[3], ws))
+    mod = torchglue()
+    if mod is not None and hasattr(mod, "workspaces"):
+        seen += list(mod.workspaces())
+    for dbytes, ws in seen:
+        desc = StegoCorrDesc.from_buffer_copy(dbytes)
+        a, b = event_counters(desc, ws)
+        g += a
+        r += b
+    return g, r
+
+
 def corr_fwd_launches(desc, feats, feats_pos, code, code_pos):
     """Kernel launches stego_corr_fwd_prepared needs for these maps: 1 = the fused forward, 3 = sample / tile / finalize."""
     lib = load()

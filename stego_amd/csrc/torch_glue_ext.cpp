@@ -190,6 +190,15 @@ void reset_workspaces()
     ws_pinned.clear();
 }
 
+// (descriptor bytes, workspace) of every kept forward workspace: capi.event_counters_total() reads their two event words
+std::vector<std::pair<py::bytes, at::Tensor>> workspaces()
+{
+    std::lock_guard<std::recursive_mutex> lock(ws_mutex);
+    std::vector<std::pair<py::bytes, at::Tensor>> out;
+    for (auto& e : ws_cache) out.emplace_back(py::bytes(std::get<2>(e.first)), e.second);
+    return out;
+}
+
 StegoMap as_map(const at::Tensor& t, const char* name)
 {
     TORCH_CHECK(t.scalar_type() == at::kFloat && t.dim() == 4, "expected a float32 [N,C,H,W] tensor for ", name);
@@ -437,5 +446,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return corr_loss(a, b, c, d, e, f, g, std::string(desc), mode);
     }, "ContrastiveCorrelationLoss.forward given the draws (autograd through stego_corr_bwd)");
     m.def("reset_workspaces", &reset_workspaces);
+    m.def("workspaces", &workspaces, "[(descriptor bytes, workspace tensor)] of the kept forward workspaces");
     m.def("head", &head, "DinoFeaturizer's head (dropout masks given) -> [code [B, HW, K]] or [code, feats [B, HW, C]] (want_feats)");
 }

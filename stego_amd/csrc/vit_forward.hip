@@ -36,6 +36,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 // fp16 subnormals; the power is undone in the GEMM epilogue, exact), activation panels hold 16 x the value (same reason), the softmax
 // probabilities 1024 x.
 constexpr float VIT_ASCALE = 16.f;
+// an activation beyond +-4094 would make hi = inf and lo = NaN (the fp32 torch model stays finite): the scaled value saturates at the
+// fp16 maximum instead - one v_med3_f32; no DINO checkpoint comes near it (LayerNorm bounds its outputs by sqrt(D) gamma)
+__device__ __forceinline__ float x3_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 constexpr float VIT_PSCALE = 1024.f;
 
 __device__ __forceinline__ int amax_exp(unsigned bits)       // e with amax = m * 2^e, m in [0.5, 1); 11 for an all-zero tensor (scale 1)
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256) vit_layernorm_kernel(const float* __restr
             const int n = lane + 64 * i;
             const float y = (v[i] - mean) * rstd * gamma[n] + beta[n];
             if constexpr (TO_PANEL && X3) {           // column n = 64 i + lane: k chunk 2 i + (lane >> 5), hi at lane & 31, lo 32 further
-                const float ys = y * VIT_ASCALE;
+                const float ys = x3_sat(y * VIT_ASCALE);
                 const half_t hi = (half_t)ys;
                 unsigned char* d = outp + ((size_t)(m >> 7) * (2 * ni) + 2 * i + (lane >> 5)) * VP_BYTES + (((m & 127) * VP_LD) + (lane & 31)) * 2;
                 *reinterpret_cast<half_t*>(d) = hi;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(GT_THREADS, 4) vit_gemm_kernel(const GemmParam
                                 const int lrow = 64 * (wr & 1) + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * half;
                                 const float v = acc[mi][ni][e] * osc + bias;
                                 if constexpr (EPI == EPI_GELU && X3) {
-                                    const float g = gelu(v) * VIT_ASCALE;
+                                    const float g = x3_sat(gelu(v) * VIT_ASCALE);
                                     const half_t hi = (half_t)g;
                                     T[gslot * GRP + lrow * VP_LD + r] = hi;
                                     T[gslot * GRP + lrow * VP_LD + 32 + r] = (half_t)(g - (float)hi);

@@ -72,34 +72,38 @@ def to_target_tensor(pil_label):
     return torch.as_tensor(np.array(pil_label), dtype=torch.int64).unsqueeze(0)
 
 
+def _seeded(fn, x, seed):
+    """fn(x) with python's and torch's global generators reset to `seed` first: a random transform draws the same crop / flip for an image
+    and for its label when both calls get the same seed (what reference src/data.py:388-394 does inline)."""
+    random.seed(seed)
+    torch.manual_seed(seed)
+    return fn(x)
+
+
 class CroppedDataset(Dataset):
-    """Reference src/data.py:370-400, same constructor and return values: (image, target [H,W] with -1 = unlabelled, mask)."""
+    """Reader of the pre-cropped tree `cropped/{dataset}_{crop_type}_crop_{ratio}/{img,label}/{split}/{i}.{jpg,png}` that the reference's
+    crop_datasets.py writes (format pinned by tests/golden/cropped_ref), with the reference dataset's constructor and item contract
+    (src/data.py:370-400): item i -> (image, target [H, W] int64 with -1 = unlabelled, mask = target == -1); image and label go through
+    their transforms under ONE random seed per item, drawn from numpy's global generator as the reference does (so that a run seeded
+    like the reference sees the same augmentations)."""
 
     def __init__(self, root, dataset_name, crop_type, crop_ratio, image_set, transform=to_tensor, target_transform=to_target_tensor):
         super().__init__()
-        self.dataset_name = dataset_name
-        self.split = image_set
+        self.dataset_name, self.split = dataset_name, image_set
+        self.transform, self.target_transform = transform, target_transform
         self.root = crop_dir(root, dataset_name, crop_type, crop_ratio)
-        self.transform = transform
-        self.target_transform = target_transform
-        self.img_dir = join(self.root, "img", self.split)
-        self.label_dir = join(self.root, "label", self.split)
+        self.img_dir, self.label_dir = (join(self.root, kind, image_set) for kind in ("img", "label"))
         self.num_images = len(os.listdir(self.img_dir))
-        assert self.num_images == len(os.listdir(self.label_dir))
-
-    def __getitem__(self, index):
-        image = Image.open(join(self.img_dir, "{}.jpg".format(index))).convert('RGB')
-        target = Image.open(join(self.label_dir, "{}.png".format(index)))
-        seed = np.random.randint(2147483647)            # the same random transform for image and target (data.py:388-394)
-        random.seed(seed)
-        torch.manual_seed(seed)
-        image = self.transform(image)
-        random.seed(seed)
-        torch.manual_seed(seed)
-        target = self.target_transform(target)
-        target = target - 1
-        mask = target == -1
-        return image, target.squeeze(0), mask
+        if self.num_images != len(os.listdir(self.label_dir)):
+            raise AssertionError("%s: %d images but %d labels" % (self.root, self.num_images, len(os.listdir(self.label_dir))))
 
     def __len__(self):
         return self.num_images
+
+    def __getitem__(self, index):
+        seed = int(np.random.randint(2147483647))
+        with Image.open(join(self.img_dir, "%d.jpg" % index)) as im:
+            image = _seeded(self.transform, im.convert("RGB"), seed)
+        with Image.open(join(self.label_dir, "%d.png" % index)) as lab:
+            target = _seeded(self.target_transform, lab, seed) - 1      # the tree stores label + 1: 0 on disk = unlabelled
+        return image, target.squeeze(0), target == -1

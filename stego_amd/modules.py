@@ -254,21 +254,18 @@ class _LossFamily:
         if t is None:
             if torch.cuda.is_available() and like.is_cuda and torch.cuda.is_current_stream_capturing():
                 return None                    # (no allocation + fill inside a capture: the caller takes the plain path)
-            if len(cls._const) > 256:
-                cls._const.clear()
+            # (never evicted: a cached constant may be baked into a captured graph as an upstream gradient - a training loop uses a handful)
             t = cls._const[key] = torch.full((), float(value), device=like.device, dtype=like.dtype)
         return t
 
     @classmethod
     def const3(cls, coeffs, like):
         """The coefficient vector [3] as a device tensor (cached per value triple): the upstream of the vector output."""
-        key = (coeffs, like.device)
+        key = (coeffs, like.device, like.dtype)
         t = cls._const.get(key)
         if t is None:
             if like.is_cuda and torch.cuda.is_current_stream_capturing():
                 return None
-            if len(cls._const) > 256:
-                cls._const.clear()
             t = cls._const[key] = torch.tensor(coeffs, device=like.device, dtype=like.dtype)
         return t
 
@@ -637,18 +634,19 @@ class _HelperFunction(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- the loss
-_PAIR_SET_BOUND = []
+_PAIR_SET_BOUND = {}
 
 
-def _pair_set_bound():
+def _pair_set_bound(device=None):
     """Largest batch of the single-launch forward: the tiles of one pair-set run at the same time, one per compute unit
     (fused_supported, csrc/corr_fused.hip: device_cu_count() & ~7) - 256 on a whole MI355X, fewer on a partitioned one."""
-    if not _PAIR_SET_BOUND:
-        n = 256
-        if torch.cuda.is_available():
-            n = max(8, torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count & ~7)
-        _PAIR_SET_BOUND.append(n)
-    return _PAIR_SET_BOUND[0]
+    if not torch.cuda.is_available():
+        return 256
+    idx = torch.cuda.current_device() if device is None or getattr(device, "index", None) is None else device.index
+    n = _PAIR_SET_BOUND.get(idx)
+    if n is None:       # per device: a partitioned or different device in the same process has its own compute-unit count
+        n = _PAIR_SET_BOUND[idx] = max(8, torch.cuda.get_device_properties(idx).multi_processor_count & ~7)
+    return n
 
 
 class ContrastiveCorrelationLoss(nn.Module):
@@ -694,14 +692,14 @@ class ContrastiveCorrelationLoss(nn.Module):
         return coords1, coords2
 
     @staticmethod
-    def fused_kernels_cover(B, C, K, H, W, S):
+    def fused_kernels_cover(B, C, K, H, W, S, device=None):
         """Does the hand-written loss path (stego_corr_fwd / _bwd, include/stego_corr.h "Limits of this build") take this shape?
         S * S <= 128 sample points per image; K <= 72 on any layout; 72 < K <= 128 on the single-launch forward (any parity, ViT widths,
         B and the map within its bounds).  Everything else - e.g. cfg.feature_samples = 16 - is computed by generic_forward()."""
         if S * S > 128 or K > 128 or H > 32767 or W > 32767:
             return False
         if K > 72:
-            return C in (192, 384, 768) and B <= _pair_set_bound() and H <= 256 and W <= 256
+            return C in (192, 384, 768) and B <= _pair_set_bound(device) and H <= 256 and W <= 256
         return True
 
     def generic_helper(self, f1, f2, c1, c2, shift):
@@ -773,7 +771,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         B, C, H, W = orig_feats.shape
         K = orig_code.shape[1]
         S = cfg.feature_samples
-        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, K, H, W, S):
+        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, K, H, W, S, orig_feats.device):
             return self.generic_forward(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
         n_neg = int(perms.shape[0]) if perms is not None else 0
         if perms is None:
@@ -811,7 +809,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         coords1, coords2, perms = self.draw(orig_feats, orig_salience, orig_salience_pos)
         cfg = self.cfg
         B, C, H, W = orig_feats.shape
-        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, orig_code.shape[1], H, W, cfg.feature_samples):
+        if orig_feats.is_cuda and not self.fused_kernels_cover(B, C, orig_code.shape[1], H, W, cfg.feature_samples, orig_feats.device):
             o = self.generic_forward(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms)
             neg_mean = o[4].mean() if o[4].numel() else o[0].new_zeros(())
             return torch.stack([o[0], o[2], neg_mean]), o[1], o[3], o[5]

@@ -393,6 +393,8 @@ class Trainer:
                     print("step %5d  loss %.5f  " % (step, float(history[-1])) +
                           "  ".join("%s %.5f" % (k, float(v)) for k, v in model.logged.items() if k.startswith("loss/pos") or k.startswith("loss/neg")))
                 step += 1
+                if step % self.event_check_every == 0 or step >= self.max_steps:
+                    self._check_loss_events(step)
                 if self.val_loader is not None and self.val_check_interval and step % self.val_check_interval == 0:
                     self._validate(model)
                 if step >= self.max_steps:
@@ -400,6 +402,28 @@ class Trainer:
         if self.checkpoint_path and self.rank == 0:
             model.save_checkpoint(self.checkpoint_path)
         return [float(v) for v in torch.stack(history).cpu()] if history else []
+
+    event_check_every = 200        # steps between two looks at the loss kernels' event counters (a device -> host copy of a few bytes)
+    _events_warned = False
+
+    def _check_loss_events(self, step):
+        """The single-launch forward of the correspondence loss has two bounded waits between workgroups; a launch whose workgroups are not
+        all on the device at once (another kernel holds compute units: a shared or partitioned device) gives them up and takes its fallback
+        paths - same bytes, ~30 us slower per step, and silent.  The library counts those events per workspace; said once here."""
+        if self._events_warned or self.device.type != "cuda":
+            return
+        try:
+            from . import capi
+            gave_up, repaired = capi.event_counters_total()
+        except Exception:       # noqa: BLE001 - a diagnostic must not stop a training run
+            return
+        if gave_up or repaired:
+            import warnings
+            self._events_warned = True
+            warnings.warn("correspondence loss (rank %d, step %d): %d tiles sampled their anchor themselves and %d old_mean rendezvous timed out "
+                          "since the run started - the forward's workgroups are not co-resident (device shared with other kernels, or "
+                          "partitioned?).  Results are unaffected; set cfg.shared_device = True (STEGO_FLAG_SHARED_DEVICE) when kernels "
+                          "of other streams run beside the loss." % (self.rank, step, gave_up, repaired))
 
     def _shard_loader(self, loader):
         """Data parallelism needs every rank to see its own slice: a loader without a DistributedSampler over a dataset that is

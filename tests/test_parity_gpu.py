@@ -1406,6 +1406,19 @@ def test_event_counters_report_the_give_up_and_repair_paths():
         assert (b[0] - a[0], b[1] - a[1]) == (0, n_neg * B), (a, b)
         capi.debug_set("STEGO_DEBUG", 0)
         assert run() == b
+        # what the trainer reads every few hundred steps (round 5): the sum over every kept workspace of this process - the Python wrapper's
+        # and the C++ autograd function's - and its one-time warning
+        tot = capi.event_counters_total()
+        assert tot[0] >= b[0] and tot[1] >= b[1], (tot, b)
+        import warnings
+        from stego_amd.train_segmentation import Trainer
+        tr = Trainer.__new__(Trainer)
+        tr.device, tr.rank, tr._events_warned = dev, 0, False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            tr._check_loss_events(200)
+            tr._check_loss_events(400)
+        assert len([x for x in w if "sampled their anchor themselves" in str(x.message)]) == 1 and tr._events_warned
     finally:
         capi.debug_set("STEGO_DEBUG", 0)
 

@@ -330,7 +330,10 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
     chk = rec["collective_check"]
     assert chk["grad_mean_after_allreduce"] == chk["expected"] == 1.5
     assert chk["bucket_numel"] == 384 * 70 + 70 + 384 * 384 + 384 + 384 * 70 + 70 + 70 * 27 + 27 + 27 * 70
-    assert rec["config"]["collective"].startswith("all_reduce(")
+    coll = rec["config"]["collective"]
+    assert coll["what"].startswith("all_reduce(")
+    # (round 5) a scaling run explains itself: every rank's own ms per step and the all-reduce timed on its own
+    assert len(coll["ms_per_step_by_rank"]) == 2 and coll["ms_per_step_rank_min"] <= coll["ms_per_step_rank_max"] and coll["allreduce_us"] > 0
 
 
 def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():

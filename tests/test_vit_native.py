@@ -139,6 +139,25 @@ def test_native_f16x3_is_in_the_fp32_class_at_baseline_shapes(arch, patch, size,
 
 
 @pytest.mark.gpu
+def test_native_f16x3_saturates_instead_of_overflowing():
+    """The default backbone stores 16 x the LayerNorm / GELU outputs as fp16 pairs: an activation beyond +-4094 used to become (inf, NaN)
+    and poison every token, where the fp32 torch model stays finite.  With LayerNorm gains of 1500 the outputs pass
+    4094: the scaled value now saturates at the fp16 maximum - finite features (no accuracy claim out there; real checkpoints stay far
+    inside: the golden test above asserts finiteness at DINO's own magnitudes)."""
+    torch.manual_seed(11)
+    model = dino_vit.ARCHS["vit_tiny"](patch_size=16).cuda().eval()
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+                prm.fill_(1500.0)
+    img = torch.randn(2, 3, 96, 96, device="cuda")
+    with torch.no_grad():
+        ref = model.get_intermediate_feat(img, n=1)[0][0]
+    got = vit_native.NativeViT(model).forward_tokens(img)
+    assert torch.isfinite(ref).all() and torch.isfinite(got).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("arch,patch,size,B", SHAPES)
 def test_native_f16_matches_fp32_torch_at_baseline_shapes(arch, patch, size, B):
     """Precision "f16".  Bar: relative L2 error vs the fp32 torch model below 2e-3, or - for networks that amplify rounding (a random
