@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define STEGO_ABI_VERSION 6   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
+#define STEGO_ABI_VERSION 7   /* 2: + stego_corr_workspace_prepare, stego_corr_fwd_prepared, stego_corr_fwd_launches, stego_finish_draws, stego_debug_set; K <= 128
                                 * 3: StegoCorrDesc.flags (STEGO_FLAG_SHARED_DEVICE is per call, no longer a process-wide knob)
                                 * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now
                                 * 5: stego_corr_event_counters
-                                * 6: StegoVitDesc.precision (STEGO_VIT_F16X3: the backbone in the fp32 class) */
+                                * 6: StegoVitDesc.precision (STEGO_VIT_F16X3: the backbone in the fp32 class)
+                                * 7: stego_sample, stego_sample_bwd */
 
 enum {
     STEGO_OK = 0,
@@ -333,6 +334,18 @@ size_t stego_dense_corr_workspace_bytes(int32_t B, int32_t C, int32_t H1, int32_
 int stego_dense_corr(const StegoMap* a, const StegoMap* b, int32_t B, int32_t C, int32_t H1, int32_t W1, int32_t H2,
                      int32_t W2, int32_t normalize, float* out, void* workspace, size_t workspace_bytes,
                      stego_stream_t stream);
+
+/* ---- sample() with an image index (reference: sample(), src/modules.py:287-288, as ContrastiveCorrelationLoss.forward calls it on
+ * orig_feats[perm] / orig_code[perm], :384-385 - without the permuted copy of the maps).
+ *   out[n][p][c] (channels-last rows, p = h * S + w) = bilinear sample (align_corners = True, border padding) of map[index[n]] (index
+ *   NULL: map[n]) at coords[n % n_coords][w][h][:] ([..., 0] = x, [..., 1] = y in [-1, 1]).
+ * stego_sample_bwd adds the adjoint into d_map (same shape and strides as the forward's map; the caller zeroes it): fp32 atomic adds,
+ * so the summation order is not fixed.  Any strides; 16-byte loads when the map is channels-last.  Used by the loss for shapes the fused
+ * kernels do not take (feature_samples > 11, dim > 128: stego_amd.modules.ContrastiveCorrelationLoss.generic_forward). */
+int stego_sample(const StegoMap* map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W, const float* coords,
+                 int32_t n_coords, int32_t S, float* out, stego_stream_t stream);
+int stego_sample_bwd(const float* g_out, const StegoMap* d_map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W,
+                     const float* coords, int32_t n_coords, int32_t S, stego_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_SHARED_DEVICE = 1          # StegoCorrDesc.flags
 PREC_F32 = 0
 PREC_F16X3 = 1
@@ -71,6 +71,8 @@ SIGNATURES = {
     "stego_corr_helper_saved_ctx_bytes": (c_size_t, [_D]),
     "stego_dense_corr_workspace_bytes": (c_size_t, [c_int32] * 6),
     "stego_dense_corr": (c_int32, [_M, _M] + [c_int32] * 7 + [_P, _P, c_size_t, _P]),
+    "stego_sample": (c_int32, [_M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, _P]),
+    "stego_sample_bwd": (c_int32, [_P, _M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P]),
     "stego_knn_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32, c_int32, ctypes.c_int64]),
     "stego_knn_topk": (c_int32, [_P, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64,
                                  _P, _P, _P, c_size_t, _P]),
@@ -596,6 +598,47 @@ def dense_corr(a, b, normalize=False):
         _check(lib.stego_dense_corr(byref(ma), byref(mb), B, C, H1, W1, H2, W2, 1 if normalize else 0, _ptr(out), _ptr(ws),
                                     ws.numel(), _stream()))
     return out
+
+
+def sample(t, coords, index=None):
+    """sample(t[index], coords) of the reference (modules.py:287-288) without the indexed copy of `t`: t [M, C, H, W] (fp32, HIP device, any
+    strides), coords [Nc, S, S, 2], index int64 [N] or None (N = M) -> [N, C, S, S] (a view of channels-last rows [N, S*S, C]).  Row n
+    uses the coordinates of row n % Nc."""
+    _require_dev(t, coords)
+    if t.dim() != 4 or t.dtype != torch.float32 or coords.dim() != 4 or coords.shape[-1] != 2 or coords.shape[1] != coords.shape[2]:
+        raise ValueError("sample expects a float32 [M, C, H, W] map and [Nc, S, S, 2] coordinates")
+    lib = load()
+    M, C, H, W = t.shape
+    S = int(coords.shape[1])
+    N = M if index is None else int(index.numel())
+    coords = coords.contiguous().float()
+    if index is not None:
+        index = index.contiguous().to(torch.int64)
+    out = torch.empty(N, S * S, C, dtype=torch.float32, device=t.device)
+    m = _map(t)
+    with _on_device(t.device):
+        _check(lib.stego_sample(byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords), int(coords.shape[0]), S,
+                                _ptr(out), _stream()))
+    return out.view(N, S, S, C).permute(0, 3, 1, 2)
+
+
+def sample_bwd(g_out, like, coords, index=None):
+    """Adjoint of sample(): g_out [N, C, S, S] -> the gradient of the map (shape and memory format of `like`), atomic fp32 adds."""
+    _require_dev(g_out, coords)
+    lib = load()
+    M, C, H, W = like.shape
+    S = int(coords.shape[1])
+    N = M if index is None else int(index.numel())
+    g = g_out.permute(0, 2, 3, 1).contiguous()                     # [N, S, S, C] rows
+    coords = coords.contiguous().float()
+    if index is not None:
+        index = index.contiguous().to(torch.int64)
+    d = torch.zeros_like(like, dtype=torch.float32)               # (preserves the strides of a dense `like`: channels-last stays channels-last)
+    m = _map(d)
+    with _on_device(like.device):
+        _check(lib.stego_sample_bwd(_ptr(g), byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords),
+                                    int(coords.shape[0]), S, _stream()))
+    return d
 
 
 # ------------------------------------------------------------------ segmentation head (include/stego_head.h)

@@ -38,6 +38,35 @@ def average_norm(t):
     return t / t.square().sum(1, keepdim=True).sqrt().mean()
 
 
+class _SampleFunction(torch.autograd.Function):
+    """sample(t[index], coords) on the native gather (stego_sample) with its adjoint (stego_sample_bwd): no permuted copy of the maps."""
+
+    @staticmethod
+    def forward(ctx, t, coords, index):
+        ctx.save_for_backward(coords, index if index is not None else coords.new_empty(0))
+        ctx.has_index = index is not None
+        ctx.like = t
+        return capi.sample(t.detach(), coords, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        coords, index = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        return capi.sample_bwd(g, ctx.like, coords, index if ctx.has_index else None), None, None
+
+
+def sample_indexed(t, coords, index=None):
+    """sample(t if index is None else t[index], coords.repeat(...)) (modules.py:287-288, :384-385): native on a HIP device (no copy of the
+    permuted maps; row n of the result uses coords[n % len(coords)]), the reference's expression elsewhere."""
+    if t.is_cuda and t.dtype == torch.float32 and coords.shape[1] == coords.shape[2]:
+        return _SampleFunction.apply(t, coords, index)
+    if index is not None:
+        t = t[index]
+        coords = coords.repeat(t.shape[0] // coords.shape[0], 1, 1, 1)
+    return sample(t, coords)
+
+
 class _DenseCorrFunction(torch.autograd.Function):
     """tensor_correlation with gradients, all three contractions on the native dense-correspondence kernel:
         out[n,h,w,i,j] = sum_c a[n,c,h,w] b[n,c,i,j]
@@ -730,19 +759,23 @@ class ContrastiveCorrelationLoss(nn.Module):
         B = orig_feats.shape[0]
         n_neg = int(perms.shape[0]) if perms is not None else 0
         n_sets = 2 + n_neg
-        feats, code = sample(orig_feats, coords1), sample(orig_code, coords1)
-        f2, c2 = [feats, sample(orig_feats_pos, coords2)], [code, sample(orig_code_pos, coords2)]
+        feats, code = sample_indexed(orig_feats, coords1), sample_indexed(orig_code, coords1)
+        f2, c2 = [feats, sample_indexed(orig_feats_pos, coords2)], [code, sample_indexed(orig_code_pos, coords2)]
         if n_neg:
-            idx = perms.reshape(-1)                                       # [n_neg * B]: image perm_n[b] for pair (n, b)
-            c2_rep = coords2.repeat(n_neg, 1, 1, 1)
-            f2.append(sample(orig_feats[idx], c2_rep))
-            c2.append(sample(orig_code[idx], c2_rep))
+            # the negatives read the maps of image perm_n[b] at pair (n, b)'s coords2[b] - through an index, not through the permuted
+            # copies of modules.py:384-385 (5 x (38.5 + 7) MB at BASELINE config 2, the largest single cost of the reference's step)
+            idx = perms.reshape(-1)                                       # [n_neg * B]
+            f2.append(sample_indexed(orig_feats, coords2, idx))
+            c2.append(sample_indexed(orig_code, coords2, idx))
         f2, c2 = torch.cat(f2), torch.cat(c2)
         f1, c1 = feats.repeat(n_sets, 1, 1, 1), code.repeat(n_sets, 1, 1, 1)
         S1, S2 = feats.shape[2:]
         per_set = lambda t: t.view(n_sets, B, S1, S2, S1, S2)            # noqa: E731
         with torch.no_grad():
-            fd = per_set(tensor_correlation(norm(f1), norm(f2)))
+            if f1.is_cuda and f1.dtype == torch.float32:
+                fd = per_set(capi.dense_corr(f1, f2, normalize=True))    # norm() inside the kernel's operand pass (no gradient flows here)
+            else:
+                fd = per_set(tensor_correlation(norm(f1), norm(f2)))
             if cfg.pointwise:                                            # helper(), modules.py:331-333, per pair-set
                 # (a set's mean as the mean of its row means - equal counts: the same number, and a reduction with B S^2 outputs per
                 # set instead of ONE, which torch runs on a handful of workgroups: 0.45 ms each at S = 16)

@@ -195,7 +195,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libstego_corr.so does not export %s" % n
         assert n in capi.SIGNATURES, "capi.py has no signature for %s" % n
-    assert lib.stego_abi_version() == 6
+    assert lib.stego_abi_version() == 7
 
 
 def test_library_validates_before_enqueueing():

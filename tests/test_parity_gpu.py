@@ -56,7 +56,7 @@ def _run(case_inputs, perms, cfg, layout="nchw", grad=True, upstream=None, preci
 def test_library_loaded_is_the_in_tree_hip_extension():
     lib = capi.load()
     assert "stego_amd/lib/libstego_corr.so" in capi.library_path()
-    assert lib.stego_abi_version() == 6
+    assert lib.stego_abi_version() == 7
     assert torch.cuda.is_available()
 
 
@@ -1485,3 +1485,31 @@ def test_odd_code_dimensions_take_the_single_launch_forward(K, precision):
     dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
     assert_close(r["d_code"], dc, rtol=1e-3, atol_frac=1e-3, what="d_code")
     assert_close(r["d_code_pos"], dcp, rtol=1e-3, atol_frac=1e-3, what="d_code_pos")
+
+
+@pytest.mark.parametrize("layout", ["cl", "nchw"])
+def test_native_sample_with_index_matches_the_reference_expression(layout):
+    """stego_sample / stego_sample_bwd (ABI 7) against the reference's own statement sample(t[perm], coords.repeat(..)) (modules.py:287-288,
+    :384-385) on torch's grid_sample: forward values and the gradient that flows back into `t` through the duplicated rows of `perm`, for the
+    channels-last views the featurizer emits and for a contiguous NCHW map, S = 13 (not a shape of the fused kernels), borders included."""
+    from stego_amd.modules import sample, sample_indexed
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, C, H, W, S, n_rep = 6, 70, 9, 14, 13, 3
+    t = torch.randn(M, C, H, W, generator=g).to(dev)
+    if layout == "cl":
+        t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    coords = (torch.rand(M, S, S, 2, generator=g) * 2.4 - 1.2).to(dev)          # beyond [-1, 1]: border padding
+    idx = torch.tensor([3, 0, 3, 5, 1, 1] * n_rep, device=dev)                  # duplicates: gradients accumulate
+    t_ref = t.detach().clone().requires_grad_(True)
+    t_nat = t.detach().clone().requires_grad_(True)
+    ref = sample(t_ref[idx], coords.repeat(n_rep, 1, 1, 1))
+    got = sample_indexed(t_nat, coords, idx)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-6
+    up = torch.randn(ref.shape, generator=g).to(dev)
+    (ref * up).sum().backward()
+    (got * up).sum().backward()
+    assert float((t_nat.grad - t_ref.grad).abs().max()) < 2e-5 * float(t_ref.grad.abs().max())
+    # no index: the plain sample()
+    assert float((sample_indexed(t, coords) - sample(t, coords)).abs().max()) < 2e-6
