@@ -130,6 +130,57 @@ def build_torchglue(force=False, verbose=False):
     return TORCHGLUE_PATH
 
 
+# ---- sanitizer build of the HOST side ("race / memory checkers"): the same sources, host code instrumented with
+# AddressSanitizer + UndefinedBehaviorSanitizer (the device code is what the product ships: clang ignores -fsanitize for gfx950 without
+# xnack+).  tests/test_asan_host.py runs the C-ABI's host logic - descriptor validation, geometry, error paths, the symbol table - through it.
+ASAN_DIR = os.path.join(LIB_DIR, "asan")
+ASAN_LIB_PATH = os.path.join(ASAN_DIR, "libstego_corr.so")
+ASAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-shared-libsan", "-g", "-Wno-option-ignored"]
+
+
+def asan_runtime():
+    """The clang AddressSanitizer runtime to LD_PRELOAD into an uninstrumented python (None if this toolchain has none)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib", "llvm", "lib", "clang", "*", "lib", "linux",
+                                         "libclang_rt.asan-x86_64.so")))
+    return hits[-1] if hits else None
+
+
+def build_asan(force=False, verbose=False):
+    """lib/asan/libstego_corr.so: every source with ASAN_FLAGS (objects cached under lib/obj/asan)."""
+    odir = os.path.join(OBJ_DIR, "asan")
+    os.makedirs(odir, exist_ok=True)
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    srcs = sources()
+    deps = _headers() + [os.path.abspath(__file__)]
+
+    def obj(src):
+        return os.path.join(odir, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+    def stale(src):
+        o = obj(src)
+        return force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in [src] + deps)
+
+    def one(src):
+        cmd = [_hipcc()] + CFLAGS + ASAN_FLAGS + ["-c", src, "-o", obj(src) + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc (asan) failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+        os.replace(obj(src) + ".tmp", obj(src))
+
+    todo = [s for s in srcs if stale(s)]
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(one, todo))
+    if todo or not os.path.exists(ASAN_LIB_PATH):
+        res = subprocess.run([_hipcc()] + LDFLAGS + ASAN_FLAGS + [obj(s) for s in srcs] + ["-o", ASAN_LIB_PATH + ".tmp"], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc link (asan) failed:\n" + res.stdout + res.stderr)
+        os.replace(ASAN_LIB_PATH + ".tmp", ASAN_LIB_PATH)
+    return ASAN_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_torchglue(force=True, verbose=True))

@@ -104,7 +104,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    """The in-tree library - or the file STEGO_LIB_PATH names (the sanitizer build of tests/test_asan_host.py; tools)."""
+    return os.environ.get("STEGO_LIB_PATH") or _build.LIB_PATH
 
 
 def load():
