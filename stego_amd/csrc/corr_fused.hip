@@ -264,6 +264,16 @@ __device__ __forceinline__ float half_wave_sum(float v, bool butterfly)
     return v + __shfl_xor(v, 16, 64);                 // the other row of the half-wave
 }
 
+// Sum over the 64 lanes of a wave in ONE fixed order (the tree of half_wave_sum in each half, then the two halves): what a tile's
+// rendezvous and the last workgroup's tail both use for the per-tile sums of a pair-set, 64 images at a time - the two must agree to the bit
+// (saved_mean is what the backward adds to w; the repair path rewrites losses with the tail's old_mean), and a sequential sum of 32 values
+// was 32 dependent readlane + add steps on every negative tile's way out and 0.7 us of the tail (round 5).
+__device__ __forceinline__ float wave_tree_sum(float v)
+{
+    v = half_wave_sum(v, false);
+    return v + __shfl_xor(v, 32, 64);
+}
+
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
 template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false, bool ODDK = false>
@@ -684,41 +694,32 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
     // reads = 6.7 us at the very end of every launch)
     const bool repair = __syncthreads_or(mine) && prm.pointwise;
     if (ts && tid == 0) ts[13] = __builtin_amdgcn_s_memrealtime();
+    // the per-pair-set sums (sum fd, sum lp, sum clamp over the images, wave_tree_sum's order): (pair-set, quantity) idx by wave idx % 12
+    for (int idx = tid >> 6; idx < 3 * prm.n_sets; idx += FUSED_WAVES) {
+        const int ps = idx / 3, k = idx - 3 * ps, lane = tid & 63;
+        const float* st = sst + (size_t)ps * B * 4 + k;
+        float acc = 0.f;
+        for (int i0 = 0; i0 < B; i0 += 64) acc += wave_tree_sum(i0 + lane < B ? st[(i0 + lane) * 4] : 0.f);
+        if (lane == 0) sums3[idx] = acc;
+    }
     if (tid >= 64) {
-        // every hand-off word has been copied: waves 1.. write them back to zero while wave 0 does the arithmetic
+        // every hand-off word has been copied: waves 1.. write them back to zero
         constexpr int NZ = FUSED_THREADS - 64;
-        for (int i = tid - 64; i < B; i += NZ)
+        for (int i = tid - 64; i < B; i += NZ) {
             __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         for (int i = tid - 64; i < n_tiles * 4; i += NZ)
             __hip_atomic_store(prm.gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        // wave 0, no workgroup barriers in between (the LDS executes a wave's operations in order).  (pair-set, quantity) per lane,
-        // image order; independent LDS reads in flight eight at a time (one thread per pair-set walking all three was 3 B
-        // dependent round trips: 1.1 us)
+    }
+    __syncthreads();                             // sums3 complete
+    if (tid < 64) {
         const float inv_cnt = 1.f / ((float)B * (float)P2);
-        for (int idx = tid; idx < 3 * prm.n_sets; idx += 64) {
-            const int ps = idx / 3, k = idx - 3 * ps;
-            const float* st = sst + (size_t)ps * B * 4 + k;
-            float acc = 0.f;
-            int bb = 0;
-            for (; bb + 8 <= B; bb += 8) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = st[(bb + i) * 4];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc += v[i];
-            }
-            for (; bb < B; ++bb) acc += st[bb * 4];
-            sums3[idx] = acc;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
         for (int ps = tid; ps < prm.n_sets; ps += 64) {
             const float fsum = sums3[3 * ps], lsum = sums3[3 * ps + 1], csum = sums3[3 * ps + 2];
             const float omp = prm.pointwise ? fsum * inv_cnt : 0.f;
             som[ps] = fsum * inv_cnt;
             som[prm.n_sets + ps] = lsum - omp * csum;               // sum of this pair-set's loss
-            const float poison = timed_out[0] != 0.f ? __builtin_nanf("") : 0.f;       // (written before the barrier above)
+            const float poison = timed_out[0] != 0.f ? __builtin_nanf("") : 0.f;       // (written before the first barrier above)
             if (prm.saved_mean) prm.saved_mean[ps] = omp + poison;
             if (ps < 2) prm.loss_means[ps] = (lsum - omp * csum) * inv_cnt + poison;
         }
@@ -1347,36 +1348,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
     __syncthreads();                             // E0: the ring is dead, csc / cscc complete
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
     if (mfma_team) {
-        // sum(fd) of the tile straight from the accumulators (fixed order), then park fd in the flat output layout
-        float s = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = 64 * wc + 32 * ni + (lane & 31);
-            float sc = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    sc += row < P ? accf[mi][ni][r] : 0.f;
-                }
-            s += col < P ? sc * csc[col] : 0.f;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (lane == 0) red[wave] = s;
+        // park fd in the flat output layout.  (sum(fd) of the tile - what the old_mean rendezvous needs - used to be taken here from the
+        // accumulators: 0.9 us of masked adds and a 64-lane reduction on every tile's way out; it is now the sum of the row sums the gather
+        // waves take from the parked tile anyway, round 5.)
         if (stamp_on && !(prm.debug & 1024)) ts[12] = __builtin_amdgcn_s_memrealtime();
         if (stamp_on && !(prm.debug & 1024)) ts[13] = __builtin_amdgcn_s_memrealtime();
         park_flat(accf, Tfd + a, P, csc, lane, wr, wc);
         if (stamp_on && !(prm.debug & 1024)) ts[14] = __builtin_amdgcn_s_memrealtime();
     }
-    __syncthreads();                             // E1: Tfd and the four partial sums are complete
-    if (tid == 0) {
-        const float sfd = (red[0] + red[1]) + (red[2] + red[3]);
-        // one aligned 8-byte write-through store: {tag, value} (read by the tiles of my pair-set and by the last workgroup)
-        __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __syncthreads();                             // E1: Tfd is complete
     float* omv = red + 8;                        // [0] old_mean, [1] applied
     if (mfma_team) {
         park_flat(accc, Tcd + a, P, cscc, lane, wr, wc);
@@ -1398,8 +1378,19 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         sfull += __shfl_xor(sfull, 1, 64);
         sfull += __shfl_xor(sfull, 2, 64);
         if (t == 0 && row < TP) rowmean[row] = (prm.pointwise && row < P) ? sfull / (float)P : 0.f;
+        // sum(fd) of the tile = the sum of its row sums, in a fixed order: the 16 rows of a wave (one lane per row counts), then the waves
+        float ws = (t == 0 && row < P) ? sfull : 0.f;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor(ws, m, 64);
+        if (lane == 0) red[40 + (wave8 - 4)] = ws;
     }
-    __syncthreads();                             // E2: Tcd, rowmean
+    __syncthreads();                             // E2: Tcd, rowmean, the eight partial sums of fd
+    if (tid == 0) {
+        const float sfd = ((red[40] + red[41]) + (red[42] + red[43])) + ((red[44] + red[45]) + (red[46] + red[47]));
+        // one aligned 8-byte write-through store: {tag, value} (read by the tiles of my pair-set and by the last workgroup)
+        __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
 
     // ---- output sweep, in two parts: cd and the backward's w (+ the two sums) do not need old_mean and leave first, so that
@@ -1471,8 +1462,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
                         __builtin_amdgcn_s_sleep(16);
                     }
                     const float v = i < B ? __builtin_bit_cast(float, (unsigned)x) : 0.f;
-                    const int n = min(64, B - i0);
-                    for (int l = 0; l < n; ++l) acc += __shfl(v, l, 64);
+                    acc += wave_tree_sum(v);
                 }
                 if (ok_all) om = acc * (1.f / ((float)B * (float)P2));     // same expression as the scalar kernel
                 else applied = 0.f;
