@@ -32,7 +32,7 @@ extern "C" {
                                 * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now
                                 * 5: stego_corr_event_counters
                                 * 6: StegoVitDesc.precision (STEGO_VIT_F16X3: the backbone in the fp32 class)
-                                * 7: stego_sample, stego_sample_bwd */
+                                * 7: stego_sample, stego_sample_bwd, stego_rowsum, stego_loss_pointwise_fwd / _bwd */
 
 enum {
     STEGO_OK = 0,
@@ -346,6 +346,22 @@ int stego_sample(const StegoMap* map, const int64_t* index, int32_t N, int32_t C
                  int32_t n_coords, int32_t S, float* out, stego_stream_t stream);
 int stego_sample_bwd(const float* g_out, const StegoMap* d_map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W,
                      const float* coords, int32_t n_coords, int32_t S, stego_stream_t stream);
+
+/* ---- the elementwise part of helper() (src/modules.py:330-345) over the correlation tensors of ALL pair-sets at once, for shapes the
+ * fused kernels do not take: fd, cd = [n_sets][B][P][P] contiguous (set 0 intra, 1 inter, 2.. negatives; shift[min(set, 2)]).
+ *   stego_rowsum: out[r] = sum_j x[r][j] (rows x P contiguous).  The caller reduces rowsum to the per-set old_mean = sum / (B P P).
+ *   _fwd: loss = -clamp(cd, clamp_min, clamp_max) * ((fd - rowsum / P) + old_mean[set] - shift) (pointwise = 0: fd - shift); writes the
+ *         loss of the negative sets to neg_loss [n_sets - 2][B][P][P] and the row sums of the loss of every set to loss_rowsum [n_sets][B][P].
+ *   _bwd: g_cd = -((fd - rowsum / P) + old_mean - shift) * 1[clamp_min <= cd <= clamp_max] * (g_sums[set] + (set >= 2 ? g_neg_bcast[0] +
+ *         g_neg_loss : 0)); g_neg_loss (dense), g_neg_bcast (ONE device float: an expanded scalar upstream) and g_sums (device [n_sets])
+ *         are the upstreams of the two outputs, each may be NULL. */
+int stego_rowsum(const float* x, int64_t rows, int32_t P, float* out, stego_stream_t stream);
+int stego_loss_pointwise_fwd(const float* fd, const float* cd, const float* rowsum, const float* old_mean, int32_t n_sets, int32_t B, int32_t P,
+                             const float shift[3], float clamp_min, float clamp_max, int32_t pointwise, float* neg_loss, float* loss_rowsum,
+                             stego_stream_t stream);
+int stego_loss_pointwise_bwd(const float* fd, const float* cd, const float* rowsum, const float* old_mean, int32_t n_sets, int32_t B, int32_t P,
+                             const float shift[3], float clamp_min, float clamp_max, int32_t pointwise, const float* g_neg_loss,
+                             const float* g_neg_bcast, const float* g_sums, float* g_cd, stego_stream_t stream);
 
 #ifdef __cplusplus
 }

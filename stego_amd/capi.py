@@ -73,6 +73,9 @@ SIGNATURES = {
     "stego_dense_corr": (c_int32, [_M, _M] + [c_int32] * 7 + [_P, _P, c_size_t, _P]),
     "stego_sample": (c_int32, [_M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, _P]),
     "stego_sample_bwd": (c_int32, [_P, _M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P]),
+    "stego_rowsum": (c_int32, [_P, ctypes.c_int64, c_int32, _P, _P]),
+    "stego_loss_pointwise_fwd": (c_int32, [_P] * 4 + [c_int32] * 3 + [POINTER(c_float), c_float, c_float, c_int32, _P, _P, _P]),
+    "stego_loss_pointwise_bwd": (c_int32, [_P] * 4 + [c_int32] * 3 + [POINTER(c_float), c_float, c_float, c_int32, _P, _P, _P, _P, _P]),
     "stego_knn_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32, c_int32, ctypes.c_int64]),
     "stego_knn_topk": (c_int32, [_P, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64,
                                  _P, _P, _P, c_size_t, _P]),
@@ -621,6 +624,51 @@ def sample(t, coords, index=None):
         _check(lib.stego_sample(byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords), int(coords.shape[0]), S,
                                 _ptr(out), _stream()))
     return out.view(N, S, S, C).permute(0, 3, 1, 2)
+
+
+def loss_pointwise_fwd(fd, cd, shifts, cmin, cmax, pointwise):
+    """The elementwise part of helper() (modules.py:330-345) over all pair-sets: fd, cd [n_sets, B, P, P] contiguous fp32 ->
+    (neg_loss [n_sets - 2, B, P, P], per-set loss sums [n_sets], rowsum [n_sets * B * P], old_mean [n_sets])."""
+    _require_dev(fd, cd)
+    lib = load()
+    n_sets, B, P = int(fd.shape[0]), int(fd.shape[1]), int(fd.shape[2])
+    dev = fd.device
+    rows = n_sets * B * P
+    rowsum = torch.empty(rows, dtype=torch.float32, device=dev)
+    sh = (c_float * 3)(*[float(x) for x in shifts])
+    neg_loss = torch.empty(max(n_sets - 2, 0), B, P, P, dtype=torch.float32, device=dev)
+    loss_rowsum = torch.empty(rows, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        if pointwise:
+            _check(lib.stego_rowsum(_ptr(fd), rows, P, _ptr(rowsum), _stream()))
+            old_mean = rowsum.view(n_sets, -1).sum(1) / float(B * P * P)
+        else:
+            old_mean = torch.zeros(n_sets, dtype=torch.float32, device=dev)
+        _check(lib.stego_loss_pointwise_fwd(_ptr(fd), _ptr(cd), _ptr(rowsum), _ptr(old_mean), n_sets, B, P, sh, float(cmin), float(cmax),
+                                            1 if pointwise else 0, _ptr(neg_loss) if n_sets > 2 else None, _ptr(loss_rowsum), _stream()))
+    return neg_loss, loss_rowsum.view(n_sets, -1).sum(1), rowsum, old_mean
+
+
+def loss_pointwise_bwd(fd, cd, rowsum, old_mean, shifts, cmin, cmax, pointwise, g_neg, g_sums):
+    """d cd of loss_pointwise_fwd: g_neg (upstream of neg_loss: dense, an expanded scalar, or None), g_sums (upstream of the sums, or None)."""
+    lib = load()
+    n_sets, B, P = int(fd.shape[0]), int(fd.shape[1]), int(fd.shape[2])
+    sh = (c_float * 3)(*[float(x) for x in shifts])
+    g_cd = torch.empty_like(cd)
+    dense = bcast = None
+    if g_neg is not None and g_neg.numel() > 0:
+        if all(st == 0 for st in g_neg.stride()):
+            bcast = g_neg                                   # ONE value behind every element (the backward of .mean() / .sum())
+        else:
+            dense = g_neg.contiguous().float()
+    if g_sums is not None:
+        g_sums = g_sums.contiguous().float()
+    with _on_device(fd.device):
+        _check(lib.stego_loss_pointwise_bwd(_ptr(fd), _ptr(cd), _ptr(rowsum), _ptr(old_mean), n_sets, B, P, sh, float(cmin), float(cmax),
+                                            1 if pointwise else 0, _ptr(dense) if dense is not None else None,
+                                            _ptr(bcast) if bcast is not None else None, _ptr(g_sums) if g_sums is not None else None,
+                                            _ptr(g_cd), _stream()))
+    return g_cd
 
 
 def sample_bwd(g_out, like, coords, index=None):

@@ -67,6 +67,26 @@ def sample_indexed(t, coords, index=None):
     return sample(t, coords)
 
 
+class _PointwiseLossFunction(torch.autograd.Function):
+    """helper()'s elementwise part (modules.py:330-345) for all pair-sets in three launches (stego_rowsum, stego_loss_pointwise_fwd /
+    _bwd): (fd [sets, B, P, P] - no gradient, the reference computes it under no_grad -, cd [sets, B, P, P]) ->
+    (neg_loss [sets - 2, B, P, P], the sum of every set's loss [sets])."""
+
+    @staticmethod
+    def forward(ctx, fd, cd, shifts, cmin, cmax, pointwise):
+        fd, cdc = fd.contiguous(), cd.detach().contiguous()
+        neg_loss, sums, rowsum, old_mean = capi.loss_pointwise_fwd(fd, cdc, shifts, cmin, cmax, pointwise)
+        ctx.save_for_backward(fd, cdc, rowsum, old_mean)
+        ctx.args = (shifts, cmin, cmax, pointwise)
+        return neg_loss, sums
+
+    @staticmethod
+    def backward(ctx, g_neg, g_sums):
+        fd, cdc, rowsum, old_mean = ctx.saved_tensors
+        shifts, cmin, cmax, pointwise = ctx.args
+        return None, capi.loss_pointwise_bwd(fd, cdc, rowsum, old_mean, shifts, cmin, cmax, pointwise, g_neg, g_sums), None, None, None, None
+
+
 class _DenseCorrFunction(torch.autograd.Function):
     """tensor_correlation with gradients, all three contractions on the native dense-correspondence kernel:
         out[n,h,w,i,j] = sum_c a[n,c,h,w] b[n,c,i,j]
@@ -91,6 +111,15 @@ class _DenseCorrFunction(torch.autograd.Function):
         H2, W2 = b.shape[2:]
         g = g.contiguous().view(N, H1 * W1, H2 * W2)
         da = db = None
+        if C <= 128 and H1 * W1 <= 1024 and H2 * W2 <= 1024:
+            # the adjoints of a CODE correlation over sampled points (the loss at cfg.feature_samples > 11): N small batched GEMMs
+            # [C x P] . [P x P] - plain library GEMMs (rocBLAS through torch.bmm).  On the native kernel each first re-lays its "map" g -
+            # 59 MB at S = 16 - into fp16 operand panels: 0.25 ms per adjoint for 2 GFLOP (tools/exp/generic_loop.py)
+            if ctx.needs_input_grad[0]:
+                da = torch.bmm(b.flatten(2), g.transpose(1, 2)).view(N, C, H1, W1)
+            if ctx.needs_input_grad[1]:
+                db = torch.bmm(a.flatten(2), g).view(N, C, H2, W2)
+            return da, db
         if ctx.needs_input_grad[0]:
             gq = g.permute(0, 2, 1).unflatten(2, (H1, W1))             # [N, (i,j), H1, W1]: "channels" = positions of b
             bt = b.flatten(2).permute(0, 2, 1).unsqueeze(-1)           # [N, (i,j), C, 1]
@@ -771,11 +800,25 @@ class ContrastiveCorrelationLoss(nn.Module):
         f1, c1 = feats.repeat(n_sets, 1, 1, 1), code.repeat(n_sets, 1, 1, 1)
         S1, S2 = feats.shape[2:]
         per_set = lambda t: t.view(n_sets, B, S1, S2, S1, S2)            # noqa: E731
-        with torch.no_grad():
-            if f1.is_cuda and f1.dtype == torch.float32:
-                fd = per_set(capi.dense_corr(f1, f2, normalize=True))    # norm() inside the kernel's operand pass (no gradient flows here)
+        min_val = 0.0 if cfg.zero_clamp else -9999.0
+        if f1.is_cuda and f1.dtype == torch.float32:
+            # native: norm() of the features inside the dense kernel's operand pass, the elementwise part of helper() for all pair-sets in
+            # three launches (stego_rowsum / stego_loss_pointwise_fwd / _bwd: ~25 torch kernels over 59 MB tensors at S = 16 before)
+            with torch.no_grad():
+                fd = capi.dense_corr(f1, f2, normalize=True)
+            cd = per_set(tensor_correlation(norm(c1), norm(c2)))
+            P = S1 * S2
+            neg, sums = _PointwiseLossFunction.apply(fd.view(n_sets, B, P, P), cd.view(n_sets, B, P, P),
+                                                     (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), min_val,
+                                                     0.8 if cfg.stabalize else 3.0e38, bool(cfg.pointwise))
+            cnt = float(B * P * P)
+            if n_neg:
+                neg_inter_loss, neg_inter_cd = neg.view(n_neg * B, S1, S2, S1, S2), cd[2:].flatten(0, 1)
             else:
-                fd = per_set(tensor_correlation(norm(f1), norm(f2)))
+                neg_inter_loss = neg_inter_cd = cd.new_zeros(0, S1, S2, S1, S2)
+            return sums[0] / cnt, cd[0], sums[1] / cnt, cd[1], neg_inter_loss, neg_inter_cd
+        with torch.no_grad():
+            fd = per_set(tensor_correlation(norm(f1), norm(f2)))
             if cfg.pointwise:                                            # helper(), modules.py:331-333, per pair-set
                 # (a set's mean as the mean of its row means - equal counts: the same number, and a reduction with B S^2 outputs per
                 # set instead of ONE, which torch runs on a handful of workgroups: 0.45 ms each at S = 16)
@@ -790,7 +833,6 @@ class ContrastiveCorrelationLoss(nn.Module):
             if n_neg:
                 torch.sub(fd[2:], cfg.neg_inter_shift, out=fds[2:])
         cd = per_set(tensor_correlation(norm(c1), norm(c2)))
-        min_val = 0.0 if cfg.zero_clamp else -9999.0
         loss = -(cd.clamp(min_val, .8) if cfg.stabalize else cd.clamp(min_val)) * fds
         if n_neg:
             neg_inter_loss, neg_inter_cd = loss[2:].flatten(0, 1), cd[2:].flatten(0, 1)

@@ -1513,3 +1513,57 @@ def test_native_sample_with_index_matches_the_reference_expression(layout):
     assert float((t_nat.grad - t_ref.grad).abs().max()) < 2e-5 * float(t_ref.grad.abs().max())
     # no index: the plain sample()
     assert float((sample_indexed(t, coords) - sample(t, coords)).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("variant", ["default", "noclamp_stab", "plain"])
+def test_native_pointwise_loss_matches_the_reference_statements(variant):
+    """stego_rowsum + stego_loss_pointwise_fwd / _bwd (ABI 7) against helper()'s own statements (modules.py:330-345) in torch, per pair-set:
+    the negative losses, every set's loss sum, and the gradient to cd for dense + per-set upstreams; zero_clamp / stabalize / pointwise variants."""
+    from stego_amd.modules import _PointwiseLossFunction
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n_sets, B, P = 4, 3, 37
+    fd = (torch.randn(n_sets, B, P, P, generator=g) * 0.3).to(dev)
+    cd0 = (torch.randn(n_sets, B, P, P, generator=g) * 0.6).to(dev)
+    shifts = (0.18, 0.12, 0.46)
+    zero_clamp, stab, pointwise = {"default": (True, False, True), "noclamp_stab": (False, True, True), "plain": (True, False, False)}[variant]
+    cmin, cmax = (0.0 if zero_clamp else -9999.0), (0.8 if stab else 3.0e38)
+    cd_ref = cd0.clone().requires_grad_(True)
+    losses = []
+    for s_ in range(n_sets):                                   # the reference, one helper() call per pair-set
+        f = fd[s_].clone()
+        if pointwise:
+            old = f.mean()
+            f = f - f.mean(dim=2, keepdim=True)                # fd.mean([3, 4]) of [n, h, w, i, j]: over the second set of points
+            f = f - f.mean() + old
+        c = cd_ref[s_]
+        cl = c.clamp(cmin, 0.8) if stab else c.clamp(cmin)
+        losses.append(-cl * (f - shifts[min(s_, 2)]))
+    ref_neg = torch.stack(losses[2:])
+    ref_sums = torch.stack([l.sum() for l in losses])
+    cd_nat = cd0.clone().requires_grad_(True)
+    neg, sums = _PointwiseLossFunction.apply(fd, cd_nat, shifts, cmin, cmax, pointwise)
+    scale = float(ref_neg.abs().mean())
+    assert float((neg - ref_neg).abs().max()) < 2e-6 * max(1.0, scale) + 2e-6
+    assert float((sums - ref_sums).abs().max()) < 1e-4 * float(ref_sums.abs().max()) + 1e-4
+    up_neg = torch.randn(ref_neg.shape, generator=g).to(dev)
+    up_sums = torch.randn(n_sets, generator=g).to(dev)
+    ((ref_neg * up_neg).sum() + (ref_sums * up_sums).sum()).backward()
+    ((neg * up_neg).sum() + (sums * up_sums).sum()).backward()
+    assert float((cd_nat.grad - cd_ref.grad).abs().max()) < 1e-5 * float(cd_ref.grad.abs().max()) + 1e-6
+    # an expanded scalar upstream (the backward of .mean()): no dense copy is made
+    cd_b = cd0.clone().requires_grad_(True)
+    neg_b, _ = _PointwiseLossFunction.apply(fd, cd_b, shifts, cmin, cmax, pointwise)
+    neg_b.mean().backward()
+    cd_r = cd0.clone().requires_grad_(True)
+    ls = []
+    for s_ in range(2, n_sets):
+        f = fd[s_].clone()
+        if pointwise:
+            old = f.mean()
+            f = f - f.mean(dim=2, keepdim=True)
+            f = f - f.mean() + old
+        c = cd_r[s_]
+        ls.append(-(c.clamp(cmin, 0.8) if stab else c.clamp(cmin)) * (f - shifts[2]))
+    torch.stack(ls).mean().backward()
+    assert float((cd_b.grad - cd_r.grad).abs().max()) < 1e-5 * float(cd_r.grad.abs().max()) + 1e-9
