@@ -32,7 +32,7 @@ extern "C" {
                                 * 4: StegoHeadDesc.tokens_amax, stego_tokens_from_cache, stego_ref_dropout_masks, stego_ref_draws_indirect, stego_corr_workspace_prepare_now
                                 * 5: stego_corr_event_counters
                                 * 6: StegoVitDesc.precision (STEGO_VIT_F16X3: the backbone in the fp32 class)
-                                * 7: stego_sample, stego_sample_bwd, stego_rowsum, stego_loss_pointwise_fwd / _bwd */
+                                * 7: stego_sample, stego_sample_bwd, stego_rowsum, stego_loss_pointwise_fwd / _bwd, stego_sample_panels, stego_dense_corr_panels, stego_sample_bwd_rows; stego_corr_fwd / _bwd take S = 12 .. 16 */
 
 enum {
     STEGO_OK = 0,
@@ -93,9 +93,12 @@ enum {
                                     * bit for bit; ~2 us slower on an otherwise idle device.  Per call: part of the descriptor. */
 };
 
-/* Limits of this build: S*S <= 128 (S <= 11); K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
+/* Limits of this build: S*S <= 128 (S <= 11): K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
  * channels-last maps with C = 192 / 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
- * helper()); every per-image element offset < 2^31.  Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
+ * helper()); 128 < S*S <= 256 (S = 12 .. 16, ABI 7): K <= 88, any C and layout - the same entry points run the multi-launch kernels of
+ * csrc/corr_wide.hip (stego_corr_fwd_launches says 11; split-fp16 products in both precision modes; the code gradients are accumulated with
+ * fp32 atomics, so their last bits are not repeatable - everything below is about S <= 11); every per-image element offset < 2^31.
+ * Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
  * GEMMs are split-fp16 products in both precision modes (their fp32 operand images no longer fit LDS).
  * Determinism: every kernel sums in a fixed order (bitwise repeatable results), with ONE exception: the backward of maps
  * wider than 64 pixels (no BASELINE config) takes a band fallback whose fp32 summation order follows arrival order; repeated
@@ -215,7 +218,8 @@ int stego_ref_draws_indirect(const int64_t* seed_ptr, const int64_t* offset_ptr,
 int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2,
                      int64_t* perms, stego_stream_t stream);
 
-/* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize; < 0: -error code. */
+/* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize, 9 or 11 = S > 11 (csrc/corr_wide.hip);
+ * < 0: -error code. */
 int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
                             const StegoMap* code, const StegoMap* code_pos);
 int stego_corr_workspace_prepare(const StegoCorrDesc* desc, void* workspace, size_t workspace_bytes, stego_stream_t stream);
@@ -346,6 +350,29 @@ int stego_sample(const StegoMap* map, const int64_t* index, int32_t N, int32_t C
                  int32_t n_coords, int32_t S, float* out, stego_stream_t stream);
 int stego_sample_bwd(const float* g_out, const StegoMap* d_map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W,
                      const float* coords, int32_t n_coords, int32_t S, stego_stream_t stream);
+
+/* ---- the sampled points as prepared OPERANDS of the dense-correspondence kernel (the loss for feature_samples 12 .. 16 / dim > 128: what
+ * the reference computes as tensor_correlation(norm(sample(t[perm], coords)), ...), src/modules.py:328,335,384-385, without the fp32 rows
+ * of the sampled features ever existing).  An operand image = [128-point block][64-channel chunk][hi | lo][128 rows][72 fp16] - the row's
+ * values times a power-of-two scale, split into fp16 hi + lo - stego_panel_image_bytes(C, P) bytes per image, with a row-scale array of
+ * ceil(P / 128) * 128 floats per image beside it; the caller allocates both (16-byte aligned) for as many images as it samples.
+ *   stego_sample_panels: image n of the set = the S * S points of map[index[n]] (NULL: map[n]) at coords[n % n_coords], L2-normalised over
+ *     the channels when `normalize` (eps 1e-10, F.normalize).  rows_out (optional): the normalised fp32 rows [N][P][C]; inv_out (optional):
+ *     1 / max(|row|, eps) [N][P] - what the backward of norm() needs for tensors that carry a gradient.
+ *   stego_dense_corr_panels: out[n][i][j] = <A image n % images_a, point i ; B image n, point j> (M x Ncols per pair, fp32, contiguous):
+ *     one set of anchors against the second operands of several pair-sets.  The two operand sets may be the same buffer.  rowsum (optional,
+ *     [N][M]): sum_j out[n][i][j], what the pointwise shift of helper() (src/modules.py:332) needs of fd.
+ *   stego_sample_bwd_rows: the adjoint of the sampling for the gradient g_rows [N][P][C] of those rows, ADDED into d_map (fp32 atomics, as
+ *     stego_sample_bwd); with rows_n / inv (what stego_sample_panels wrote) g_rows is the gradient of the NORMALISED rows and the backward of
+ *     norm() is applied first: d row = inv * (g - rows_n <rows_n, g>), inv * g where the row's norm was below eps. */
+size_t stego_panel_image_bytes(int32_t C, int32_t P);
+int stego_sample_bwd_rows(const float* g_rows, const float* rows_n, const float* inv, const StegoMap* d_map, const int64_t* index, int32_t N,
+                          int32_t C, int32_t H, int32_t W, const float* coords, int32_t n_coords, int32_t S, stego_stream_t stream);
+int stego_sample_panels(const StegoMap* map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W, const float* coords,
+                        int32_t n_coords, int32_t S, int32_t normalize, void* panels, float* row_scale, float* rows_out, float* inv_out,
+                        stego_stream_t stream);
+int stego_dense_corr_panels(const void* panels_a, const float* row_scale_a, int32_t images_a, const void* panels_b, const float* row_scale_b,
+                            int32_t N, int32_t C, int32_t M, int32_t Ncols, float* out, float* rowsum, stego_stream_t stream);
 
 /* ---- the elementwise part of helper() (src/modules.py:330-345) over the correlation tensors of ALL pair-sets at once, for shapes the
  * fused kernels do not take: fd, cd = [n_sets][B][P][P] contiguous (set 0 intra, 1 inter, 2.. negatives; shift[min(set, 2)]).

@@ -73,6 +73,10 @@ SIGNATURES = {
     "stego_dense_corr": (c_int32, [_M, _M] + [c_int32] * 7 + [_P, _P, c_size_t, _P]),
     "stego_sample": (c_int32, [_M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, _P]),
     "stego_sample_bwd": (c_int32, [_P, _M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P]),
+    "stego_sample_bwd_rows": (c_int32, [_P, _P, _P, _M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P]),
+    "stego_panel_image_bytes": (c_size_t, [c_int32, c_int32]),
+    "stego_sample_panels": (c_int32, [_M, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "stego_dense_corr_panels": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "stego_rowsum": (c_int32, [_P, ctypes.c_int64, c_int32, _P, _P]),
     "stego_loss_pointwise_fwd": (c_int32, [_P] * 4 + [c_int32] * 3 + [POINTER(c_float), c_float, c_float, c_int32, _P, _P, _P]),
     "stego_loss_pointwise_bwd": (c_int32, [_P] * 4 + [c_int32] * 3 + [POINTER(c_float), c_float, c_float, c_int32, _P, _P, _P, _P, _P]),
@@ -451,6 +455,8 @@ def event_counters_total():
         seen += list(mod.workspaces())
     for dbytes, ws in seen:
         desc = StegoCorrDesc.from_buffer_copy(dbytes)
+        if desc.S * desc.S > 128:                   # the multi-launch path (csrc/corr_wide.hip) has no hand-off words
+            continue
         a, b = event_counters(desc, ws)
         g += a
         r += b
@@ -626,21 +632,25 @@ def sample(t, coords, index=None):
     return out.view(N, S, S, C).permute(0, 3, 1, 2)
 
 
-def loss_pointwise_fwd(fd, cd, shifts, cmin, cmax, pointwise):
+def loss_pointwise_fwd(fd, cd, shifts, cmin, cmax, pointwise, rowsum=None):
     """The elementwise part of helper() (modules.py:330-345) over all pair-sets: fd, cd [n_sets, B, P, P] contiguous fp32 ->
-    (neg_loss [n_sets - 2, B, P, P], per-set loss sums [n_sets], rowsum [n_sets * B * P], old_mean [n_sets])."""
+    (neg_loss [n_sets - 2, B, P, P], per-set loss sums [n_sets], rowsum [n_sets * B * P], old_mean [n_sets]).  rowsum: the row sums of fd when
+    the correlation kernel already took them (dense_corr_panels(want_rowsum=True))."""
     _require_dev(fd, cd)
     lib = load()
     n_sets, B, P = int(fd.shape[0]), int(fd.shape[1]), int(fd.shape[2])
     dev = fd.device
     rows = n_sets * B * P
-    rowsum = torch.empty(rows, dtype=torch.float32, device=dev)
+    have_rowsum = rowsum is not None
+    if not have_rowsum:
+        rowsum = torch.empty(rows, dtype=torch.float32, device=dev)
     sh = (c_float * 3)(*[float(x) for x in shifts])
     neg_loss = torch.empty(max(n_sets - 2, 0), B, P, P, dtype=torch.float32, device=dev)
     loss_rowsum = torch.empty(rows, dtype=torch.float32, device=dev)
     with _on_device(dev):
         if pointwise:
-            _check(lib.stego_rowsum(_ptr(fd), rows, P, _ptr(rowsum), _stream()))
+            if not have_rowsum:
+                _check(lib.stego_rowsum(_ptr(fd), rows, P, _ptr(rowsum), _stream()))
             old_mean = rowsum.view(n_sets, -1).sum(1) / float(B * P * P)
         else:
             old_mean = torch.zeros(n_sets, dtype=torch.float32, device=dev)
@@ -688,6 +698,91 @@ def sample_bwd(g_out, like, coords, index=None):
         _check(lib.stego_sample_bwd(_ptr(g), byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords),
                                     int(coords.shape[0]), S, _stream()))
     return d
+
+
+def sample_bwd_rows(g_rows, d_map, coords, index=None, rows_n=None, inv=None):
+    """Adjoint of sample() for gradients that are already channels-last rows: g_rows [N, P, C] contiguous is ADDED into d_map (the map's
+    gradient, fp32, any strides, zeroed by the caller).  With rows_n / inv (the normalised rows and 1 / max(|row|, eps) stego_sample_panels
+    saved) g_rows is the gradient of the NORMALISED rows and the backward of norm() (F.normalize, modules.py:275-276) is applied on the way:
+    d row = inv * (g - rows_n <rows_n, g>), or inv * g where the row's norm was below eps."""
+    _require_dev(g_rows, d_map)
+    lib = load()
+    M, C, H, W = d_map.shape
+    S = int(coords.shape[1])
+    N = int(g_rows.shape[0])
+    if g_rows.dim() != 3 or not g_rows.is_contiguous() or g_rows.shape[1] != S * S or g_rows.shape[2] != C or g_rows.dtype != torch.float32:
+        raise ValueError("sample_bwd_rows expects contiguous float32 [N, S*S, C] rows")
+    if (rows_n is None) != (inv is None) or (rows_n is not None and (not rows_n.is_contiguous() or not inv.is_contiguous()
+                                                                   or rows_n.shape != g_rows.shape or inv.numel() != N * S * S)):
+        raise ValueError("sample_bwd_rows: rows_n [N, P, C] and inv [N, P] go together, contiguous")
+    coords = coords.contiguous().float()
+    if index is not None:
+        index = index.contiguous().to(torch.int64)
+        if index.numel() != N:
+            raise ValueError("sample_bwd_rows: one index per row image")
+    elif N != M:
+        raise ValueError("sample_bwd_rows: %d row images for a map of %d" % (N, M))
+    m = _map(d_map)
+    with _on_device(d_map.device):
+        _check(lib.stego_sample_bwd_rows(_ptr(g_rows), _ptr(rows_n) if rows_n is not None else None, _ptr(inv) if inv is not None else None,
+                                         byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords),
+                                         int(coords.shape[0]), S, _stream()))
+    return d_map
+
+
+class PanelSet:
+    """Prepared operands of the dense-correspondence kernel for `images` point sets of P points x C channels (include/stego_corr.h,
+    stego_sample_panels): split-fp16 operand images + one scale per row."""
+
+    def __init__(self, images, C, P, device):
+        lib = load()
+        self.images, self.C, self.P = int(images), int(C), int(P)
+        self.image_bytes = int(lib.stego_panel_image_bytes(self.C, self.P))
+        if self.image_bytes <= 0:
+            raise ValueError("PanelSet: bad shape C = %d, P = %d" % (C, P))
+        self.rows = (self.P + 127) // 128 * 128
+        self.panels = torch.empty(self.images * self.image_bytes, dtype=torch.uint8, device=device)
+        self.row_scale = torch.empty(self.images, self.rows, dtype=torch.float32, device=device)
+
+
+def sample_panels(pset, first, t, coords, index=None, normalize=True, rows_out=None, inv_out=None):
+    """Images [first, first + N) of `pset` = norm(sample(t if index is None else t[index], coords)) (modules.py:275-276, 287-288, 384-385) as
+    operands of dense_corr_panels; rows_out [N, P, C] / inv_out [N, P] (contiguous fp32, optional) receive the normalised rows and
+    1 / max(|row|, eps)."""
+    _require_dev(t, coords)
+    if t.dim() != 4 or t.dtype != torch.float32 or coords.dim() != 4 or coords.shape[-1] != 2 or coords.shape[1] != coords.shape[2]:
+        raise ValueError("sample_panels expects a float32 [M, C, H, W] map and [Nc, S, S, 2] coordinates")
+    lib = load()
+    M, C, H, W = t.shape
+    S = int(coords.shape[1])
+    N = M if index is None else int(index.numel())
+    if C != pset.C or S * S != pset.P or first < 0 or first + N > pset.images:
+        raise ValueError("sample_panels: the panel set holds %d images of %d x %d" % (pset.images, pset.P, pset.C))
+    for o, shape in ((rows_out, (N, S * S, C)), (inv_out, (N, S * S))):
+        if o is not None and (tuple(o.shape) != shape or not o.is_contiguous() or o.dtype != torch.float32):
+            raise ValueError("sample_panels: optional outputs are contiguous float32 %s" % (shape,))
+    coords = coords.contiguous().float()
+    if index is not None:
+        index = index.contiguous().to(torch.int64)
+    m = _map(t)
+    with _on_device(t.device):
+        _check(lib.stego_sample_panels(byref(m), _ptr(index) if index is not None else None, N, C, H, W, _ptr(coords), int(coords.shape[0]), S,
+                                       1 if normalize else 0, pset.panels.data_ptr() + first * pset.image_bytes, _ptr(pset.row_scale[first:]),
+                                       _ptr(rows_out) if rows_out is not None else None, _ptr(inv_out) if inv_out is not None else None, _stream()))
+
+
+def dense_corr_panels(pa, images_a, pb, N, want_rowsum=False):
+    """out[n] = (image n % images_a of pa) . (image n of pb)^T, [N, P, P] fp32: tensor_correlation (modules.py:283-284) of one set of anchors
+    against the second operands of N / images_a pair-sets.  want_rowsum: also returns sum_j out[n, i, j] as [N * P]."""
+    lib = load()
+    if pa.C != pb.C or images_a > pa.images or N > pb.images or images_a < 1 or N < 1:
+        raise ValueError("dense_corr_panels: operand sets do not match")
+    out = torch.empty(N, pa.P, pb.P, dtype=torch.float32, device=pa.panels.device)
+    rowsum = torch.empty(N * pa.P, dtype=torch.float32, device=out.device) if want_rowsum else None
+    with _on_device(out.device):
+        _check(lib.stego_dense_corr_panels(_ptr(pa.panels), _ptr(pa.row_scale), images_a, _ptr(pb.panels), _ptr(pb.row_scale), N, pa.C, pa.P, pb.P,
+                                           _ptr(out), _ptr(rowsum), _stream()))
+    return (out, rowsum) if want_rowsum else out
 
 
 # ------------------------------------------------------------------ segmentation head (include/stego_head.h)

@@ -7,6 +7,7 @@
 #include "corr_common.h"
 #include "host_util.h"
 #include "../../include/stego_head.h"
+#include "corr_wide.h"
 
 namespace stego {
 hipError_t launch_corr_sample(const SampleParams& prm, int precision, hipStream_t stream);
@@ -28,6 +29,9 @@ hipError_t launch_ref_masks(unsigned long long seed, unsigned long long offset, 
                             int variant, int n_masks, long long numel, float keep_prob, int cus, int threads_per_cu, float* out,
                             hipStream_t stream);
 size_t dense_workspace_bytes(int B, int C, int M, int N);
+hipError_t launch_dense_corr_panels(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
+                                    float* out, float* rowsum, hipStream_t stream);
+size_t dense_panel_image_bytes(int C, int P);
 hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize,
                              float* out, void* ws, hipStream_t stream);
 size_t knn_workspace_bytes(long long N, int D, int k, long long q_count);
@@ -70,8 +74,9 @@ int check_desc(const StegoCorrDesc* d, bool helper)
         if ((int64_t)d->H * d->W > TP) return STEGO_ERR_UNSUPPORTED;
     } else {
         if (d->S <= 0 || d->n_neg < 0) return STEGO_ERR_SHAPE;
-        if (d->S * d->S > TP) return STEGO_ERR_UNSUPPORTED;
+        if (d->S > 16) return STEGO_ERR_UNSUPPORTED;
         if (d->n_neg + 2 > 256) return STEGO_ERR_UNSUPPORTED;
+        if (d->S * d->S > TP && !wide_supported(d->B, d->C, d->K, d->S, d->n_neg)) return STEGO_ERR_UNSUPPORTED;   /* 129 .. 256 points: corr_wide.hip */
     }
     if (d->precision != STEGO_PREC_F32 && d->precision != STEGO_PREC_F16X3) return STEGO_ERR_UNSUPPORTED;
     if (d->flags & ~STEGO_FLAG_SHARED_DEVICE) return STEGO_ERR_UNSUPPORTED;
@@ -129,6 +134,37 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
 }
 
 int hip_rc(hipError_t e) { return e == hipSuccess ? STEGO_OK : STEGO_ERR_HIP + (int)e; }
+
+// feature_samples 12 .. 16: more points than one tile holds - the multi-launch path of corr_wide.hip behind the same entry points
+bool is_wide(const StegoCorrDesc* d) { return d->S * d->S > TP; }
+WideGeom wide_geom(const StegoCorrDesc* d) { return wide_geometry(d->B, d->C, d->K, d->S, d->n_neg); }
+
+int wide_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code, const StegoMap* code_pos,
+             const float* coords1, const float* coords2, const int64_t* perms, float* loss_means, float* pos_intra_cd, float* pos_inter_cd,
+             float* neg_inter_loss, float* neg_inter_cd, float* saved_w, float* saved_mean, void* saved_ctx, void* workspace,
+             size_t workspace_bytes, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (!workspace || !coords1 || !coords2 || !loss_means || !pos_intra_cd || !pos_inter_cd) return STEGO_ERR_NULL;
+    if (d->n_neg > 0 && (!perms || !neg_inter_loss || !neg_inter_cd)) return STEGO_ERR_NULL;
+    if ((saved_w == nullptr) != (saved_mean == nullptr)) return STEGO_ERR_NULL;
+    if (workspace_bytes < wide_geom(d).ws_bytes) return STEGO_ERR_WORKSPACE;
+    const StegoMap* maps[4] = {feats, feats_pos, code, code_pos};
+    for (const StegoMap* m : maps) {
+        if (!m || !m->data) return STEGO_ERR_NULL;
+        if (!aligned4(m->data)) return STEGO_ERR_ALIGN;
+    }
+    WideFwdArgs a{};
+    a.feats = feats; a.feats_pos = feats_pos; a.code = code; a.code_pos = code_pos;
+    a.coords1 = coords1; a.coords2 = coords2; a.perms = reinterpret_cast<const long long*>(perms);
+    a.loss_means = loss_means; a.intra_cd = pos_intra_cd; a.inter_cd = pos_inter_cd; a.neg_loss = neg_inter_loss; a.neg_cd = neg_inter_cd;
+    a.saved_w = saved_w; a.saved_mean = saved_mean; a.saved_ctx = saved_ctx; a.workspace = workspace;
+    a.B = d->B; a.C = d->C; a.K = d->K; a.H = d->H; a.W = d->W; a.S = d->S; a.n_neg = d->n_neg; a.pointwise = d->pointwise ? 1 : 0;
+    a.cmin = d->zero_clamp ? 0.0f : -9999.0f;
+    a.cmax = d->stabalize ? 0.8f : std::numeric_limits<float>::infinity();
+    a.shift[0] = d->pos_intra_shift; a.shift[1] = d->pos_inter_shift; a.shift[2] = d->neg_inter_shift;
+    return hip_rc(launch_wide_fwd(a, stream));
+}
 
 // Measurement knobs: host_util.h (read from the environment once at load; tools flip them with stego_debug_set).
 
@@ -313,7 +349,7 @@ const char* stego_error_string(int code)
         case STEGO_OK: return "ok";
         case STEGO_ERR_NULL: return "required pointer is NULL";
         case STEGO_ERR_SHAPE: return "bad or inconsistent dimension";
-        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S*S<=128, K<=128 (K>72: channels-last maps with C = 192 / 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
+        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S<=16 (S*S>128: K<=88), K<=128 (K>72: channels-last maps with C = 192 / 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
         case STEGO_ERR_WORKSPACE: return "workspace too small";
         case STEGO_ERR_ALIGN: return "pointer not 4-byte aligned";
         default: return code >= STEGO_ERR_HIP ? "HIP runtime error (code - 1000 = hipError_t)" : "unknown error";
@@ -323,12 +359,13 @@ const char* stego_error_string(int code)
 size_t stego_corr_workspace_bytes(const StegoCorrDesc* desc)
 {
     if (check_desc(desc, false) != STEGO_OK) return 0;
+    if (is_wide(desc)) return wide_geom(desc).ws_bytes;
     return geometry(desc, false).ws_bytes;
 }
 
 const uint32_t* stego_corr_event_counters(const StegoCorrDesc* desc, const void* workspace, size_t workspace_bytes)
 {
-    if (check_desc(desc, false) != STEGO_OK || !workspace) return nullptr;
+    if (check_desc(desc, false) != STEGO_OK || !workspace || is_wide(desc)) return nullptr;      // (no hand-off words in the multi-launch path)
     const Geometry g = geometry(desc, false);
     if (workspace_bytes < g.ws_bytes) return nullptr;
     // the block of the done counter (plan_fwd: sync + sync_bytes - 256): word 0 is the counter, words 1-2 the events
@@ -338,12 +375,14 @@ const uint32_t* stego_corr_event_counters(const StegoCorrDesc* desc, const void*
 size_t stego_corr_saved_ctx_bytes(const StegoCorrDesc* desc)
 {
     if (check_desc(desc, false) != STEGO_OK) return 0;
+    if (is_wide(desc)) return wide_geom(desc).ctx_bytes;
     return geometry(desc, false).ctx_bytes;
 }
 
 size_t stego_corr_bwd_workspace_bytes(const StegoCorrDesc* desc)
 {
     if (check_desc(desc, false) != STEGO_OK) return 0;
+    if (is_wide(desc)) return wide_geom(desc).bwd_ws_bytes;
     return geometry(desc, false).bwd_ws_bytes;
 }
 
@@ -372,9 +411,13 @@ int stego_corr_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap
                    size_t workspace_bytes, stego_stream_t stream)
 {
     FwdPlan pl;
-    int rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
-                      pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
-                      workspace_bytes, &pl);
+    int rc = check_desc(d, false);
+    if (rc) return rc;
+    if (is_wide(d)) return wide_fwd(d, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd, pos_inter_cd, neg_inter_loss,
+                                    neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
+                  pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
+                  workspace_bytes, &pl);
     if (rc) return rc;
     return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr));
 }
@@ -463,6 +506,7 @@ int stego_corr_fwd_launches(const StegoCorrDesc* d, const StegoMap* feats, const
     int rc = check_desc(d, false);
     if (rc) return -rc;
     if (!feats || !feats_pos || !code || !code_pos) return -STEGO_ERR_NULL;
+    if (is_wide(d)) return 5 + 2 * (d->n_neg > 0 ? 3 : 2);        // corr_wide.hip: samplers x 2 x (2 or 3), two correlations, three elementwise
     const Geometry g = geometry(d, false);
     FusedParams fp{};
     if ((rc = to_mapv(feats, d->C, d->H, d->W, &fp.feats)) || (rc = to_mapv(feats_pos, d->C, d->H, d->W, &fp.feats_pos)) ||
@@ -480,6 +524,7 @@ int stego_corr_workspace_prepare(const StegoCorrDesc* d, void* workspace, size_t
     int rc = check_desc(d, false);
     if (rc) return rc;
     if (!workspace) return STEGO_ERR_NULL;
+    if (is_wide(d)) return workspace_bytes < wide_geom(d).ws_bytes ? STEGO_ERR_WORKSPACE : STEGO_OK;       // nothing to prepare
     const Geometry g = geometry(d, false);
     if (workspace_bytes < g.ws_bytes) return STEGO_ERR_WORKSPACE;
     // the hand-off words sit right behind the per-tile sums (plan_fwd carves the same way)
@@ -506,9 +551,13 @@ int stego_corr_fwd_prepared(const StegoCorrDesc* d, const StegoMap* feats, const
                             size_t workspace_bytes, stego_stream_t stream)
 {
     FwdPlan pl;
-    int rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
-                      pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
-                      workspace_bytes, &pl);
+    int rc = check_desc(d, false);
+    if (rc) return rc;
+    if (is_wide(d)) return wide_fwd(d, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd, pos_inter_cd, neg_inter_loss,
+                                    neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
+                  pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
+                  workspace_bytes, &pl);
     if (rc) return rc;
     return hip_rc(run_fwd(pl, static_cast<hipStream_t>(stream), nullptr, true));
 }
@@ -521,6 +570,29 @@ int stego_corr_fwd_profile(const StegoCorrDesc* d, const StegoMap* feats, const 
                            int32_t iters, float* ms_kernels /* [3] */)
 {
     if (!ms_kernels || iters <= 0) return STEGO_ERR_NULL;
+    if (d && check_desc(d, false) == STEGO_OK && is_wide(d)) {
+        // the multi-launch path: the whole forward between two events, reported in the slot of the tile kernel
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        hipEvent_t ev[2];
+        hipError_t e;
+        for (int i = 0; i < 2; ++i)
+            if ((e = hipEventCreate(&ev[i])) != hipSuccess) return hip_rc(e);
+        double acc = 0.0;
+        int rc = STEGO_OK;
+        for (int i = 0; i < iters && rc == STEGO_OK; ++i) {
+            (void)hipEventRecord(ev[0], s);
+            rc = wide_fwd(d, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd, pos_inter_cd, neg_inter_loss,
+                          neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace, workspace_bytes, s);
+            (void)hipEventRecord(ev[1], s);
+            if (rc == STEGO_OK) rc = hip_rc(hipEventSynchronize(ev[1]));
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+            acc += ms;
+        }
+        for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
+        ms_kernels[0] = 0.f; ms_kernels[1] = (float)(acc / iters); ms_kernels[2] = 0.f;
+        return rc;
+    }
     FwdPlan pl;
     int rc = plan_fwd(d, false, feats, feats_pos, code, code_pos, coords1, coords2, perms, loss_means, pos_intra_cd,
                       pos_inter_cd, neg_inter_loss, neg_inter_cd, saved_w, saved_mean, saved_ctx, workspace,
@@ -559,6 +631,18 @@ int stego_corr_bwd(const StegoCorrDesc* d, const int64_t* perms, const float* sa
     if (!saved_w || !saved_mean || !pos_intra_cd || !pos_inter_cd || !d_code || !d_code_pos) return STEGO_ERR_NULL;
     if (d->n_neg > 0 && (!perms || !neg_inter_cd)) return STEGO_ERR_NULL;
     if (g_neg_loss_stride < -1 || g_neg_loss_stride > 1) return STEGO_ERR_SHAPE;
+    if (is_wide(d)) {
+        if (!saved_ctx || !workspace) return STEGO_ERR_NULL;
+        if (workspace_bytes < wide_geom(d).bwd_ws_bytes) return STEGO_ERR_WORKSPACE;
+        WideBwdArgs a{};
+        a.perms = reinterpret_cast<const long long*>(perms);
+        a.saved_w = saved_w; a.saved_mean = saved_mean; a.saved_ctx = saved_ctx;
+        a.g_intra = g_intra; a.g_inter = g_inter; a.g_neg = g_neg_loss; a.g_neg_stride = g_neg_loss_stride;
+        a.g_intra_cd = g_intra_cd; a.g_inter_cd = g_inter_cd; a.g_neg_cd = g_neg_cd;
+        a.d_code = d_code; a.d_code_pos = d_code_pos; a.workspace = workspace;
+        a.B = d->B; a.C = d->C; a.K = d->K; a.H = d->H; a.W = d->W; a.S = d->S; a.n_neg = d->n_neg;
+        return hip_rc(launch_wide_bwd(a, static_cast<hipStream_t>(stream)));
+    }
     BwdParams prm{};
     if ((rc = fill_bwd_ctx(d, false, saved_ctx, workspace, workspace_bytes, &prm))) return rc;
     prm.perms = reinterpret_cast<const long long*>(perms);
@@ -667,6 +751,23 @@ int stego_dense_corr(const StegoMap* a, const StegoMap* b, int32_t B, int32_t C,
     if ((rc = to_mapv(b, C, H2, W2, &mb))) return rc;
     return hip_rc(launch_dense_corr(ma, mb, B, C, H1, W1, H2, W2, normalize ? 1 : 0, out, workspace,
                                     static_cast<hipStream_t>(stream)));
+}
+
+size_t stego_panel_image_bytes(int32_t C, int32_t P)
+{
+    if (C <= 0 || P <= 0 || P > (1 << 24)) return 0;
+    return dense_panel_image_bytes(C, P);
+}
+
+int stego_dense_corr_panels(const void* panels_a, const float* row_scale_a, int32_t images_a, const void* panels_b, const float* row_scale_b,
+                            int32_t N, int32_t C, int32_t M, int32_t Ncols, float* out, float* rowsum, stego_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (N <= 0 || C <= 0 || M <= 0 || Ncols <= 0 || images_a <= 0) return STEGO_ERR_SHAPE;
+    if (M > (1 << 24) || Ncols > (1 << 24) || N > 65535) return STEGO_ERR_UNSUPPORTED;
+    if (!panels_a || !row_scale_a || !panels_b || !row_scale_b || !out) return STEGO_ERR_NULL;
+    if (reinterpret_cast<uintptr_t>(panels_a) % 16 != 0 || reinterpret_cast<uintptr_t>(panels_b) % 16 != 0) return STEGO_ERR_ALIGN;
+    return hip_rc(launch_dense_corr_panels(panels_a, row_scale_a, images_a, panels_b, row_scale_b, N, C, M, Ncols, out, rowsum, static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

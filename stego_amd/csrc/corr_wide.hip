@@ -1,0 +1,537 @@
+// ContrastiveCorrelationLoss for point sets larger than one 128 x 128 tile: cfg.feature_samples 12 .. 16 (144 .. 256 points per image) - gfx950.
+//
+//   reference: src/modules.py:349-398 (forward), :325-347 (helper), :275-295 (norm / tensor_correlation / sample); the autograd backward of
+//              the code side.  configs/train_config.yml:51 leaves feature_samples free; the reference's own value is 11, which the single-launch
+//              kernel of corr_fused.hip serves (S * S <= 128).
+//
+// The same C ABI (stego_corr_fwd / stego_corr_bwd, include/stego_corr.h) dispatches here when S * S > 128: the caller sees the same outputs and
+// the same saved tensors, only more launches.  Forward (11 launches):
+//   stego_sample_panels x 3   the sampled, L2-normalised FEATURES of all 2 + n_neg pair-sets as split-fp16 operand images (anchors: images [0, B);
+//                             orig_feats_pos at coords2: [B, 2 B); orig_feats[perm_k] at coords2 through an index: the rest) - the fp32 rows never exist
+//   dense_rowblock_kernel     fd[n] = anchors(n % B) . image(n)^T for all pair-sets in one launch, row sums on the way     -> saved_w (raw fd)
+//   stego_sample_panels x 3   the same for the CODES, keeping the normalised fp32 rows and 1 / |row| (saved context: the backward needs them)
+//   dense_rowblock_kernel     cd[n], written straight into the three cd outputs
+//   wide_set_mean_kernel      old_mean of every pair-set (modules.py:331) from the row sums                                -> saved_mean
+//   wide_pointwise_kernel     helper()'s elementwise part (:330-345) in place: loss (negative sets), the row sums of the loss of every set, and
+//                             w = fd - rowmean + old_mean - shift with the clamp's pass mask in its mantissa LSB             -> saved_w
+//   wide_loss_means_kernel    the three means the caller gets (:393-398)
+// Backward (6 launches + 2 memsets), wide_bwd_kernel: one workgroup per pair (set, image) walks its <= 2 x 2 tiles of G = -w * mask * upstream and
+// takes both adjoints of the code correlation on the fp16 matrix cores (split-fp16 x 3 like the forward): d anchors(n) = G . rows(n),
+// d rows(n) = G^T . anchors - G is staged once per tile in LDS and read along rows for the first, along columns for the second product.  Then
+// stego_sample_bwd_rows x 3: the backward of norm() and of the bilinear sampling, added into the two code gradients (fp32 atomics: the one place
+// in the library whose summation order is not fixed; the fused path for S <= 11 stays bitwise repeatable).
+#include "corr_common.h"
+#include "host_util.h"
+#include "../../include/stego_corr.h"
+#include "corr_wide.h"
+
+namespace stego {
+
+hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
+                                        float* out, float* out1, float* out2, int seg, float* rowsum, hipStream_t stream);                     // dense_corr.hip
+size_t dense_panel_image_bytes(int C, int P);
+hipError_t launch_sample_panels(const StegoMap* map, const long long* index, int N, int C, int H, int W, const float* coords, int n_coords, int S,
+                                int normalize, void* panels, float* row_scale, float* rows_out, float* inv_out, hipStream_t stream);         // sample_sets.hip
+hipError_t launch_sample_scatter(const float* g_rows, const float* rows_n, const float* inv, const StegoMap* d_map, const long long* index, int N, int C,
+                                 int H, int W, const float* coords, int n_coords, int S, const float* extra, int n_extra, long long extra_stride,
+                                 hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------ forward: the elementwise part
+struct WidePwParams {
+    float* fd;                  // [n_img][P][P] raw fd in, w (mask in the LSB) out - in place
+    const float* cd[3];         // the three cd outputs: images [0, B) | [B, 2 B) | [2 B, n_img)
+    const float* rowsum;        // [n_img][P]
+    float* mean;                // [n_sets] old_mean (zeros when not pointwise)
+    float* neg_loss;            // [n_img - 2 B][P][P]
+    float* lrowsum;             // [n_img][P] row sums of the loss
+    float* loss_means;          // [3]
+    float shift[3];
+    float cmin, cmax;
+    int n_sets, B, P, pointwise, keep_w;
+};
+
+// one workgroup per pair-set, a fixed summation order
+__global__ void __launch_bounds__(256) wide_set_mean_kernel(const WidePwParams p)
+{
+    __shared__ float red[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    if (p.pointwise) {
+        const float* r = p.rowsum + (size_t)s * p.B * p.P;
+        for (int i = tid; i < p.B * p.P; i += 256) acc += r[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) p.mean[s] = p.pointwise ? ((red[0] + red[1]) + (red[2] + red[3])) / ((float)p.B * (float)p.P * (float)p.P) : 0.f;
+}
+
+// one wave per row of one pair: modules.py:330-345
+__global__ void __launch_bounds__(256) wide_pointwise_kernel(const WidePwParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)p.n_sets * p.B * p.P;
+    const long long r = __builtin_amdgcn_readfirstlane((int)((long long)blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (r >= rows) return;
+    const int n = (int)(r / p.P);
+    const int s = n / p.B;
+    const float shift = p.shift[s < 2 ? s : 2];
+    const float rm = p.pointwise ? p.rowsum[r] / (float)p.P : 0.f;
+    const float om = p.pointwise ? p.mean[s] : 0.f;
+    float* fd = p.fd + r * p.P;
+    const float* cd = p.cd[s < 2 ? s : 2] + (r - (long long)(s < 2 ? s : 2) * p.B * p.P) * p.P;
+    float* nl = s >= 2 ? p.neg_loss + (r - 2ll * p.B * p.P) * p.P : nullptr;
+    float acc = 0.f;
+    for (int j = lane; j < p.P; j += 64) {
+        const float c = cd[j];
+        const float wv = ((fd[j] - rm) + om) - shift;
+        const float l = -fminf(fmaxf(c, p.cmin), p.cmax) * wv;
+        if (nl) nl[j] = l;
+        acc += l;
+        if (p.keep_w) {
+            // the backward's weight, the clamp's pass mask (inclusive, as torch's clamp backward) in the mantissa LSB
+            const unsigned b = (__builtin_bit_cast(unsigned, wv) & ~1u) | ((c >= p.cmin && c <= p.cmax) ? 1u : 0u);
+            fd[j] = __builtin_bit_cast(float, b);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) p.lrowsum[r] = acc;
+}
+
+// one workgroup: the three returned means (modules.py:393-398) in a fixed order
+__global__ void __launch_bounds__(1024) wide_loss_means_kernel(const WidePwParams p)
+{
+    __shared__ float red[3][16];
+    const int tid = threadIdx.x;
+    const int per = p.B * p.P;
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int q = 0; q < 3; ++q) {
+        const int beg = q * per, end = q < 2 ? (q + 1) * per : p.n_sets * per;
+        for (int i = beg + tid; i < end; i += 1024) a[q] += p.lrowsum[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a[q] += __shfl_xor(a[q], m, 64);
+        if ((tid & 63) == 0) red[q][tid >> 6] = a[q];
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[tid][w];
+        const float cnt = (float)p.B * (float)p.P * (float)p.P;
+        p.loss_means[tid] = tid < 2 ? t / cnt : (p.n_sets > 2 ? t / (cnt * (float)(p.n_sets - 2)) : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: both adjoints of the code correlation
+constexpr int WB_GS = 132;      // floats per row of the G tile (528 B: conflict-free 16-byte reads along a row, column walks hit 64 banks)
+constexpr int WB_TS = 136;      // halves per row of a transposed code tile [channel][128 points] (272 B: conflict-free 16-byte reads)
+constexpr int WB_MAXNB = 2;     // point blocks per side: S * S <= 256
+constexpr int WB_MAXKB = 3;     // 32-channel blocks: K <= 88 (the tiles of both sides + G in 160 KB of LDS)
+
+struct WideBwdParams {
+    const float* w;             // saved_w [n_img][P][P]
+    const float* cn;            // [n_img][P][K] normalised sampled codes
+    const unsigned char* tiles; // [n_img][nb] code tiles, transposed and split: hi [Kr][WB_TS] | lo [Kr][WB_TS] fp16 of CSCALE * cn, tile_bytes each
+    unsigned char* tiles_out;   // (wide_code_tiles_kernel)
+    int tile_bytes;
+    const float* g_intra;       // device scalars: upstreams of loss_means[0 .. 1] (null: 0)
+    const float* g_inter;
+    const float* g_neg;         // upstream of the negative losses, see g_neg_stride (null: 0)
+    const float* g_cd[3];       // optional dense upstreams of the three cd outputs
+    float* d_rows;              // [n_img][P][K] gradient of image n's rows as the second operand of pair n
+    float* d_anchor;            // [n_img][P][K] gradient of the anchors (image n % B) from pair n
+    int g_neg_stride;           // 1 dense [n_neg B][P][P], 0 one scalar per element, -1 one scalar = the upstream of loss_means[2]
+    int B, P, K, Kr, n_sets;
+};
+
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, f16x8& hi, f16x8& lo)
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_f16_pair(v[2 * q] * scale, v[2 * q + 1] * scale, h[q], l[q]);
+    typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(f16x8, du32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(f16x8, du32x4{l[0], l[1], l[2], l[3]});
+}
+
+constexpr float WB_CSCALE = 16.f;     // the normalised codes (|x| <= 1) times 16: their lo parts leave the fp16 subnormals
+
+__device__ __forceinline__ void wide_dma_piece(const unsigned char* gsrc_lane, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+}
+
+// The operands of the backward's GEMMs that come from the codes, once per backward: tile (image, 128-point block) = the block's normalised rows
+// TRANSPOSED ([channel][point]: a fragment of either product is then 8 consecutive points of one channel = one 16-byte LDS read) and split
+// into fp16 hi | lo, in the layout the GEMM kernel keeps in LDS - staging a tile there is a linear LDS-DMA copy.
+__global__ void __launch_bounds__(256) wide_code_tiles_kernel(const WideBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int nbp = (p.P + TP - 1) / TP;
+    const int img = blockIdx.x / nbp, blk = blockIdx.x - img * nbp;
+    const int P = p.P, K = p.K, Kr = p.Kr, p0 = blk * TP;
+    half_t* T = reinterpret_cast<half_t*>(smem);
+    for (int i = tid; i < p.tile_bytes / 16; i += 256) reinterpret_cast<du32x4*>(smem)[i] = du32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const float* src = p.cn + ((size_t)img * P + p0) * K;
+    const int rows = min(TP, P - p0);
+    constexpr int UN = 8;
+    for (int base = 0; base < rows * K; base += 256 * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int idx = base + u * 256 + tid;
+            v[u] = idx < rows * K ? src[idx] : 0.f;                     // (rows of a block are contiguous: [point][K])
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < rows * K) {
+                const int jl = idx / K, k = idx - jl * K;
+                unsigned hh, ll;
+                split_f16_pair(v[u] * WB_CSCALE, 0.f, hh, ll);
+                reinterpret_cast<unsigned short*>(T)[k * WB_TS + jl] = (unsigned short)(hh & 0xffffu);
+                reinterpret_cast<unsigned short*>(T + Kr * WB_TS)[k * WB_TS + jl] = (unsigned short)(ll & 0xffffu);
+            }
+        }
+    }
+    __syncthreads();
+    du32x4* dst = reinterpret_cast<du32x4*>(p.tiles_out + (size_t)blockIdx.x * p.tile_bytes);
+    for (int i = tid; i < p.tile_bytes / 16; i += 256) dst[i] = reinterpret_cast<const du32x4*>(smem)[i];
+}
+
+__global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Gs = reinterpret_cast<float*>(smem);                                       // [128][WB_GS]
+    half_t* Ta = reinterpret_cast<half_t*>(smem + 128 * WB_GS * 4);                   // anchors' tile: hi [Kr][WB_TS] | lo
+    half_t* Tb = reinterpret_cast<half_t*>(smem + 128 * WB_GS * 4 + p.tile_bytes);   // the second operand's tile
+    float* red = Gs;                                                                  // (the first pass over G below: before any tile is staged)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x, P = p.P, K = p.K, Kr = p.Kr;
+    const int s = n / p.B, na = n - s * p.B;
+    const int nbp = (P + TP - 1) / TP, NK = (Kr + 31) >> 5;
+    const float cnt = (float)p.B * (float)P * (float)P;
+    // the scalar part of the upstream of this pair's loss elements
+    float up = 0.f;
+    if (s == 0) up = p.g_intra ? p.g_intra[0] / cnt : 0.f;
+    else if (s == 1) up = p.g_inter ? p.g_inter[0] / cnt : 0.f;
+    else if (p.g_neg && p.g_neg_stride <= 0) up = p.g_neg_stride == 0 ? p.g_neg[0] : p.g_neg[0] / (cnt * (float)(p.n_sets - 2));
+    const float* gneg = (s >= 2 && p.g_neg && p.g_neg_stride == 1) ? p.g_neg + (size_t)(n - 2 * p.B) * P * P : nullptr;
+    const float* gcd = p.g_cd[s < 2 ? s : 2] ? p.g_cd[s < 2 ? s : 2] + (size_t)(n - (s < 2 ? s : 2) * p.B) * P * P : nullptr;
+    const float* wn = p.w + (size_t)n * P * P;
+    auto g_of = [&](int i, int j, float wv) {
+        float u = up;
+        if (gneg) u += gneg[(size_t)i * P + j];
+        float g = (__builtin_bit_cast(unsigned, wv) & 1u) ? -(wv * u) : 0.f;
+        if (gcd) g += gcd[(size_t)i * P + j];
+        return g;
+    };
+    // one power-of-two scale for G so that its fp16 hi / lo parts stay in the normal range: |w| < 8 bounds the scalar case; dense upstreams take a
+    // pass over the pair's G first
+    float gmax = fabsf(up) * 8.f;
+    if (gneg || gcd) {
+        float m = 0.f;
+        for (int idx = tid; idx < P * P; idx += 256) {
+            const int i = idx / P, j = idx - i * P;
+            m = fmaxf(m, fabsf(g_of(i, j, wn[idx])));
+        }
+#pragma unroll
+        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float gscale = gmax > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(gmax)) : 1.f;
+    const float unscale = 1.f / (gscale * WB_CSCALE);
+
+    // a prepared code tile into LDS: linear LDS-DMA, 1 KB per wave instruction (asynchronous: waited for with the G tile's barrier)
+    const unsigned smem_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)smem);
+    auto stage_codes = [&](const half_t* T, int img, int blk) {
+        const unsigned char* src = p.tiles + ((size_t)img * nbp + blk) * p.tile_bytes + lane * 16;
+        const unsigned dst = smem_addr + (unsigned)(reinterpret_cast<const unsigned char*>(T) - smem);
+        for (int pc = wave; pc < p.tile_bytes / 1024; pc += 4) wide_dma_piece(src + pc * 1024, dst + pc * 1024);
+    };
+
+    f32x16 accB[WB_MAXNB][WB_MAXKB];
+#pragma unroll
+    for (int a = 0; a < WB_MAXNB; ++a)
+#pragma unroll
+        for (int b = 0; b < WB_MAXKB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accB[a][b][e] = 0.f;
+
+    for (int mi = 0; mi < nbp; ++mi) {
+        f32x16 accA[WB_MAXKB];
+#pragma unroll
+        for (int b = 0; b < WB_MAXKB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accA[b][e] = 0.f;
+#pragma unroll
+        for (int nj = 0; nj < WB_MAXNB; ++nj) {
+            if (nj < nbp) {
+                __syncthreads();                                        // the previous tile's fragments are read
+                if (nj == 0) stage_codes(Ta, na, mi);
+                stage_codes(Tb, n, nj);
+                // G tile (mi, nj): rows i0 .. + 127 of the anchors, columns j0 .. + 127 of the second operand; all of a thread's loads of a
+                // half tile in flight at once
+                const int i0 = mi * TP, j0 = nj * TP;
+                const int jl = 4 * (tid & 31);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x4 wv[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int il = (tid >> 5) + 8 * (8 * hf + it);
+                        wv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (i0 + il < P) {
+                            const float* wr = wn + (size_t)(i0 + il) * P + j0 + jl;
+                            if ((P & 3) == 0) {
+                                if (j0 + jl < P) wv[it] = *reinterpret_cast<const f32x4*>(wr);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (j0 + jl + q < P) wv[it][q] = wr[q];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int il = (tid >> 5) + 8 * (8 * hf + it);
+                        f32x4 g4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (i0 + il < P) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (j0 + jl + q < P) g4[q] = g_of(i0 + il, j0 + jl + q, wv[it][q]);
+                        }
+                        *reinterpret_cast<f32x4*>(Gs + il * WB_GS + jl) = g4;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the code tiles' copies
+                __syncthreads();
+                // ---- d anchors: rows i (32 per wave) x channels, contraction over the tile's columns j
+#pragma unroll 2
+                for (int ks = 0; ks < TP / 16; ++ks) {
+                    float gv[8];
+                    const float* gp = Gs + (32 * wave + r) * WB_GS + 16 * ks + 8 * h;
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { gv[q] = g0[q]; gv[4 + q] = g1[q]; }
+                    f16x8 ah, al;
+                    split8(gv, gscale, ah, al);
+#pragma unroll
+                    for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                        if (kb < NK) {
+                            const bool kv = 32 * kb + r < Kr;
+                            const half_t* tp = Tb + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
+                            f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
+                            if (!kv) { bh = f16x8{}; bl = f16x8{}; }
+                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accA[kb], 0, 0, 0);
+                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accA[kb], 0, 0, 0);
+                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accA[kb], 0, 0, 0);
+                        }
+                    }
+                }
+                // ---- d rows of the second operand: rows j (32 per wave) x channels, contraction over the tile's rows i: G read along columns
+#pragma unroll 2
+                for (int ks = 0; ks < TP / 16; ++ks) {
+                    float gv[8];
+                    const float* gp = Gs + (16 * ks + 8 * h) * WB_GS + 32 * wave + r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[e] = gp[e * WB_GS];
+                    f16x8 ah, al;
+                    split8(gv, gscale, ah, al);
+#pragma unroll
+                    for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                        if (kb < NK) {
+                            const bool kv = 32 * kb + r < Kr;
+                            const half_t* tp = Ta + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
+                            f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
+                            if (!kv) { bh = f16x8{}; bl = f16x8{}; }
+                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accB[nj][kb], 0, 0, 0);
+                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accB[nj][kb], 0, 0, 0);
+                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accB[nj][kb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // the anchors' rows of block mi are complete.  C/D layout: column (channel) = lane & 31 (+ 32 kb), row = (e & 3) + 8 (e >> 2) + 4 h
+        float* da = p.d_anchor + (size_t)n * P * K;
+#pragma unroll
+        for (int kb = 0; kb < WB_MAXKB; ++kb) {
+            const int k = 32 * kb + r;
+            if (kb < NK && k < K) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = mi * TP + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (i < P) da[(size_t)i * K + k] = accA[kb][e] * unscale;
+                }
+            }
+        }
+    }
+    float* dr = p.d_rows + (size_t)n * P * K;
+#pragma unroll
+    for (int nj = 0; nj < WB_MAXNB; ++nj) {
+        if (nj < nbp) {
+#pragma unroll
+            for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                const int k = 32 * kb + r;
+                if (kb < NK && k < K) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int j = nj * TP + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (j < P) dr[(size_t)j * K + k] = accB[nj][kb][e] * unscale;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool wide_supported(int B, int C, int K, int S, int n_neg)
+{
+    const int P = S * S;
+    return P > TP && P <= WB_MAXNB * TP && K <= 32 * WB_MAXKB - 8 && B >= 1 && C >= 1 && n_neg >= 0 &&
+           (long long)(2 + n_neg) * B <= 65535 && (long long)(2 + n_neg) * B * P < (1ll << 31) / 4;
+}
+
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+WideGeom wide_geometry(int B, int C, int K, int S, int n_neg)
+{
+    WideGeom g;
+    g.n_sets = 2 + n_neg;
+    g.n_img = g.n_sets * B;
+    g.P = S * S;
+    g.nb = (g.P + TP - 1) / TP;
+    g.Kr = (K + 7) & ~7;
+    g.fimg = dense_panel_image_bytes(C, g.P);
+    g.cimg = dense_panel_image_bytes(K, g.P);
+    const size_t rows = (size_t)g.n_img * g.P;
+    g.c_cn = 0;
+    g.c_inv = up256(rows * K * 4);
+    g.c_co1 = g.c_inv + up256(rows * 4);
+    g.c_co2 = g.c_co1 + up256((size_t)B * g.P * 8);
+    g.ctx_bytes = g.c_co2 + up256((size_t)B * g.P * 8);
+    size_t o = 0;
+    g.o_fpan = o; o += up256((size_t)g.n_img * g.fimg);
+    g.o_frs = o; o += up256((size_t)g.n_img * g.nb * TP * 4);
+    g.o_cpan = o; o += up256((size_t)g.n_img * g.cimg);
+    g.o_crs = o; o += up256((size_t)g.n_img * g.nb * TP * 4);
+    g.o_rowsum = o; o += up256(rows * 4);
+    g.o_lrowsum = o; o += up256(rows * 4);
+    g.o_mean = o; o += 256;
+    g.o_fd = o; o += up256(rows * g.P * 4);                 // fd when the caller keeps nothing for a backward
+    g.o_ctx = o; o += g.ctx_bytes;                          // the context likewise
+    g.ws_bytes = o + 256;
+    g.tile_bytes = (2 * g.Kr * WB_TS * 2 + 1023) / 1024 * 1024;
+    g.b_rows = 0;
+    g.b_anchor = up256(rows * K * 4);
+    g.b_tiles = g.b_anchor + up256(rows * K * 4);
+    g.bwd_ws_bytes = g.b_tiles + up256((size_t)g.n_img * g.nb * g.tile_bytes) + 256;
+    return g;
+}
+
+hipError_t launch_wide_fwd(const WideFwdArgs& a, hipStream_t stream)
+{
+    const WideGeom g = wide_geometry(a.B, a.C, a.K, a.S, a.n_neg);
+    unsigned char* ws = static_cast<unsigned char*>(a.workspace);
+    ws += (256 - (reinterpret_cast<uintptr_t>(ws) & 255)) & 255;
+    unsigned char* ctx = a.saved_ctx ? static_cast<unsigned char*>(a.saved_ctx) : ws + g.o_ctx;
+    float* fd = a.saved_w ? a.saved_w : reinterpret_cast<float*>(ws + g.o_fd);
+    float* mean = a.saved_mean ? a.saved_mean : reinterpret_cast<float*>(ws + g.o_mean);
+    float* cn = reinterpret_cast<float*>(ctx + g.c_cn);
+    float* inv = reinterpret_cast<float*>(ctx + g.c_inv);
+    float* rowsum = reinterpret_cast<float*>(ws + g.o_rowsum);
+    const int B = a.B, P = g.P, nnb = a.n_neg * B;
+    hipError_t e;
+    // the bilinear coordinates travel with the context: the backward is given the permutations only
+    if ((e = hipMemcpyAsync(ctx + g.c_co1, a.coords1, (size_t)B * P * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(ctx + g.c_co2, a.coords2, (size_t)B * P * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    struct Src { const StegoMap* f; const StegoMap* c; const float* co; const long long* idx; int first, n; };
+    const Src src[3] = {{a.feats, a.code, a.coords1, nullptr, 0, B}, {a.feats_pos, a.code_pos, a.coords2, nullptr, B, B},
+                        {a.feats, a.code, a.coords2, a.perms, 2 * B, nnb}};
+    float* frs = reinterpret_cast<float*>(ws + g.o_frs);
+    float* crs = reinterpret_cast<float*>(ws + g.o_crs);
+    for (const Src& q : src) {
+        if (q.n == 0) continue;
+        if ((e = launch_sample_panels(q.f, q.idx, q.n, a.C, a.H, a.W, q.co, B, a.S, 1, ws + g.o_fpan + (size_t)q.first * g.fimg,
+                                      frs + (size_t)q.first * g.nb * TP, nullptr, nullptr, stream)) != hipSuccess) return e;
+    }
+    if ((e = launch_dense_corr_panels_seg(ws + g.o_fpan, frs, B, ws + g.o_fpan, frs, g.n_img, a.C, P, P, fd, nullptr, nullptr, 0,
+                                          a.pointwise ? rowsum : nullptr, stream)) != hipSuccess) return e;
+    for (const Src& q : src) {
+        if (q.n == 0) continue;
+        if ((e = launch_sample_panels(q.c, q.idx, q.n, a.K, a.H, a.W, q.co, B, a.S, 1, ws + g.o_cpan + (size_t)q.first * g.cimg,
+                                      crs + (size_t)q.first * g.nb * TP, cn + (size_t)q.first * P * a.K, inv + (size_t)q.first * P, stream)) != hipSuccess) return e;
+    }
+    if ((e = launch_dense_corr_panels_seg(ws + g.o_cpan, crs, B, ws + g.o_cpan, crs, g.n_img, a.K, P, P, a.intra_cd, a.inter_cd, a.neg_cd, B,
+                                          nullptr, stream)) != hipSuccess) return e;
+    WidePwParams p{};
+    p.fd = fd; p.cd[0] = a.intra_cd; p.cd[1] = a.inter_cd; p.cd[2] = a.neg_cd;
+    p.rowsum = rowsum; p.mean = mean; p.neg_loss = a.neg_loss;
+    p.lrowsum = reinterpret_cast<float*>(ws + g.o_lrowsum);
+    p.loss_means = a.loss_means;
+    p.shift[0] = a.shift[0]; p.shift[1] = a.shift[1]; p.shift[2] = a.shift[2];
+    p.cmin = a.cmin; p.cmax = a.cmax;
+    p.n_sets = g.n_sets; p.B = B; p.P = P; p.pointwise = a.pointwise; p.keep_w = a.saved_w ? 1 : 0;
+    hipLaunchKernelGGL(wide_set_mean_kernel, dim3(g.n_sets), dim3(256), 0, stream, p);
+    const long long rows = (long long)g.n_img * P;
+    hipLaunchKernelGGL(wide_pointwise_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(wide_loss_means_kernel, dim3(1), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
+{
+    const WideGeom g = wide_geometry(a.B, a.C, a.K, a.S, a.n_neg);
+    unsigned char* ws = static_cast<unsigned char*>(a.workspace);
+    ws += (256 - (reinterpret_cast<uintptr_t>(ws) & 255)) & 255;
+    const unsigned char* ctx = static_cast<const unsigned char*>(a.saved_ctx);
+    const float* cn = reinterpret_cast<const float*>(ctx + g.c_cn);
+    const float* inv = reinterpret_cast<const float*>(ctx + g.c_inv);
+    const float* co1 = reinterpret_cast<const float*>(ctx + g.c_co1);
+    const float* co2 = reinterpret_cast<const float*>(ctx + g.c_co2);
+    const int B = a.B, P = g.P, K = a.K, nnb = a.n_neg * B;
+    hipError_t e;
+    const size_t map_bytes = (size_t)B * a.H * a.W * K * 4;
+    if ((e = hipMemsetAsync(a.d_code, 0, map_bytes, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.d_code_pos, 0, map_bytes, stream)) != hipSuccess) return e;
+    WideBwdParams p{};
+    p.w = a.saved_w; p.cn = cn;
+    p.g_intra = a.g_intra; p.g_inter = a.g_inter; p.g_neg = a.g_neg; p.g_neg_stride = a.g_neg_stride;
+    p.g_cd[0] = a.g_intra_cd; p.g_cd[1] = a.g_inter_cd; p.g_cd[2] = a.g_neg_cd;
+    p.d_rows = reinterpret_cast<float*>(ws + g.b_rows);
+    p.d_anchor = reinterpret_cast<float*>(ws + g.b_anchor);
+    p.B = B; p.P = P; p.K = K; p.Kr = g.Kr; p.n_sets = g.n_sets;
+    p.tiles_out = ws + g.b_tiles;
+    p.tiles = p.tiles_out;
+    p.tile_bytes = g.tile_bytes;
+    if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_code_tiles_kernel), g.tile_bytes)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb), dim3(256), g.tile_bytes, stream, p);
+    const int lds = 128 * WB_GS * 4 + 2 * g.tile_bytes;
+    if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_bwd_kernel), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(256), lds, stream, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the backward of norm() and of the sampling: anchors (their rows were the second operand of the intra set and the first of every set)
+    StegoMap dm{a.d_code, (int64_t)a.H * a.W * K, 1, (int64_t)a.W * K, K}, dmp{a.d_code_pos, (int64_t)a.H * a.W * K, 1, (int64_t)a.W * K, K};
+    const size_t rowsB = (size_t)B * P;
+    if ((e = launch_sample_scatter(p.d_rows, cn, inv, &dm, nullptr, B, K, a.H, a.W, co1, B, a.S, p.d_anchor, g.n_sets, (long long)rowsB * K,
+                                   stream)) != hipSuccess) return e;
+    if ((e = launch_sample_scatter(p.d_rows + rowsB * K, cn + rowsB * K, inv + rowsB, &dmp, nullptr, B, K, a.H, a.W, co2, B, a.S, nullptr, 0, 0,
+                                   stream)) != hipSuccess) return e;
+    if (nnb > 0 && (e = launch_sample_scatter(p.d_rows + 2 * rowsB * K, cn + 2 * rowsB * K, inv + 2 * rowsB, &dm, a.perms, nnb, K, a.H, a.W, co2, B, a.S,
+                                              nullptr, 0, 0, stream)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+}  // namespace stego

@@ -18,6 +18,8 @@
 
 namespace stego {
 
+hipError_t launch_rowsum(const float* x, float* out, long long rows, int P, hipStream_t stream);          // loss_pointwise.hip
+
 constexpr int DC_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] fp16
 
 struct DenseParams {
@@ -28,6 +30,11 @@ struct DenseParams {
     float* rsA;                 // [B][nbA*128] 1 / (power-of-two row scale) of the fp16 staging; rsB likewise
     float* rsB;
     int B, C, M, N, W1, W2, nbA, nbB, NCH, normalize;
+    float* out1;                // seg > 0: images [seg, 2 seg) go to out1, [2 seg, B) to out2 (the three cd outputs of the loss)
+    float* out2;
+    int seg;
+    float* rowsum;              // optional [B][M]: sum_j out[n][i][j] (row-block kernel with prepared A operands only: a workgroup sees whole rows)
+    int a_mod;                  // > 0: pair n multiplies the A image n % a_mod (one set of A operands against several sets of B: the pair-sets of the loss)
 };
 
 // grid = (B * (nbA + nbB)), block = 256 = 8 half-waves; a half-wave owns 16 of the block's 128 pixel rows, one at a time.
@@ -118,7 +125,8 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
     const int wr = wave >> 1, wc = wave & 1;
     const int nj = blockIdx.x, mi = blockIdx.y, n = blockIdx.z;
     const int NCH = prm.NCH;
-    const unsigned char* A = static_cast<const unsigned char*>(prm.imgA) + ((size_t)n * prm.nbA + mi) * NCH * DC_SIDE;
+    const int na = prm.a_mod > 0 ? n % prm.a_mod : n;
+    const unsigned char* A = static_cast<const unsigned char*>(prm.imgA) + ((size_t)na * prm.nbA + mi) * NCH * DC_SIDE;
     const unsigned char* Bm = static_cast<const unsigned char*>(prm.imgB) + ((size_t)n * prm.nbB + nj) * NCH * DC_SIDE;
     auto issue = [&](int c) {
         unsigned char* dst = smem + (c & 1) * (2 * DC_SIDE);
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
     }
     // ---- store: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* out = prm.out + (size_t)n * prm.M * prm.N;
-    const float* ra = prm.rsA + ((size_t)n * prm.nbA + mi) * TP;       // undo the rows' staging scales
+    const float* ra = prm.rsA + ((size_t)na * prm.nbA + mi) * TP;      // undo the rows' staging scales
     const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -200,6 +208,8 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
 // kernel runs for the B side only.
 constexpr int DR_NST = 3;
 constexpr int DR_MAXCH = 6;
+constexpr int DR_PKS = 68;        // floats per row of a wave's parked 32 x 64 half slab (272 B: conflict-free 16-byte reads along a row)
+static_assert(4 * 32 * DR_PKS * 4 <= DC_SIDE, "the parked half slabs of four waves fit one ring slot");
 static_assert(DC_SIDE % 4096 == 0, "whole 1 KB pieces per wave");
 __device__ __forceinline__ void dense_dma_piece(const unsigned char* gsrc_lane, unsigned lds_addr)
 {
@@ -208,10 +218,15 @@ __device__ __forceinline__ void dense_dma_piece(const unsigned char* gsrc_lane, 
                  : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
 }
 
+// APANELS (round 5): the A block is a prepared operand image too (stego_sample_panels wrote it: the sampled points of the loss) - the
+// fragments are 16-byte loads of its hi / lo planes.
+// NST = stages of the B ring: 3 (two copies in flight, one workgroup per CU) or 2 (one in flight, 74 KB: TWO workgroups per CU that hide each
+// other's copies and store drains - the loss's point sets, where a workgroup has 2 x 2 .. 2 x 6 chunks between 128 KB of stores).
+template <bool APANELS, int NST = 3>
 __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DenseParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* ra_s = reinterpret_cast<float*>(smem + DR_NST * DC_SIDE);        // [128] 1 / row scale of the A block
+    float* ra_s = reinterpret_cast<float*>(smem + NST * DC_SIDE);        // [128] 1 / row scale of the A block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NCH = prm.NCH, C = prm.C;
@@ -222,6 +237,24 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
     const int r = lane & 31, half = lane >> 5;
 
     // ---- my row of the A block -> MFMA fragments (lane (r, half) holds channels 16 ks + 8 half .. + 7 of every 64-channel chunk)
+    f16x8 Ah[DR_MAXCH][KC / 16], Al[DR_MAXCH][KC / 16];
+    if constexpr (APANELS) {
+        const int na = prm.a_mod > 0 ? n % prm.a_mod : n;
+        const half_t* ap = static_cast<const half_t*>(prm.imgA) + ((size_t)na * prm.nbA + mi) * NCH * (2 * TP * LDH) + (32 * wave + r) * LDH + 8 * half;
+        if (half == 0) ra_s[32 * wave + r] = prm.rsA[((size_t)na * prm.nbA + mi) * TP + 32 * wave + r];
+#pragma unroll
+        for (int c = 0; c < DR_MAXCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                if (c < NCH && !(prm.normalize & 1)) {
+                    Ah[c][ks] = *reinterpret_cast<const f16x8*>(ap + (size_t)c * (2 * TP * LDH) + 16 * ks);
+                    Al[c][ks] = *reinterpret_cast<const f16x8*>(ap + (size_t)c * (2 * TP * LDH) + TP * LDH + 16 * ks);
+                } else {
+                    Ah[c][ks] = f16x8{};
+                    Al[c][ks] = f16x8{};
+                }
+            }
+    } else {
     const int pix = mi * TP + 32 * wave + r;
     const bool rv = pix < prm.M;
     const int hh = rv ? pix / prm.W1 : 0, ww = rv ? pix - hh * prm.W1 : 0;
@@ -247,7 +280,6 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
     const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
     inv *= rs;
     if (half == 0) ra_s[32 * wave + r] = 1.f / rs;
-    f16x8 Ah[DR_MAXCH][KC / 16], Al[DR_MAXCH][KC / 16];
 #pragma unroll
     for (int c = 0; c < DR_MAXCH; ++c)
 #pragma unroll
@@ -264,6 +296,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
             Ah[c][ks] = __builtin_bit_cast(f16x8, du32x4{h[0], h[1], h[2], h[3]});
             Al[c][ks] = __builtin_bit_cast(f16x8, du32x4{l[0], l[1], l[2], l[3]});
         }
+    }
     __syncthreads();                                       // ra_s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the counted waits below start from zero
 
@@ -273,14 +306,18 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
     const int nstage = prm.nbB * NCH;
     auto issue = [&](int g) {
         const unsigned char* src = Bimg + (size_t)g * DC_SIDE + lane * 16;
-        const unsigned dst = smem_addr + (g % DR_NST) * DC_SIDE;
+        const unsigned dst = smem_addr + (g % NST) * DC_SIDE;
 #pragma unroll
         for (int i = 0; i < DC_SIDE / 4096; ++i) dense_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
     };
-    for (int s0 = 0; s0 < DR_NST - 1 && s0 < nstage; ++s0) issue(s0);
+    for (int s0 = 0; s0 < NST - 1 && s0 < nstage; ++s0) issue(s0);
     float* outn = prm.out + (size_t)n * prm.M * prm.N;
+    if (prm.seg > 0 && n >= prm.seg) outn = n < 2 * prm.seg ? prm.out1 + (size_t)(n - prm.seg) * prm.M * prm.N : prm.out2 + (size_t)(n - 2 * prm.seg) * prm.M * prm.N;
     constexpr int LO = TP * LDH;
     int g = 0;
+    float rsum[8];                     // (APANELS) row 4 k + (lane >> 4) of the wave's 32
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rsum[e] = 0.f;
     for (int nj = 0; nj < prm.nbB; ++nj) {
         f32x16 acc[4];
 #pragma unroll
@@ -290,15 +327,16 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
 #pragma unroll
         for (int c = 0; c < DR_MAXCH; ++c) {
             if (c < NCH) {
-                if (nstage - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                if (NST == 3 && nstage - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (g + DR_NST - 1 < nstage) issue(g + DR_NST - 1);
-                const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % DR_NST) * DC_SIDE) + r * LDH + 8 * half;
+                if (g + NST - 1 < nstage) issue(g + NST - 1);
+                const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % NST) * DC_SIDE) + r * LDH + 8 * half;
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ++ks) {
+                    if (APANELS && (prm.normalize & 4)) break;
                     f16x8 bh[4], bl[4];
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
@@ -317,6 +355,53 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
         }
         // ---- my 32 x 128 slab.  C/D layout: col = lane & 31 (+ 32 ni), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
         const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
+        if constexpr (APANELS) {
+            // through LDS: a lane then owns 4 consecutive columns of a row - 16-byte stores, 256 contiguous bytes per quarter wave - instead of
+            // 4-byte stores in 128-byte pieces (59 MB left at 2.2 TB/s that way: tools/exp/r5_rowblock_abl.py), and the row sums of the loss's
+            // pointwise shift (modules.py:332) are one 4-step reduction per row.  The slab is parked in the ring slot the block's last chunk was
+            // read from (free until the next copy is issued, behind the next barrier), in two passes of 64 columns
+            __builtin_amdgcn_s_barrier();                                // everybody has read the last chunk
+            float* park = reinterpret_cast<float*>(smem + ((g - 1) % NST) * DC_SIDE) + wave * (32 * DR_PKS);
+            const int c4 = 4 * (lane & 15);
+            const bool v4 = (prm.N & 3) == 0;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int ni = 2 * pass + nh;
+                    const float sb = rb[32 * ni + (lane & 31)];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        park[rl * DR_PKS + 32 * nh + (lane & 31)] = acc[ni][e] * (ra_s[32 * wave + rl] * sb);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (one wave: its LDS operations execute in order)
+                const int col = nj * TP + 64 * pass + c4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rl = 4 * k + (lane >> 4);
+                    const int row = mi * TP + 32 * wave + rl;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(park + rl * DR_PKS + c4);
+                    float sm = 0.f;
+                    if (row < prm.M && !(prm.normalize & 2)) {
+                        float* o = outn + (size_t)row * prm.N + col;
+                        if (v4 && col < prm.N) {
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
+                            sm = (v[0] + v[1]) + (v[2] + v[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < prm.N) { __builtin_nontemporal_store(v[q], o + q); sm += v[q]; }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) sm += __shfl_xor(sm, m, 64);
+                    rsum[k] += sm;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next pass overwrites the slab
+            }
+        } else {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int cl = 32 * ni + (lane & 31);
@@ -329,10 +414,20 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 if (row < prm.M && col < prm.N) __builtin_nontemporal_store(acc[ni][e] * (ra_s[rw] * sb), outn + (size_t)row * prm.N + col);
             }
         }
+        }
         // (the stores and the rb loads above are vector-memory operations too: they complete in order IN FRONT of the copies issued
         // after them only if none of those is waited for by count - the copies of the next chunks were issued before them, so the
         // counted waits stay valid once these are drained)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (APANELS) {
+        if (prm.rowsum) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = mi * TP + 32 * wave + 4 * k + (lane >> 4);
+                if ((lane & 15) == 0 && row < prm.M) prm.rowsum[(size_t)n * prm.M + row] = rsum[k];
+            }
+        }
     }
 }
 
@@ -367,9 +462,9 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
         pb.nbA = 0;                                    // the prep kernel's block index then runs over the B blocks only
         hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * prm.nbB)), dim3(NTHREADS), 0, stream, pb, vec);
         const int lds2 = DR_NST * DC_SIDE + 512;
-        hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel), lds2);
+        hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel<false>), lds2);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(dense_rowblock_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * prm.nbA)), dim3(NTHREADS), lds2, stream, prm);
+        hipLaunchKernelGGL(dense_rowblock_kernel<false>, dim3((unsigned)(((B + 7) / 8) * 8 * prm.nbA)), dim3(NTHREADS), lds2, stream, prm);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * (prm.nbA + prm.nbB))), dim3(NTHREADS), 0, stream, prm, vec);
@@ -378,6 +473,58 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
     if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
     return hipGetLastError();
+}
+
+// Both operands already prepared (stego_sample_panels): pair n = A image n % imagesA (M points) x B image n (N points).
+hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
+                                        float* out, float* out1, float* out2, int seg, float* rowsum, hipStream_t stream);
+hipError_t launch_dense_corr_panels(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
+                                    float* out, float* rowsum, hipStream_t stream)
+{
+    return launch_dense_corr_panels_seg(imgA, rsA, imagesA, imgB, rsB, B, C, M, N, out, nullptr, nullptr, 0, rowsum, stream);
+}
+
+hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
+                                        float* out, float* out1, float* out2, int seg, float* rowsum, hipStream_t stream)
+{
+    DenseParams prm{};
+    prm.out = out;
+    prm.B = B; prm.C = C; prm.M = M; prm.N = N; prm.W1 = 1; prm.W2 = 1;
+    prm.nbA = (M + TP - 1) / TP; prm.nbB = (N + TP - 1) / TP; prm.NCH = (C + KC - 1) / KC;
+    prm.imgA = const_cast<void*>(imgA); prm.imgB = const_cast<void*>(imgB);
+    prm.rsA = const_cast<float*>(rsA); prm.rsB = const_cast<float*>(rsB);
+    prm.a_mod = imagesA;
+    prm.rowsum = rowsum;
+    prm.out1 = out1; prm.out2 = out2; prm.seg = seg;
+    prm.normalize = (knob(KNOB_DEBUG) >> 16) & 7;          // (tools: ablations of the row-block kernel)
+    if (prm.NCH <= DR_MAXCH && !(knob(KNOB_DEBUG) & 8192)) {
+        const dim3 grid((unsigned)(((B + 7) / 8) * 8 * prm.nbA));
+        if (knob(KNOB_DEBUG) & (1 << 19)) {                     // (tools: three ring stages, one workgroup per CU)
+            const int lds3 = 3 * DC_SIDE + 512;
+            hipError_t e3 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel<true, 3>), lds3);
+            if (e3 != hipSuccess) return e3;
+            hipLaunchKernelGGL((dense_rowblock_kernel<true, 3>), grid, dim3(NTHREADS), lds3, stream, prm);
+            return hipGetLastError();
+        }
+        const int lds2 = 2 * DC_SIDE + 512;
+        hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel<true, 2>), lds2);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL((dense_rowblock_kernel<true, 2>), grid, dim3(NTHREADS), lds2, stream, prm);
+        return hipGetLastError();
+    }
+    if (seg > 0) return hipErrorInvalidValue;                 // (segmented outputs: the row-block kernel only - codes, K <= 384)
+    const int lds = 4 * DC_SIDE;
+    hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tile_kernel), lds);
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && rowsum) e = launch_rowsum(out, rowsum, (long long)B * M, N, stream);        // (the tile kernel's workgroups see 128 columns)
+    return e;
+}
+
+size_t dense_panel_image_bytes(int C, int P)
+{
+    return (size_t)((P + TP - 1) / TP) * ((C + KC - 1) / KC) * DC_SIDE;
 }
 
 }  // namespace stego

@@ -78,6 +78,12 @@ __global__ void __launch_bounds__(256) loss_pointwise_kernel(const LossPwParams 
     }
 }
 
+hipError_t launch_rowsum(const float* x, float* out, long long rows, int P, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, out, rows, P);
+    return hipGetLastError();
+}
+
 static int check_pw(const void* a, const void* b, int32_t n_sets, int32_t B, int32_t P)
 {
     if (!a || !b) return STEGO_ERR_NULL;

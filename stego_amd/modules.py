@@ -73,9 +73,9 @@ class _PointwiseLossFunction(torch.autograd.Function):
     (neg_loss [sets - 2, B, P, P], the sum of every set's loss [sets])."""
 
     @staticmethod
-    def forward(ctx, fd, cd, shifts, cmin, cmax, pointwise):
+    def forward(ctx, fd, cd, shifts, cmin, cmax, pointwise, fd_rowsum=None):
         fd, cdc = fd.contiguous(), cd.detach().contiguous()
-        neg_loss, sums, rowsum, old_mean = capi.loss_pointwise_fwd(fd, cdc, shifts, cmin, cmax, pointwise)
+        neg_loss, sums, rowsum, old_mean = capi.loss_pointwise_fwd(fd, cdc, shifts, cmin, cmax, pointwise, fd_rowsum)
         ctx.save_for_backward(fd, cdc, rowsum, old_mean)
         ctx.args = (shifts, cmin, cmax, pointwise)
         return neg_loss, sums
@@ -84,7 +84,62 @@ class _PointwiseLossFunction(torch.autograd.Function):
     def backward(ctx, g_neg, g_sums):
         fd, cdc, rowsum, old_mean = ctx.saved_tensors
         shifts, cmin, cmax, pointwise = ctx.args
-        return None, capi.loss_pointwise_bwd(fd, cdc, rowsum, old_mean, shifts, cmin, cmax, pointwise, g_neg, g_sums), None, None, None, None
+        return None, capi.loss_pointwise_bwd(fd, cdc, rowsum, old_mean, shifts, cmin, cmax, pointwise, g_neg, g_sums), None, None, None, None, None
+
+
+class _CodeCorrFunction(torch.autograd.Function):
+    """cd of ALL pair-sets for shapes the fused kernels do not take (modules.py:335 with :369-385 in front of it):
+        image n of the operand set = norm(sample(orig_code, coords1)) [0, B) | norm(sample(orig_code_pos, coords2)) [B, 2 B) |
+                                     norm(sample(orig_code[perm_k], coords2)) [2 B + k B, ...)
+        cd[n] = rows(n % B) . rows(n)^T
+    Forward: three sampling launches that write the dense kernel's operands directly (stego_sample_panels) + one correlation launch.
+    Backward: two batched GEMMs against the saved normalised rows, then the backward of norm() and of the sampling in one scatter launch
+    per source (stego_sample_bwd_rows)."""
+
+    @staticmethod
+    def forward(ctx, orig_code, orig_code_pos, coords1, coords2, idx):
+        B, K = orig_code.shape[:2]
+        P = int(coords1.shape[1]) ** 2
+        n_img = 2 * B + (int(idx.numel()) if idx is not None else 0)
+        dev = orig_code.device
+        oc, ocp = orig_code.detach(), orig_code_pos.detach()
+        pset = capi.PanelSet(n_img, K, P, dev)
+        cn = torch.empty(n_img, P, K, dtype=torch.float32, device=dev)
+        inv = torch.empty(n_img, P, dtype=torch.float32, device=dev)
+        capi.sample_panels(pset, 0, oc, coords1, None, True, cn[:B], inv[:B])
+        capi.sample_panels(pset, B, ocp, coords2, None, True, cn[B:2 * B], inv[B:2 * B])
+        if n_img > 2 * B:
+            capi.sample_panels(pset, 2 * B, oc, coords2, idx, True, cn[2 * B:], inv[2 * B:])
+        ctx.save_for_backward(cn, inv, coords1, coords2, idx if idx is not None else coords1.new_empty(0))
+        ctx.has_idx = idx is not None
+        ctx.like = (orig_code, orig_code_pos)
+        ctx.set_materialize_grads(False)
+        return capi.dense_corr_panels(pset, B, pset, n_img)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None
+        cn, inv, coords1, coords2, idx = ctx.saved_tensors
+        orig_code, orig_code_pos = ctx.like
+        n_img, P, K = cn.shape
+        B = orig_code.shape[0]
+        n_sets = n_img // B
+        g = g.contiguous().view(n_sets, B, P, P)
+        # the gradient of every image's normalised rows: as a second operand (g^T . anchors), the anchors' also as the first (sum over the sets)
+        d_rows = torch.matmul(g.transpose(2, 3), cn[:B]).view(n_img, P, K)
+        d_rows[:B] += torch.bmm(g.view(n_img, P, P), cn).view(n_sets, B, P, K).sum(0)
+        d_code = d_pos = None
+        if ctx.needs_input_grad[0]:
+            d_code = torch.zeros_like(orig_code, dtype=torch.float32)
+            capi.sample_bwd_rows(d_rows[:B], d_code, coords1, None, cn[:B], inv[:B])
+            if ctx.has_idx:
+                capi.sample_bwd_rows(d_rows[2 * B:], d_code, coords2, idx, cn[2 * B:], inv[2 * B:])
+        if ctx.needs_input_grad[1]:
+            d_pos = torch.zeros_like(orig_code_pos, dtype=torch.float32)
+            capi.sample_bwd_rows(d_rows[B:2 * B], d_pos, coords2, None, cn[B:2 * B], inv[B:2 * B])
+        return d_code, d_pos, None, None, None
 
 
 class _DenseCorrFunction(torch.autograd.Function):
@@ -752,10 +807,14 @@ class ContrastiveCorrelationLoss(nn.Module):
     @staticmethod
     def fused_kernels_cover(B, C, K, H, W, S, device=None):
         """Does the hand-written loss path (stego_corr_fwd / _bwd, include/stego_corr.h "Limits of this build") take this shape?
-        S * S <= 128 sample points per image; K <= 72 on any layout; 72 < K <= 128 on the single-launch forward (any parity, ViT widths,
-        B and the map within its bounds).  Everything else - e.g. cfg.feature_samples = 16 - is computed by generic_forward()."""
-        if S * S > 128 or K > 128 or H > 32767 or W > 32767:
+        S * S <= 128 sample points per image: K <= 72 on any layout, 72 < K <= 128 on the single-launch forward (any parity, ViT widths, B and the
+        map within its bounds); 128 < S * S <= 256 (cfg.feature_samples 12 .. 16): K <= 88.  Everything else is computed by generic_forward()."""
+        if K > 128 or H > 32767 or W > 32767:
             return False
+        if S * S > 128:
+            # 129 .. 256 points per image (cfg.feature_samples 12 .. 16): the multi-launch kernels of csrc/corr_wide.hip behind the same entry
+            # points (round 5)
+            return S <= 16 and K <= 88 and (2 + 253) * B <= 65535
         if K > 72:
             return C in (192, 384, 768) and B <= _pair_set_bound(device) and H <= 256 and W <= 256
         return True
@@ -788,35 +847,46 @@ class ContrastiveCorrelationLoss(nn.Module):
         B = orig_feats.shape[0]
         n_neg = int(perms.shape[0]) if perms is not None else 0
         n_sets = 2 + n_neg
+        min_val = 0.0 if cfg.zero_clamp else -9999.0
+        idx = perms.reshape(-1) if n_neg else None                       # [n_neg * B]
+        if orig_feats.is_cuda and orig_feats.dtype == torch.float32 and orig_code.dtype == torch.float32 and coords1.shape[1] == coords1.shape[2] \
+                and coords1.shape == coords2.shape:
+            # native (round 5).  The negatives read the maps of image perm_n[b] at pair (n, b)'s coords2[b] through an index, not through the
+            # permuted copies of modules.py:384-385 (5 x (38.5 + 7) MB at BASELINE config 2, the largest single cost of the reference's step);
+            # the sampler normalises (norm(), :275-276) and writes the dense kernel's split-fp16 OPERANDS - the fp32 rows of the sampled features
+            # (88 MB at S = 16) never exist, the anchors are one operand set against all pair-sets' second operands (no repeat / cat copies);
+            # helper()'s elementwise part for all pair-sets is three launches (stego_rowsum / stego_loss_pointwise_fwd / _bwd)
+            S = int(coords1.shape[1])
+            P = S * S
+            C = orig_feats.shape[1]
+            with torch.no_grad():
+                fset = capi.PanelSet(n_sets * B, C, P, orig_feats.device)
+                capi.sample_panels(fset, 0, orig_feats, coords1)
+                capi.sample_panels(fset, B, orig_feats_pos, coords2)
+                if n_neg:
+                    capi.sample_panels(fset, 2 * B, orig_feats, coords2, idx)
+                fd, fd_rowsum = capi.dense_corr_panels(fset, B, fset, n_sets * B, want_rowsum=bool(cfg.pointwise))[:2] if cfg.pointwise \
+                    else (capi.dense_corr_panels(fset, B, fset, n_sets * B), None)
+                del fset
+            cd = _CodeCorrFunction.apply(orig_code, orig_code_pos, coords1, coords2, idx).view(n_sets, B, S, S, S, S)
+            neg, sums = _PointwiseLossFunction.apply(fd.view(n_sets, B, P, P), cd.view(n_sets, B, P, P),
+                                                     (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), min_val,
+                                                     0.8 if cfg.stabalize else 3.0e38, bool(cfg.pointwise), fd_rowsum)
+            cnt = float(B * P * P)
+            if n_neg:
+                neg_inter_loss, neg_inter_cd = neg.view(n_neg * B, S, S, S, S), cd[2:].flatten(0, 1)
+            else:
+                neg_inter_loss = neg_inter_cd = cd.new_zeros(0, S, S, S, S)
+            return sums[0] / cnt, cd[0], sums[1] / cnt, cd[1], neg_inter_loss, neg_inter_cd
         feats, code = sample_indexed(orig_feats, coords1), sample_indexed(orig_code, coords1)
         f2, c2 = [feats, sample_indexed(orig_feats_pos, coords2)], [code, sample_indexed(orig_code_pos, coords2)]
         if n_neg:
-            # the negatives read the maps of image perm_n[b] at pair (n, b)'s coords2[b] - through an index, not through the permuted
-            # copies of modules.py:384-385 (5 x (38.5 + 7) MB at BASELINE config 2, the largest single cost of the reference's step)
-            idx = perms.reshape(-1)                                       # [n_neg * B]
             f2.append(sample_indexed(orig_feats, coords2, idx))
             c2.append(sample_indexed(orig_code, coords2, idx))
         f2, c2 = torch.cat(f2), torch.cat(c2)
         f1, c1 = feats.repeat(n_sets, 1, 1, 1), code.repeat(n_sets, 1, 1, 1)
         S1, S2 = feats.shape[2:]
         per_set = lambda t: t.view(n_sets, B, S1, S2, S1, S2)            # noqa: E731
-        min_val = 0.0 if cfg.zero_clamp else -9999.0
-        if f1.is_cuda and f1.dtype == torch.float32:
-            # native: norm() of the features inside the dense kernel's operand pass, the elementwise part of helper() for all pair-sets in
-            # three launches (stego_rowsum / stego_loss_pointwise_fwd / _bwd: ~25 torch kernels over 59 MB tensors at S = 16 before)
-            with torch.no_grad():
-                fd = capi.dense_corr(f1, f2, normalize=True)
-            cd = per_set(tensor_correlation(norm(c1), norm(c2)))
-            P = S1 * S2
-            neg, sums = _PointwiseLossFunction.apply(fd.view(n_sets, B, P, P), cd.view(n_sets, B, P, P),
-                                                     (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), min_val,
-                                                     0.8 if cfg.stabalize else 3.0e38, bool(cfg.pointwise))
-            cnt = float(B * P * P)
-            if n_neg:
-                neg_inter_loss, neg_inter_cd = neg.view(n_neg * B, S1, S2, S1, S2), cd[2:].flatten(0, 1)
-            else:
-                neg_inter_loss = neg_inter_cd = cd.new_zeros(0, S1, S2, S1, S2)
-            return sums[0] / cnt, cd[0], sums[1] / cnt, cd[1], neg_inter_loss, neg_inter_cd
         with torch.no_grad():
             fd = per_set(tensor_correlation(norm(f1), norm(f2)))
             if cfg.pointwise:                                            # helper(), modules.py:331-333, per pair-set

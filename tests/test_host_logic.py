@@ -209,8 +209,17 @@ def test_library_validates_before_enqueueing():
     args_null = [None] * 4 + [None] * 3 + [None] * 8 + [None, 0, None]
     assert lib.stego_corr_fwd(None, *args_null) == 1                      # STEGO_ERR_NULL
     assert lib.stego_corr_fwd(ctypes.byref(d), *args_null) == 1
-    d12 = capi.make_desc(4, 384, 70, 28, 28, 12, 5, cfg, (.18, .12, .46))  # S*S = 144 > 128
-    assert lib.stego_corr_fwd(ctypes.byref(d12), *args_null) == 3         # STEGO_ERR_UNSUPPORTED
+    d12 = capi.make_desc(4, 384, 70, 28, 28, 12, 5, cfg, (.18, .12, .46))  # S*S = 144 > 128: the multi-launch path (csrc/corr_wide.hip) since round 5
+    assert lib.stego_corr_fwd(ctypes.byref(d12), *args_null) == 1
+    w16 = capi.make_desc(32, 384, 70, 28, 28, 16, 5, cfg, (.18, .12, .46))
+    n_img, P = 7 * 32, 256
+    assert lib.stego_corr_workspace_bytes(ctypes.byref(w16)) >= n_img * P * (384 + 70) * 4           # the operand images of both correlations
+    assert lib.stego_corr_saved_ctx_bytes(ctypes.byref(w16)) >= n_img * P * (70 + 1) * 4             # the normalised code rows + 1 / |row|
+    assert lib.stego_corr_bwd_workspace_bytes(ctypes.byref(w16)) >= 2 * n_img * P * 70 * 4
+    for bad in (capi.make_desc(4, 384, 70, 28, 28, 17, 5, cfg, (.18, .12, .46)),                    # S * S > 256
+                capi.make_desc(4, 384, 96, 28, 28, 12, 5, cfg, (.18, .12, .46))):                   # K > 88 beyond 128 points
+        assert lib.stego_corr_fwd(ctypes.byref(bad), *args_null) == 3     # STEGO_ERR_UNSUPPORTED
+        assert lib.stego_corr_workspace_bytes(ctypes.byref(bad)) == 0
     d0 = capi.make_desc(0, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46))
     assert lib.stego_corr_fwd(ctypes.byref(d0), *args_null) == 2          # STEGO_ERR_SHAPE
     assert b"unsupported" in lib.stego_error_string(3)

@@ -462,17 +462,24 @@ def test_salience_path_on_device_matches_oracle():
     assert_close(out[5].cpu().numpy(), ref.neg_inter_cd, what="neg_inter_cd")
 
 
-@pytest.mark.parametrize("S,K,C", [(12, 70, 384), (16, 70, 384), (16, 24, 64), (5, 130, 384), (3, 96, 16)])
-def test_feature_samples_above_11_and_wide_codes_run_on_the_generic_path(S, K, C):
-    """cfg.feature_samples and cfg.dim are free in the reference (train_config.yml:39,51).  Beyond the fused kernels' S * S <= 128 /
-    K <= 128 the loss is computed by generic_forward (torch grid_sample + the native dense-correlation kernel for every einsum,
-    forward and adjoints): forward and gradients against the fp64 oracle."""
+@pytest.mark.parametrize("S,K,C,layout", [(12, 70, 384, "cl"), (13, 70, 384, "cl"), (16, 70, 384, "cl"), (16, 70, 768, "cl"), (16, 24, 64, "cl"),
+                                          (15, 88, 384, "cl"), (14, 70, 192, "nchw"), (16, 101, 384, "cl"), (5, 130, 384, "cl"), (3, 96, 16, "cl")])
+def test_feature_samples_above_11_and_wide_codes(S, K, C, layout):
+    """cfg.feature_samples and cfg.dim are free in the reference (train_config.yml:39,51).  feature_samples 12 .. 16 (144 .. 256 points per
+    image, K <= 88) run on the multi-launch kernels of csrc/corr_wide.hip behind stego_corr_fwd / _bwd - the same entry points as S <= 11;
+    beyond those limits (K > 88 at S > 11, K > 128) generic_forward computes the loss (native samplers + dense-correlation kernel +
+    elementwise launches, gradient through autograd).  Forward and gradients against the fp64 oracle, any map layout."""
     B, H, W, n_neg = 3, 10, 9, 2
     d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=900 + S + K, dino_like=True)
     cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
-    assert not M.ContrastiveCorrelationLoss.fused_kernels_cover(B, C, K, H, W, S)
+    native = S * S > 128 and K <= 88
+    assert M.ContrastiveCorrelationLoss.fused_kernels_cover(B, C, K, H, W, S) == native
     inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
-    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3")
+    if native:
+        tt = {k: torch.from_numpy(v).to(DEV) for k, v in inputs.items()}
+        desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), capi.PREC_F16X3)
+        assert capi.corr_fwd_launches(desc, tt["feats"], tt["feats_pos"], tt["code"], tt["code_pos"]) == 11
+    r = _run(inputs, d["perms"], cfg, layout=layout, precision="f16x3")
     ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
     assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=5e-4, what="intra_cd")
     assert_close(r["out"][3], ref.pos_inter_cd, atol_frac=5e-4, what="inter_cd")
@@ -1567,3 +1574,38 @@ def test_native_pointwise_loss_matches_the_reference_statements(variant):
         ls.append(-(c.clamp(cmin, 0.8) if stab else c.clamp(cmin)) * (f - shifts[2]))
     torch.stack(ls).mean().backward()
     assert float((cd_b.grad - cd_r.grad).abs().max()) < 1e-5 * float(cd_r.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("S,variant", [(12, "default"), (16, "noclamp_stab"), (13, "plain")])
+def test_wide_path_dense_upstreams_and_cfg_variants(S, variant):
+    """feature_samples 12 .. 16 on csrc/corr_wide.hip with DENSE upstreams on every output (neg_inter_loss and the three cd tensors: the
+    backward then scales G per pair by a first pass over it) and the zero_clamp / stabalize / pointwise variants: forward outputs and
+    both code gradients against the fp64 oracle."""
+    B, C, H, W, K, n_neg = 2, 64, 9, 11, 70, 2
+    zero_clamp, stab, pointwise = {"default": (True, False, True), "noclamp_stab": (False, True, True), "plain": (True, False, False)}[variant]
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=77 + S, dino_like=True)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg, zero_clamp=zero_clamp, stabalize=stab, pointwise=pointwise)
+    assert M.ContrastiveCorrelationLoss.fused_kernels_cover(B, C, K, H, W, S)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    rng = np.random.default_rng(5)
+    shp = (S,) * 4
+    g_nl = rng.standard_normal((n_neg * B,) + shp) * 1e-3
+    g_icd, g_ecd, g_ncd = (rng.standard_normal((m,) + shp) * 1e-3 for m in (B, B, n_neg * B))
+
+    def upstream(out):
+        t = lambda a: torch.from_numpy(a).float().to(DEV)                        # noqa: E731
+        return 0.67 * out[0] + 0.25 * out[2] + (out[4] * t(g_nl)).sum() + (out[1] * t(g_icd)).sum() + (out[3] * t(g_ecd)).sum() + \
+            (out[5] * t(g_ncd)).sum()
+
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3", upstream=upstream)
+    ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
+    assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=5e-4, what="intra_cd")
+    assert_close(r["out"][4], ref.neg_inter_loss, atol_frac=5e-4, what="neg_loss")
+    assert_close(r["out"][5], ref.neg_inter_cd, atol_frac=5e-4, what="neg_cd")
+    scale = float(np.mean(np.abs(ref.neg_inter_loss)))
+    assert abs(float(r["out"][0]) - float(ref.pos_intra_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_intra_loss))
+    assert abs(float(r["out"][2]) - float(ref.pos_inter_loss)) <= 1e-3 * scale + 1e-3 * abs(float(ref.pos_inter_loss))
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl,
+                                   g_intra_cd=g_icd, g_inter_cd=g_ecd, g_neg_cd=g_ncd)
+    assert_close(r["d_code"], dc, rtol=2e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=2e-3, atol_frac=1e-3, what="d_code_pos")
