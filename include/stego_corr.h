@@ -96,7 +96,7 @@ enum {
 /* Limits of this build: S*S <= 128 (S <= 11): K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
  * channels-last maps with C = 192 / 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
  * helper()); 128 < S*S <= 256 (S = 12 .. 16, ABI 7): K <= 88, any C and layout - the same entry points run the multi-launch kernels of
- * csrc/corr_wide.hip (stego_corr_fwd_launches says 11; split-fp16 products in both precision modes; the code gradients are accumulated with
+ * csrc/corr_wide.hip (stego_corr_fwd_launches says 8; split-fp16 products in both precision modes; the code gradients are accumulated with
  * fp32 atomics, so their last bits are not repeatable - everything below is about S <= 11); every per-image element offset < 2^31.
  * Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
  * GEMMs are split-fp16 products in both precision modes (their fp32 operand images no longer fit LDS).
@@ -218,7 +218,7 @@ int stego_ref_draws_indirect(const int64_t* seed_ptr, const int64_t* offset_ptr,
 int stego_fast_draws(const int64_t* seed, int64_t n_coord, int32_t n_neg, int32_t B, float* coords1, float* coords2,
                      int64_t* perms, stego_stream_t stream);
 
-/* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize, 9 or 11 = S > 11 (csrc/corr_wide.hip);
+/* Kernel launches the forward needs for these maps: 1 = the fused path, 3 = sample / tile / finalize, 7 or 8 = S > 11 (csrc/corr_wide.hip);
  * < 0: -error code. */
 int stego_corr_fwd_launches(const StegoCorrDesc* desc, const StegoMap* feats, const StegoMap* feats_pos,
                             const StegoMap* code, const StegoMap* code_pos);

@@ -506,7 +506,7 @@ int stego_corr_fwd_launches(const StegoCorrDesc* d, const StegoMap* feats, const
     int rc = check_desc(d, false);
     if (rc) return -rc;
     if (!feats || !feats_pos || !code || !code_pos) return -STEGO_ERR_NULL;
-    if (is_wide(d)) return 5 + 2 * (d->n_neg > 0 ? 3 : 2);        // corr_wide.hip: samplers x 2 x (2 or 3), two correlations, three elementwise
+    if (is_wide(d)) return 5 + (d->n_neg > 0 ? 3 : 2);            // corr_wide.hip: 2 or 3 sampler launches, two correlations, three elementwise
     const Geometry g = geometry(d, false);
     FusedParams fp{};
     if ((rc = to_mapv(feats, d->C, d->H, d->W, &fp.feats)) || (rc = to_mapv(feats_pos, d->C, d->H, d->W, &fp.feats_pos)) ||

@@ -5,21 +5,27 @@
 //              kernel of corr_fused.hip serves (S * S <= 128).
 //
 // The same C ABI (stego_corr_fwd / stego_corr_bwd, include/stego_corr.h) dispatches here when S * S > 128: the caller sees the same outputs and
-// the same saved tensors, only more launches.  Forward (11 launches):
-//   stego_sample_panels x 3   the sampled, L2-normalised FEATURES of all 2 + n_neg pair-sets as split-fp16 operand images (anchors: images [0, B);
-//                             orig_feats_pos at coords2: [B, 2 B); orig_feats[perm_k] at coords2 through an index: the rest) - the fp32 rows never exist
+// the same saved tensors, only more launches.  Forward (8 launches):
+//   sample_panels_kernel x 3  the sampled, L2-normalised FEATURES and CODES of all 2 + n_neg pair-sets (anchors: images [0, B); orig_*_pos at
+//                             coords2: [B, 2 B); orig_*[perm_k] at coords2 through an index: the rest) written as the split-fp16 operand images
+//                             of the dense-correspondence kernel - the fp32 rows of the sampled features never exist; the codes' normalised
+//                             fp32 rows and 1 / |row| also go to the saved context (the backward needs them).  Both maps in one launch: the same
+//                             points, the code map's taps ride in the feature row's round trip
 //   dense_rowblock_kernel     fd[n] = anchors(n % B) . image(n)^T for all pair-sets in one launch, row sums on the way     -> saved_w (raw fd)
-//   stego_sample_panels x 3   the same for the CODES, keeping the normalised fp32 rows and 1 / |row| (saved context: the backward needs them)
 //   dense_rowblock_kernel     cd[n], written straight into the three cd outputs
-//   wide_set_mean_kernel      old_mean of every pair-set (modules.py:331) from the row sums                                -> saved_mean
+//   wide_set_mean_kernel      old_mean of every pair-set (modules.py:331) from the row sums -> saved_mean; the coordinates -> saved context
 //   wide_pointwise_kernel     helper()'s elementwise part (:330-345) in place: loss (negative sets), the row sums of the loss of every set, and
 //                             w = fd - rowmean + old_mean - shift with the clamp's pass mask in its mantissa LSB             -> saved_w
 //   wide_loss_means_kernel    the three means the caller gets (:393-398)
-// Backward (6 launches + 2 memsets), wide_bwd_kernel: one workgroup per pair (set, image) walks its <= 2 x 2 tiles of G = -w * mask * upstream and
-// takes both adjoints of the code correlation on the fp16 matrix cores (split-fp16 x 3 like the forward): d anchors(n) = G . rows(n),
-// d rows(n) = G^T . anchors - G is staged once per tile in LDS and read along rows for the first, along columns for the second product.  Then
-// stego_sample_bwd_rows x 3: the backward of norm() and of the bilinear sampling, added into the two code gradients (fp32 atomics: the one place
-// in the library whose summation order is not fixed; the fused path for S <= 11 stays bitwise repeatable).
+// Backward (5 launches):
+//   wide_code_tiles_kernel    the codes' side of the backward's GEMMs: per (image, 128-point block) the normalised rows transposed and split into
+//                             fp16 hi | lo, in the layout the GEMM kernel keeps in LDS; its spare workgroups zero the two gradient maps
+//   wide_bwd_kernel           one workgroup per pair (set, image) walks its <= 2 x 2 tiles of G = -w * mask * upstream and takes both adjoints of
+//                             the code correlation on the fp16 matrix cores (split-fp16 x 3 like the forward): d anchors(n) = G . rows(n),
+//                             d rows(n) = G^T . anchors - G is staged once per tile in LDS (its w values loaded one tile ahead) and read along rows
+//                             by four waves for the first product, along columns by four more for the second
+//   sample_scatter_kernel x 3 the backward of norm() and of the bilinear sampling, added into the two code gradients (fp32 atomics: the one place
+//                             in the library whose summation order is not fixed; the fused path for S <= 11 stays bitwise repeatable)
 #include "corr_common.h"
 #include "host_util.h"
 #include "../../include/stego_corr.h"
@@ -30,8 +36,10 @@ namespace stego {
 hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int imagesA, const void* imgB, const float* rsB, int B, int C, int M, int N,
                                         float* out, float* out1, float* out2, int seg, float* rowsum, hipStream_t stream);                     // dense_corr.hip
 size_t dense_panel_image_bytes(int C, int P);
-hipError_t launch_sample_panels(const StegoMap* map, const long long* index, int N, int C, int H, int W, const float* coords, int n_coords, int S,
-                                int normalize, void* panels, float* row_scale, float* rows_out, float* inv_out, hipStream_t stream);         // sample_sets.hip
+hipError_t launch_sample_panels2(const StegoMap* map, int C, void* panels, float* row_scale, float* rows_out, float* inv_out,
+                                 const StegoMap* map2, int C2, void* panels2, float* row_scale2, float* rows_out2, float* inv_out2,
+                                 const long long* index, int N, int H, int W, const float* coords, int n_coords, int S, int normalize,
+                                 hipStream_t stream);                                                                                        // sample_sets.hip
 hipError_t launch_sample_scatter(const float* g_rows, const float* rows_n, const float* inv, const StegoMap* d_map, const long long* index, int N, int C,
                                  int H, int W, const float* coords, int n_coords, int S, const float* extra, int n_extra, long long extra_stride,
                                  hipStream_t stream);
@@ -48,23 +56,38 @@ struct WidePwParams {
     float shift[3];
     float cmin, cmax;
     int n_sets, B, P, pointwise, keep_w;
+    const float* co_src[2];     // coords1, coords2 [B][P][2] -> the saved context (blocks behind the pair-sets' in wide_set_mean_kernel)
+    float* co_dst[2];
 };
 
-// one workgroup per pair-set, a fixed summation order
-__global__ void __launch_bounds__(256) wide_set_mean_kernel(const WidePwParams p)
+// one workgroup per pair-set, a fixed summation order; the workgroups behind them copy the bilinear coordinates into the saved context (the
+// backward is handed the permutations only)
+constexpr int WIDE_COPY_CHUNK = 4096;
+__global__ void __launch_bounds__(1024) wide_set_mean_kernel(const WidePwParams p)
 {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= p.n_sets) {
+        const int n = p.B * p.P * 2, per = (n + WIDE_COPY_CHUNK - 1) / WIDE_COPY_CHUNK;
+        const int c = s - p.n_sets, which = c / per, beg = (c - which * per) * WIDE_COPY_CHUNK;
+        for (int i = beg + tid; i < min(beg + WIDE_COPY_CHUNK, n); i += 1024) p.co_dst[which][i] = p.co_src[which][i];
+        return;
+    }
     float acc = 0.f;
     if (p.pointwise) {
         const float* r = p.rowsum + (size_t)s * p.B * p.P;
-        for (int i = tid; i < p.B * p.P; i += 256) acc += r[i];
+#pragma unroll 8
+        for (int i = tid; i < p.B * p.P; i += 1024) acc += r[i];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
     }
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) p.mean[s] = p.pointwise ? ((red[0] + red[1]) + (red[2] + red[3])) / ((float)p.B * (float)p.P * (float)p.P) : 0.f;
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        p.mean[s] = p.pointwise ? t / ((float)p.B * (float)p.P * (float)p.P) : 0.f;
+    }
 }
 
 // one wave per row of one pair: modules.py:330-345
@@ -100,26 +123,25 @@ __global__ void __launch_bounds__(256) wide_pointwise_kernel(const WidePwParams 
     if (lane == 0) p.lrowsum[r] = acc;
 }
 
-// one workgroup: the three returned means (modules.py:393-398) in a fixed order
+// one workgroup per returned mean (modules.py:393-398), a fixed summation order
 __global__ void __launch_bounds__(1024) wide_loss_means_kernel(const WidePwParams p)
 {
-    __shared__ float red[3][16];
-    const int tid = threadIdx.x;
+    __shared__ float red[16];
+    const int tid = threadIdx.x, q = blockIdx.x;
     const int per = p.B * p.P;
-    float a[3] = {0.f, 0.f, 0.f};
-    for (int q = 0; q < 3; ++q) {
-        const int beg = q * per, end = q < 2 ? (q + 1) * per : p.n_sets * per;
-        for (int i = beg + tid; i < end; i += 1024) a[q] += p.lrowsum[i];
+    const int beg = q * per, end = q < 2 ? (q + 1) * per : p.n_sets * per;
+    float a = 0.f;
+#pragma unroll 8
+    for (int i = beg + tid; i < end; i += 1024) a += p.lrowsum[i];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) a[q] += __shfl_xor(a[q], m, 64);
-        if ((tid & 63) == 0) red[q][tid >> 6] = a[q];
-    }
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
     __syncthreads();
-    if (tid < 3) {
+    if (tid == 0) {
         float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += red[tid][w];
+        for (int w = 0; w < 16; ++w) t += red[w];
         const float cnt = (float)p.B * (float)p.P * (float)p.P;
-        p.loss_means[tid] = tid < 2 ? t / cnt : (p.n_sets > 2 ? t / (cnt * (float)(p.n_sets - 2)) : 0.f);
+        p.loss_means[q] = q < 2 ? t / cnt : (p.n_sets > 2 ? t / (cnt * (float)(p.n_sets - 2)) : 0.f);
     }
 }
 
@@ -135,12 +157,15 @@ struct WideBwdParams {
     const unsigned char* tiles; // [n_img][nb] code tiles, transposed and split: hi [Kr][WB_TS] | lo [Kr][WB_TS] fp16 of CSCALE * cn, tile_bytes each
     unsigned char* tiles_out;   // (wide_code_tiles_kernel)
     int tile_bytes;
+    float* zero[2];             // (wide_code_tiles_kernel: the two code gradients, zeroed by the workgroups behind the tiles')
+    long long zero_floats;
     const float* g_intra;       // device scalars: upstreams of loss_means[0 .. 1] (null: 0)
     const float* g_inter;
     const float* g_neg;         // upstream of the negative losses, see g_neg_stride (null: 0)
     const float* g_cd[3];       // optional dense upstreams of the three cd outputs
     float* d_rows;              // [n_img][P][K] gradient of image n's rows as the second operand of pair n
     float* d_anchor;            // [n_img][P][K] gradient of the anchors (image n % B) from pair n
+    int debug;                  // (tools: STEGO_DEBUG_BWD bits 16..18 - 1 no matrix products, 2 no w loads, 4 no code-tile copies)
     int g_neg_stride;           // 1 dense [n_neg B][P][P], 0 one scalar per element, -1 one scalar = the upstream of loss_means[2]
     int B, P, K, Kr, n_sets;
 };
@@ -167,45 +192,60 @@ __device__ __forceinline__ void wide_dma_piece(const unsigned char* gsrc_lane, u
 // The operands of the backward's GEMMs that come from the codes, once per backward: tile (image, 128-point block) = the block's normalised rows
 // TRANSPOSED ([channel][point]: a fragment of either product is then 8 consecutive points of one channel = one 16-byte LDS read) and split
 // into fp16 hi | lo, in the layout the GEMM kernel keeps in LDS - staging a tile there is a linear LDS-DMA copy.
-__global__ void __launch_bounds__(256) wide_code_tiles_kernel(const WideBwdParams p)
+constexpr int WB_ZERO_CHUNK = 16384;      // floats per zeroing workgroup
+__global__ void __launch_bounds__(512) wide_code_tiles_kernel(const WideBwdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int nbp = (p.P + TP - 1) / TP;
+    const int n_tiles = p.n_sets * p.B * nbp;
+    if ((int)blockIdx.x >= n_tiles) {
+        // the scatter launches ADD into the code gradients: zero them here
+        const long long per = (p.zero_floats + WB_ZERO_CHUNK - 1) / WB_ZERO_CHUNK;
+        const long long c = (long long)blockIdx.x - n_tiles;
+        const int which = (int)(c / per);
+        const long long beg = (c - which * per) * WB_ZERO_CHUNK, end = min(beg + (long long)WB_ZERO_CHUNK, p.zero_floats);
+        float* z = p.zero[which];
+        for (long long i = beg + 4 * tid; i < end; i += 4 * 512) {
+            if (i + 3 < end && (reinterpret_cast<uintptr_t>(z) & 15) == 0) *reinterpret_cast<f32x4*>(z + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else for (long long q = i; q < end; ++q) z[q] = 0.f;
+        }
+        return;
+    }
     const int img = blockIdx.x / nbp, blk = blockIdx.x - img * nbp;
     const int P = p.P, K = p.K, Kr = p.Kr, p0 = blk * TP;
     half_t* T = reinterpret_cast<half_t*>(smem);
-    for (int i = tid; i < p.tile_bytes / 16; i += 256) reinterpret_cast<du32x4*>(smem)[i] = du32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < p.tile_bytes / 16; i += 512) reinterpret_cast<du32x4*>(smem)[i] = du32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     const float* src = p.cn + ((size_t)img * P + p0) * K;
     const int rows = min(TP, P - p0);
-    constexpr int UN = 8;
-    for (int base = 0; base < rows * K; base += 256 * UN) {
-        float v[UN];
+    constexpr int UN = 22;                                              // 128 x 88 / 512: every load of a thread in flight at once
+    float v[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int idx = base + u * 256 + tid;
-            v[u] = idx < rows * K ? src[idx] : 0.f;                     // (rows of a block are contiguous: [point][K])
-        }
+    for (int u = 0; u < UN; ++u) {
+        const int idx = u * 512 + tid;
+        v[u] = idx < rows * K ? src[idx] : 0.f;                         // (the rows of a block are contiguous: [point][K])
+    }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int idx = base + u * 256 + tid;
-            if (idx < rows * K) {
-                const int jl = idx / K, k = idx - jl * K;
-                unsigned hh, ll;
-                split_f16_pair(v[u] * WB_CSCALE, 0.f, hh, ll);
-                reinterpret_cast<unsigned short*>(T)[k * WB_TS + jl] = (unsigned short)(hh & 0xffffu);
-                reinterpret_cast<unsigned short*>(T + Kr * WB_TS)[k * WB_TS + jl] = (unsigned short)(ll & 0xffffu);
-            }
+    for (int u = 0; u < UN; ++u) {
+        const int idx = u * 512 + tid;
+        if (idx < rows * K) {
+            const int jl = idx / K, k = idx - jl * K;
+            unsigned hh, ll;
+            split_f16_pair(v[u] * WB_CSCALE, 0.f, hh, ll);
+            reinterpret_cast<unsigned short*>(T)[k * WB_TS + jl] = (unsigned short)(hh & 0xffffu);
+            reinterpret_cast<unsigned short*>(T + Kr * WB_TS)[k * WB_TS + jl] = (unsigned short)(ll & 0xffffu);
         }
     }
     __syncthreads();
     du32x4* dst = reinterpret_cast<du32x4*>(p.tiles_out + (size_t)blockIdx.x * p.tile_bytes);
-    for (int i = tid; i < p.tile_bytes / 16; i += 256) dst[i] = reinterpret_cast<const du32x4*>(smem)[i];
+    for (int i = tid; i < p.tile_bytes / 16; i += 512) dst[i] = reinterpret_cast<const du32x4*>(smem)[i];
 }
 
-__global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
+constexpr int WB_THREADS = 512;       // 8 waves: waves 0-3 take the anchors' product, waves 4-7 the second operand's, two per SIMD
+
+__global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Gs = reinterpret_cast<float*>(smem);                                       // [128][WB_GS]
@@ -214,6 +254,7 @@ __global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
     float* red = Gs;                                                                  // (the first pass over G below: before any tile is staged)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, wq = wave & 3;                                        // 0: d anchors, 1: d rows of the second operand
     const int r = lane & 31, h = lane >> 5;
     const int n = blockIdx.x, P = p.P, K = p.K, Kr = p.Kr;
     const int s = n / p.B, na = n - s * p.B;
@@ -239,7 +280,7 @@ __global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
     float gmax = fabsf(up) * 8.f;
     if (gneg || gcd) {
         float m = 0.f;
-        for (int idx = tid; idx < P * P; idx += 256) {
+        for (int idx = tid; idx < P * P; idx += WB_THREADS) {
             const int i = idx / P, j = idx - i * P;
             m = fmaxf(m, fabsf(g_of(i, j, wn[idx])));
         }
@@ -247,7 +288,8 @@ __global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q, 64));
         if (lane == 0) red[wave] = m;
         __syncthreads();
-        gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        gmax = 0.f;
+        for (int q = 0; q < WB_THREADS / 64; ++q) gmax = fmaxf(gmax, red[q]);
     }
     const float gscale = gmax > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(gmax)) : 1.f;
     const float unscale = 1.f / (gscale * WB_CSCALE);
@@ -257,138 +299,151 @@ __global__ void __launch_bounds__(256) wide_bwd_kernel(const WideBwdParams p)
     auto stage_codes = [&](const half_t* T, int img, int blk) {
         const unsigned char* src = p.tiles + ((size_t)img * nbp + blk) * p.tile_bytes + lane * 16;
         const unsigned dst = smem_addr + (unsigned)(reinterpret_cast<const unsigned char*>(T) - smem);
-        for (int pc = wave; pc < p.tile_bytes / 1024; pc += 4) wide_dma_piece(src + pc * 1024, dst + pc * 1024);
+        if (p.debug & 4) return;
+        for (int pc = wave; pc < p.tile_bytes / 1024; pc += WB_THREADS / 64) wide_dma_piece(src + pc * 1024, dst + pc * 1024);
+    };
+    // the w values of tile (mi, nj) this thread turns into G: rows (tid >> 5) + 16 it, columns 4 (tid & 31) .. + 3.  Loaded one tile AHEAD, while
+    // the matrix cores work on the current one
+    const int jl = 4 * (tid & 31);
+    f32x4 wv[8];
+    auto fetch = [&](int mi, int nj) {
+        const int i0 = mi * TP, j0 = nj * TP;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int il = (tid >> 5) + 16 * it;
+            wv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i0 + il < P && !(p.debug & 2)) {
+                const float* wr = wn + (size_t)(i0 + il) * P + j0 + jl;
+                if ((P & 3) == 0) {
+                    if (j0 + jl < P) wv[it] = *reinterpret_cast<const f32x4*>(wr);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (j0 + jl + q < P) wv[it][q] = wr[q];
+                }
+            }
+        }
     };
 
-    f32x16 accB[WB_MAXNB][WB_MAXKB];
+    // accumulators: role 0 - acc[0][kb] = the anchors' rows of block mi (reset per mi); role 1 - acc[nj][kb] = the second operand's rows of block nj
+    f32x16 acc[WB_MAXNB][WB_MAXKB];
 #pragma unroll
     for (int a = 0; a < WB_MAXNB; ++a)
 #pragma unroll
         for (int b = 0; b < WB_MAXKB; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) accB[a][b][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+    fetch(0, 0);
     for (int mi = 0; mi < nbp; ++mi) {
-        f32x16 accA[WB_MAXKB];
-#pragma unroll
-        for (int b = 0; b < WB_MAXKB; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) accA[b][e] = 0.f;
 #pragma unroll
         for (int nj = 0; nj < WB_MAXNB; ++nj) {
             if (nj < nbp) {
                 __syncthreads();                                        // the previous tile's fragments are read
                 if (nj == 0) stage_codes(Ta, na, mi);
                 stage_codes(Tb, n, nj);
-                // G tile (mi, nj): rows i0 .. + 127 of the anchors, columns j0 .. + 127 of the second operand; all of a thread's loads of a
-                // half tile in flight at once
+                // G tile (mi, nj): rows i0 .. + 127 of the anchors, columns j0 .. + 127 of the second operand
                 const int i0 = mi * TP, j0 = nj * TP;
-                const int jl = 4 * (tid & 31);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    f32x4 wv[8];
+                for (int it = 0; it < 8; ++it) {
+                    const int il = (tid >> 5) + 16 * it;
+                    f32x4 g4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i0 + il < P) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int il = (tid >> 5) + 8 * (8 * hf + it);
-                        wv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (i0 + il < P) {
-                            const float* wr = wn + (size_t)(i0 + il) * P + j0 + jl;
-                            if ((P & 3) == 0) {
-                                if (j0 + jl < P) wv[it] = *reinterpret_cast<const f32x4*>(wr);
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    if (j0 + jl + q < P) wv[it][q] = wr[q];
-                            }
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            if (j0 + jl + q < P) g4[q] = g_of(i0 + il, j0 + jl + q, wv[it][q]);
                     }
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int il = (tid >> 5) + 8 * (8 * hf + it);
-                        f32x4 g4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (i0 + il < P) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (j0 + jl + q < P) g4[q] = g_of(i0 + il, j0 + jl + q, wv[it][q]);
-                        }
-                        *reinterpret_cast<f32x4*>(Gs + il * WB_GS + jl) = g4;
-                    }
+                    *reinterpret_cast<f32x4*>(Gs + il * WB_GS + jl) = g4;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the code tiles' copies
                 __syncthreads();
-                // ---- d anchors: rows i (32 per wave) x channels, contraction over the tile's columns j
-#pragma unroll 2
-                for (int ks = 0; ks < TP / 16; ++ks) {
-                    float gv[8];
-                    const float* gp = Gs + (32 * wave + r) * WB_GS + 16 * ks + 8 * h;
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                {                                                         // the next tile's w: in flight during the products below
+                    const int nj2 = nj + 1 < nbp ? nj + 1 : 0, mi2 = nj + 1 < nbp ? mi : mi + 1;
+                    if (mi2 < nbp) fetch(mi2, nj2);
+                }
+                if (p.debug & 1) {
+                } else if (role == 0) {
+                    // ---- d anchors: rows i (32 per wave) x channels, contraction over the tile's columns j
+#pragma unroll 1
+                    for (int ks = 0; ks < TP / 16; ++ks) {
+                        float gv[8];
+                        const float* gp = Gs + (32 * wq + r) * WB_GS + 16 * ks + 8 * h;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { gv[q] = g0[q]; gv[4 + q] = g1[q]; }
-                    f16x8 ah, al;
-                    split8(gv, gscale, ah, al);
+                        for (int q = 0; q < 4; ++q) { gv[q] = g0[q]; gv[4 + q] = g1[q]; }
+                        f16x8 ah, al;
+                        split8(gv, gscale, ah, al);
 #pragma unroll
-                    for (int kb = 0; kb < WB_MAXKB; ++kb) {
-                        if (kb < NK) {
-                            const bool kv = 32 * kb + r < Kr;
-                            const half_t* tp = Tb + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
-                            f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
-                            if (!kv) { bh = f16x8{}; bl = f16x8{}; }
-                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accA[kb], 0, 0, 0);
-                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accA[kb], 0, 0, 0);
-                            accA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accA[kb], 0, 0, 0);
+                        for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                            if (kb < NK) {
+                                const bool kv = 32 * kb + r < Kr;
+                                const half_t* tp = Tb + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
+                                f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
+                                if (!kv) { bh = f16x8{}; bl = f16x8{}; }
+                                acc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][kb], 0, 0, 0);
+                                acc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][kb], 0, 0, 0);
+                                acc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][kb], 0, 0, 0);
+                            }
                         }
                     }
-                }
-                // ---- d rows of the second operand: rows j (32 per wave) x channels, contraction over the tile's rows i: G read along columns
-#pragma unroll 2
-                for (int ks = 0; ks < TP / 16; ++ks) {
-                    float gv[8];
-                    const float* gp = Gs + (16 * ks + 8 * h) * WB_GS + 32 * wave + r;
+                } else {
+                    // ---- d rows of the second operand: rows j (32 per wave) x channels, contraction over the tile's rows i: G read along columns
+#pragma unroll 1
+                    for (int ks = 0; ks < TP / 16; ++ks) {
+                        float gv[8];
+                        const float* gp = Gs + (16 * ks + 8 * h) * WB_GS + 32 * wq + r;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gv[e] = gp[e * WB_GS];
-                    f16x8 ah, al;
-                    split8(gv, gscale, ah, al);
+                        for (int e = 0; e < 8; ++e) gv[e] = gp[e * WB_GS];
+                        f16x8 ah, al;
+                        split8(gv, gscale, ah, al);
 #pragma unroll
-                    for (int kb = 0; kb < WB_MAXKB; ++kb) {
-                        if (kb < NK) {
-                            const bool kv = 32 * kb + r < Kr;
-                            const half_t* tp = Ta + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
-                            f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
-                            if (!kv) { bh = f16x8{}; bl = f16x8{}; }
-                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accB[nj][kb], 0, 0, 0);
-                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accB[nj][kb], 0, 0, 0);
-                            accB[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accB[nj][kb], 0, 0, 0);
+                        for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                            if (kb < NK) {
+                                const bool kv = 32 * kb + r < Kr;
+                                const half_t* tp = Ta + (size_t)(kv ? 32 * kb + r : 0) * WB_TS + 16 * ks + 8 * h;
+                                f16x8 bh = *reinterpret_cast<const f16x8*>(tp), bl = *reinterpret_cast<const f16x8*>(tp + Kr * WB_TS);
+                                if (!kv) { bh = f16x8{}; bl = f16x8{}; }
+                                acc[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nj][kb], 0, 0, 0);
+                                acc[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[nj][kb], 0, 0, 0);
+                                acc[nj][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nj][kb], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
         }
-        // the anchors' rows of block mi are complete.  C/D layout: column (channel) = lane & 31 (+ 32 kb), row = (e & 3) + 8 (e >> 2) + 4 h
-        float* da = p.d_anchor + (size_t)n * P * K;
-#pragma unroll
-        for (int kb = 0; kb < WB_MAXKB; ++kb) {
-            const int k = 32 * kb + r;
-            if (kb < NK && k < K) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = mi * TP + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (i < P) da[(size_t)i * K + k] = accA[kb][e] * unscale;
-                }
-            }
-        }
-    }
-    float* dr = p.d_rows + (size_t)n * P * K;
-#pragma unroll
-    for (int nj = 0; nj < WB_MAXNB; ++nj) {
-        if (nj < nbp) {
+        if (role == 0) {
+            // the anchors' rows of block mi are complete.  C/D layout: column (channel) = lane & 31 (+ 32 kb), row = (e & 3) + 8 (e >> 2) + 4 h
+            float* da = p.d_anchor + (size_t)n * P * K;
 #pragma unroll
             for (int kb = 0; kb < WB_MAXKB; ++kb) {
                 const int k = 32 * kb + r;
                 if (kb < NK && k < K) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int j = nj * TP + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (j < P) dr[(size_t)j * K + k] = accB[nj][kb][e] * unscale;
+                        const int i = mi * TP + 32 * wq + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (i < P) da[(size_t)i * K + k] = acc[0][kb][e] * unscale;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][kb][e] = 0.f;
+            }
+        }
+    }
+    if (role == 1) {
+        float* dr = p.d_rows + (size_t)n * P * K;
+#pragma unroll
+        for (int nj = 0; nj < WB_MAXNB; ++nj) {
+            if (nj < nbp) {
+#pragma unroll
+                for (int kb = 0; kb < WB_MAXKB; ++kb) {
+                    const int k = 32 * kb + r;
+                    if (kb < NK && k < K) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int j = nj * TP + 32 * wq + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (j < P) dr[(size_t)j * K + k] = acc[nj][kb][e] * unscale;
+                        }
                     }
                 }
             }
@@ -454,26 +509,20 @@ hipError_t launch_wide_fwd(const WideFwdArgs& a, hipStream_t stream)
     float* rowsum = reinterpret_cast<float*>(ws + g.o_rowsum);
     const int B = a.B, P = g.P, nnb = a.n_neg * B;
     hipError_t e;
-    // the bilinear coordinates travel with the context: the backward is given the permutations only
-    if ((e = hipMemcpyAsync(ctx + g.c_co1, a.coords1, (size_t)B * P * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(ctx + g.c_co2, a.coords2, (size_t)B * P * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
     struct Src { const StegoMap* f; const StegoMap* c; const float* co; const long long* idx; int first, n; };
     const Src src[3] = {{a.feats, a.code, a.coords1, nullptr, 0, B}, {a.feats_pos, a.code_pos, a.coords2, nullptr, B, B},
                         {a.feats, a.code, a.coords2, a.perms, 2 * B, nnb}};
     float* frs = reinterpret_cast<float*>(ws + g.o_frs);
     float* crs = reinterpret_cast<float*>(ws + g.o_crs);
+    // features and codes of a source in ONE launch: the same points, the code map's taps ride in the feature row's round trip
     for (const Src& q : src) {
         if (q.n == 0) continue;
-        if ((e = launch_sample_panels(q.f, q.idx, q.n, a.C, a.H, a.W, q.co, B, a.S, 1, ws + g.o_fpan + (size_t)q.first * g.fimg,
-                                      frs + (size_t)q.first * g.nb * TP, nullptr, nullptr, stream)) != hipSuccess) return e;
+        if ((e = launch_sample_panels2(q.f, a.C, ws + g.o_fpan + (size_t)q.first * g.fimg, frs + (size_t)q.first * g.nb * TP, nullptr, nullptr,
+                                       q.c, a.K, ws + g.o_cpan + (size_t)q.first * g.cimg, crs + (size_t)q.first * g.nb * TP,
+                                       cn + (size_t)q.first * P * a.K, inv + (size_t)q.first * P, q.idx, q.n, a.H, a.W, q.co, B, a.S, 1, stream)) != hipSuccess) return e;
     }
     if ((e = launch_dense_corr_panels_seg(ws + g.o_fpan, frs, B, ws + g.o_fpan, frs, g.n_img, a.C, P, P, fd, nullptr, nullptr, 0,
                                           a.pointwise ? rowsum : nullptr, stream)) != hipSuccess) return e;
-    for (const Src& q : src) {
-        if (q.n == 0) continue;
-        if ((e = launch_sample_panels(q.c, q.idx, q.n, a.K, a.H, a.W, q.co, B, a.S, 1, ws + g.o_cpan + (size_t)q.first * g.cimg,
-                                      crs + (size_t)q.first * g.nb * TP, cn + (size_t)q.first * P * a.K, inv + (size_t)q.first * P, stream)) != hipSuccess) return e;
-    }
     if ((e = launch_dense_corr_panels_seg(ws + g.o_cpan, crs, B, ws + g.o_cpan, crs, g.n_img, a.K, P, P, a.intra_cd, a.inter_cd, a.neg_cd, B,
                                           nullptr, stream)) != hipSuccess) return e;
     WidePwParams p{};
@@ -484,10 +533,13 @@ hipError_t launch_wide_fwd(const WideFwdArgs& a, hipStream_t stream)
     p.shift[0] = a.shift[0]; p.shift[1] = a.shift[1]; p.shift[2] = a.shift[2];
     p.cmin = a.cmin; p.cmax = a.cmax;
     p.n_sets = g.n_sets; p.B = B; p.P = P; p.pointwise = a.pointwise; p.keep_w = a.saved_w ? 1 : 0;
-    hipLaunchKernelGGL(wide_set_mean_kernel, dim3(g.n_sets), dim3(256), 0, stream, p);
+    p.co_src[0] = a.coords1; p.co_src[1] = a.coords2;
+    p.co_dst[0] = reinterpret_cast<float*>(ctx + g.c_co1); p.co_dst[1] = reinterpret_cast<float*>(ctx + g.c_co2);
+    const int copy_blocks = 2 * ((B * P * 2 + WIDE_COPY_CHUNK - 1) / WIDE_COPY_CHUNK);
+    hipLaunchKernelGGL(wide_set_mean_kernel, dim3(g.n_sets + copy_blocks), dim3(1024), 0, stream, p);
     const long long rows = (long long)g.n_img * P;
     hipLaunchKernelGGL(wide_pointwise_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(wide_loss_means_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(wide_loss_means_kernel, dim3(3), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -503,9 +555,6 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     const float* co2 = reinterpret_cast<const float*>(ctx + g.c_co2);
     const int B = a.B, P = g.P, K = a.K, nnb = a.n_neg * B;
     hipError_t e;
-    const size_t map_bytes = (size_t)B * a.H * a.W * K * 4;
-    if ((e = hipMemsetAsync(a.d_code, 0, map_bytes, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(a.d_code_pos, 0, map_bytes, stream)) != hipSuccess) return e;
     WideBwdParams p{};
     p.w = a.saved_w; p.cn = cn;
     p.g_intra = a.g_intra; p.g_inter = a.g_inter; p.g_neg = a.g_neg; p.g_neg_stride = a.g_neg_stride;
@@ -513,16 +562,22 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     p.d_rows = reinterpret_cast<float*>(ws + g.b_rows);
     p.d_anchor = reinterpret_cast<float*>(ws + g.b_anchor);
     p.B = B; p.P = P; p.K = K; p.Kr = g.Kr; p.n_sets = g.n_sets;
+    p.debug = (knob(KNOB_DEBUG_BWD) >> 16) & 7;
     p.tiles_out = ws + g.b_tiles;
     p.tiles = p.tiles_out;
     p.tile_bytes = g.tile_bytes;
     if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_code_tiles_kernel), g.tile_bytes)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb), dim3(256), g.tile_bytes, stream, p);
+    p.zero[0] = a.d_code; p.zero[1] = a.d_code_pos;
+    p.zero_floats = (long long)B * a.H * a.W * K;
+    const int zero_blocks = 2 * (int)((p.zero_floats + WB_ZERO_CHUNK - 1) / WB_ZERO_CHUNK);
+    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb + zero_blocks), dim3(512), g.tile_bytes, stream, p);
     const int lds = 128 * WB_GS * 4 + 2 * g.tile_bytes;
     if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_bwd_kernel), lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(WB_THREADS), lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    // the backward of norm() and of the sampling: anchors (their rows were the second operand of the intra set and the first of every set)
+    // the backward of norm() and of the sampling, added into the code gradients the tile kernel's spare workgroups zeroed: one wave per point, global
+    // fp32 atomics.  (Measured and dropped: one workgroup per (map, image, band of pixel rows) accumulating its band in LDS - no global atomics,
+    // plain stores - was 190 us against 88: ds_add_f32 runs at ~140 cycles per wave instruction, profiles/r05g_wide_path.txt)
     StegoMap dm{a.d_code, (int64_t)a.H * a.W * K, 1, (int64_t)a.W * K, K}, dmp{a.d_code_pos, (int64_t)a.H * a.W * K, 1, (int64_t)a.W * K, K};
     const size_t rowsB = (size_t)B * P;
     if ((e = launch_sample_scatter(p.d_rows, cn, inv, &dm, nullptr, B, K, a.H, a.W, co1, B, a.S, p.d_anchor, g.n_sets, (long long)rowsB * K,

@@ -42,7 +42,8 @@ __device__ __forceinline__ void point_of(const GatherParams& p, int gw, int& n, 
     q = gw - n * p.P;
     img = p.index ? p.index[n] : (long long)n;
     const int hh = q / p.S, ww = q - hh * p.S;          // point (h, w) reads coords[w][h] (the permute of modules.py:288)
-    const float* c = p.coords + ((size_t)(n % p.n_coords) * p.P + (size_t)ww * p.S + hh) * 2;
+    const int nc = p.n_coords < 0 ? -p.n_coords : p.n_coords;
+    const float* c = p.coords + ((size_t)(n % nc) * p.P + (size_t)ww * p.S + hh) * 2;
     make_taps(c[0], c[1], p.H, p.W, yx, w);
 }
 
@@ -116,6 +117,10 @@ __global__ void __launch_bounds__(256) sample_scatter_kernel(const GatherParams 
         const long long oc = (long long)c * p.map.sc;
         const float gc = grad(c);
         const float v = yn ? invn * (gc - yn[c] * proj) : gc;
+        if (p.n_coords < 0) {          // (tools: plain stores instead of atomics - wrong sums, the cost of the atomics by difference)
+            base[o0 + oc] = w.x * v; base[o1 + oc] = w.y * v; base[o2 + oc] = w.z * v; base[o3 + oc] = w.w * v;
+            continue;
+        }
         unsafeAtomicAdd(base + o0 + oc, w.x * v);
         unsafeAtomicAdd(base + o1 + oc, w.y * v);
         unsafeAtomicAdd(base + o2 + oc, w.z * v);
@@ -128,18 +133,120 @@ __global__ void __launch_bounds__(256) sample_scatter_kernel(const GatherParams 
 // (hi | lo) into the operand image dense_prep_kernel would have made of the fp32 rows - [n][128-point block][64-channel chunk][hi | lo][128][72]
 // (csrc/dense_corr.hip) - with 1 / scale per row beside it.  For tensors that carry a gradient (the codes) the normalised fp32 rows and
 // 1 / max(|row|, eps) are written too: what the backward of norm() and of the correlation needs.  The fp32 rows of the FEATURES never exist.
-struct PanelParams {
-    GatherParams g;             // (io / dmap_p unused)
+struct PanelSide {
+    MapL map;
+    int C, NCH;
     half_t* panels;
     float* row_scale;           // [N][nb * 128]
     float* rows_out;            // optional [N][P][C]
     float* inv_out;             // optional [N][P]
-    int nb, NCH, normalize;
 };
 
-// VW = channels per lane and load: 4 (16-byte loads; C % 4 == 0, C <= 1024), 2 (8-byte loads; C % 2 == 0, C <= 512: the reference's dim = 70), 0 = any
-// layout, scalar loads, two passes over the row.
+struct PanelParams {
+    GatherParams g;             // (map / io / dmap_p unused: the maps are in `side`)
+    PanelSide side[2];          // the loss samples two maps at the same points - features and codes: one launch, the second map's taps in the
+    int nb, normalize;          // same round trip (side[1] unused by the one-map instantiations)
+};
+
+// One row of one map.  VW = channels per lane and load: 4 (16-byte loads; C % 4 == 0, C <= 1024), 2 (8-byte loads; C % 2 == 0, C <= 512: the
+// reference's dim = 70), 0 = any layout, scalar loads, two passes over the row.
 template <int VW>
+struct RowSampler {
+    static constexpr int MAXJ = 4, VWN = VW > 0 ? VW : 1;
+    typedef float vec_t __attribute__((ext_vector_type(VWN)));
+    vec_t v[MAXJ];
+    float ss, mx;
+    const float* base;
+    long long o0, o1, o2, o3;
+
+    __device__ __forceinline__ float blend1(const float4& w, long long oc) const
+    {
+        return __builtin_fmaf(w.w, base[o3 + oc], __builtin_fmaf(w.z, base[o2 + oc], __builtin_fmaf(w.y, base[o1 + oc], w.x * base[o0 + oc])));
+    }
+    __device__ __forceinline__ void load(const PanelSide& sd, long long img, const int4& yx, const float4& w, int lane)
+    {
+        base = sd.map.p + img * sd.map.sn;
+        o0 = (long long)(yx.x >> 16) * sd.map.sh + (long long)(yx.x & 0xffff) * sd.map.sw;
+        o1 = (long long)(yx.y >> 16) * sd.map.sh + (long long)(yx.y & 0xffff) * sd.map.sw;
+        o2 = (long long)(yx.z >> 16) * sd.map.sh + (long long)(yx.z & 0xffff) * sd.map.sw;
+        o3 = (long long)(yx.w >> 16) * sd.map.sh + (long long)(yx.w & 0xffff) * sd.map.sw;
+        ss = 0.f;
+        mx = 0.f;
+        if constexpr (VW > 0) {
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = VW * lane + 64 * VW * j;
+#pragma unroll
+                for (int e = 0; e < VW; ++e) v[j][e] = 0.f;
+                if (c < sd.C) {
+                    const vec_t a = *reinterpret_cast<const vec_t*>(base + o0 + c), b = *reinterpret_cast<const vec_t*>(base + o1 + c);
+                    const vec_t cc = *reinterpret_cast<const vec_t*>(base + o2 + c), d = *reinterpret_cast<const vec_t*>(base + o3 + c);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) {
+                        v[j][e] = __builtin_fmaf(w.w, d[e], __builtin_fmaf(w.z, cc[e], __builtin_fmaf(w.y, b[e], w.x * a[e])));
+                        ss += v[j][e] * v[j][e];
+                        mx = fmaxf(mx, fabsf(v[j][e]));
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < sd.C; c += 64) {
+                const float t = blend1(w, (long long)c * sd.map.sc);
+                ss += t * t;
+                mx = fmaxf(mx, fabsf(t));
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const PanelSide& sd, const PanelParams& pp, int n, int blk, int rl, int gw, const float4& w, int lane)
+    {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ss += __shfl_xor(ss, m, 64); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
+        const float invn = pp.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;             // norm(), modules.py:276
+        const float rs = mx * invn > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * invn)) : 1.f;
+        const float inv = invn * rs;
+        if (lane == 0) {
+            sd.row_scale[((size_t)n * pp.nb + blk) * TP + rl] = 1.f / rs;
+            if (sd.inv_out) sd.inv_out[gw] = invn;
+        }
+        const int CP = sd.NCH * KC;
+        half_t* dst = sd.panels + ((size_t)n * pp.nb + blk) * sd.NCH * (2 * TP * LDH) + rl * LDH;
+        float* rows = sd.rows_out ? sd.rows_out + (size_t)gw * sd.C : nullptr;
+        if constexpr (VW > 0) {
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = VW * lane + 64 * VW * j;
+                if (c < CP) {                                                                // (zeros up to the end of the last chunk)
+                    half_t* dh = dst + (size_t)(c >> 6) * (2 * TP * LDH) + (c & 63);
+                    unsigned h0, l0;
+                    split_f16_pair(v[j][0] * inv, v[j][1] * inv, h0, l0);
+                    if constexpr (VW == 4) {
+                        unsigned h1, l1;
+                        split_f16_pair(v[j][2] * inv, v[j][3] * inv, h1, l1);
+                        *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
+                        *reinterpret_cast<u32x2*>(dh + TP * LDH) = u32x2{l0, l1};
+                    } else {
+                        *reinterpret_cast<unsigned*>(dh) = h0;
+                        *reinterpret_cast<unsigned*>(dh + TP * LDH) = l0;
+                    }
+                    if (rows && c < sd.C) *reinterpret_cast<vec_t*>(rows + c) = v[j] * invn;
+                }
+            }
+        } else {
+            for (int c = lane; c < CP; c += 64) {
+                const float t = c < sd.C ? blend1(w, (long long)c * sd.map.sc) : 0.f;
+                unsigned h, l;
+                split_f16_pair(t * inv, 0.f, h, l);
+                half_t* dh = dst + (size_t)(c >> 6) * (2 * TP * LDH) + (c & 63);
+                *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dh + TP * LDH) = (unsigned short)(l & 0xffffu);
+                if (rows && c < sd.C) rows[c] = t * invn;
+            }
+        }
+    }
+};
+
+// VW2 < 0: one map
+template <int VW1, int VW2>
 __global__ void __launch_bounds__(256) sample_panels_kernel(const PanelParams pp)
 {
     const GatherParams& p = pp.g;
@@ -151,85 +258,13 @@ __global__ void __launch_bounds__(256) sample_panels_kernel(const PanelParams pp
     int4 yx;
     float4 w;
     point_of(p, gw, n, q, img, yx, w);
-    const float* base = p.map.p + img * p.map.sn;
-    const long long o0 = (long long)(yx.x >> 16) * p.map.sh + (long long)(yx.x & 0xffff) * p.map.sw;
-    const long long o1 = (long long)(yx.y >> 16) * p.map.sh + (long long)(yx.y & 0xffff) * p.map.sw;
-    const long long o2 = (long long)(yx.z >> 16) * p.map.sh + (long long)(yx.z & 0xffff) * p.map.sw;
-    const long long o3 = (long long)(yx.w >> 16) * p.map.sh + (long long)(yx.w & 0xffff) * p.map.sw;
-    const int blk = q >> 7, rl = q & 127, CP = pp.NCH * KC;
-    half_t* dst = pp.panels + ((size_t)n * pp.nb + blk) * pp.NCH * (2 * TP * LDH) + rl * LDH;
-    float* rows = pp.rows_out ? pp.rows_out + (size_t)gw * p.C : nullptr;
-    auto blend1 = [&](long long oc) {
-        return __builtin_fmaf(w.w, base[o3 + oc], __builtin_fmaf(w.z, base[o2 + oc], __builtin_fmaf(w.y, base[o1 + oc], w.x * base[o0 + oc])));
-    };
-    float ss = 0.f, mx = 0.f;
-    constexpr int MAXJ = 4, VWN = VW > 0 ? VW : 1;
-    typedef float vec_t __attribute__((ext_vector_type(VWN)));
-    vec_t v[MAXJ];
-    if constexpr (VW > 0) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = VW * lane + 64 * VW * j;
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[j][e] = 0.f;
-            if (c < p.C) {
-                const vec_t a = *reinterpret_cast<const vec_t*>(base + o0 + c), b = *reinterpret_cast<const vec_t*>(base + o1 + c);
-                const vec_t cc = *reinterpret_cast<const vec_t*>(base + o2 + c), d = *reinterpret_cast<const vec_t*>(base + o3 + c);
-#pragma unroll
-                for (int e = 0; e < VW; ++e) {
-                    v[j][e] = __builtin_fmaf(w.w, d[e], __builtin_fmaf(w.z, cc[e], __builtin_fmaf(w.y, b[e], w.x * a[e])));
-                    ss += v[j][e] * v[j][e];
-                    mx = fmaxf(mx, fabsf(v[j][e]));
-                }
-            }
-        }
-    } else {
-        for (int c = lane; c < p.C; c += 64) {
-            const float t = blend1((long long)c * p.map.sc);
-            ss += t * t;
-            mx = fmaxf(mx, fabsf(t));
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { ss += __shfl_xor(ss, m, 64); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
-    const float invn = pp.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;                 // norm(), modules.py:276
-    const float rs = mx * invn > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * invn)) : 1.f;
-    const float inv = invn * rs;
-    if (lane == 0) {
-        pp.row_scale[((size_t)n * pp.nb + blk) * TP + rl] = 1.f / rs;
-        if (pp.inv_out) pp.inv_out[gw] = invn;
-    }
-    if constexpr (VW > 0) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = VW * lane + 64 * VW * j;
-            if (c < CP) {                                                                    // (zeros up to the end of the last chunk)
-                half_t* dh = dst + (size_t)(c >> 6) * (2 * TP * LDH) + (c & 63);
-                unsigned h0, l0;
-                split_f16_pair(v[j][0] * inv, v[j][1] * inv, h0, l0);
-                if constexpr (VW == 4) {
-                    unsigned h1, l1;
-                    split_f16_pair(v[j][2] * inv, v[j][3] * inv, h1, l1);
-                    *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
-                    *reinterpret_cast<u32x2*>(dh + TP * LDH) = u32x2{l0, l1};
-                } else {
-                    *reinterpret_cast<unsigned*>(dh) = h0;
-                    *reinterpret_cast<unsigned*>(dh + TP * LDH) = l0;
-                }
-                if (rows && c < p.C) *reinterpret_cast<vec_t*>(rows + c) = v[j] * invn;
-            }
-        }
-    } else {
-        for (int c = lane; c < CP; c += 64) {
-            const float t = c < p.C ? blend1((long long)c * p.map.sc) : 0.f;
-            unsigned h, l;
-            split_f16_pair(t * inv, 0.f, h, l);
-            half_t* dh = dst + (size_t)(c >> 6) * (2 * TP * LDH) + (c & 63);
-            *reinterpret_cast<unsigned short*>(dh) = (unsigned short)(h & 0xffffu);
-            *reinterpret_cast<unsigned short*>(dh + TP * LDH) = (unsigned short)(l & 0xffffu);
-            if (rows && c < p.C) rows[c] = t * invn;
-        }
-    }
+    const int blk = q >> 7, rl = q & 127;
+    RowSampler<VW1> a;
+    RowSampler<(VW2 < 0 ? 0 : VW2)> b;
+    a.load(pp.side[0], img, yx, w, lane);
+    if constexpr (VW2 >= 0) b.load(pp.side[1], img, yx, w, lane);
+    a.finish(pp.side[0], pp, n, blk, rl, gw, w, lane);
+    if constexpr (VW2 >= 0) b.finish(pp.side[1], pp, n, blk, rl, gw, w, lane);
 }
 
 static int check_sample(const StegoMap* map, int32_t N, int32_t C, int32_t H, int32_t W, const float* coords, int32_t n_coords, int32_t S, const void* io)
@@ -258,28 +293,56 @@ static GatherParams make_params(const StegoMap* map, const int64_t* index, int32
     return p;
 }
 
-hipError_t launch_sample_panels(const StegoMap* map, const long long* index, int N, int C, int H, int W, const float* coords, int n_coords, int S,
-                                int normalize, void* panels, float* row_scale, float* rows_out, float* inv_out, hipStream_t stream)
+static int panel_vw(const StegoMap* map, int C, const float* rows_out)
 {
-    if (N == 0) return hipSuccess;
-    PanelParams pp;
-    pp.g = make_params(map, reinterpret_cast<const int64_t*>(index), N, C, H, W, coords, n_coords, S, nullptr, nullptr);
-    pp.panels = static_cast<half_t*>(panels);
-    pp.row_scale = row_scale;
-    pp.rows_out = rows_out;
-    pp.inv_out = inv_out;
-    pp.nb = (pp.g.P + TP - 1) / TP;
-    pp.NCH = (C + KC - 1) / KC;
-    pp.normalize = normalize ? 1 : 0;
     auto aligned = [&](int vw) {
         return map->stride_c == 1 && C % vw == 0 && C <= 256 * vw && map->stride_n % vw == 0 && map->stride_h % vw == 0 && map->stride_w % vw == 0 &&
                reinterpret_cast<uintptr_t>(map->data) % (4 * vw) == 0 && (!rows_out || reinterpret_cast<uintptr_t>(rows_out) % (4 * vw) == 0);
     };
+    return aligned(4) ? 4 : aligned(2) ? 2 : 0;
+}
+
+static PanelSide panel_side(const StegoMap* map, int C, void* panels, float* row_scale, float* rows_out, float* inv_out)
+{
+    PanelSide sd;
+    sd.map = MapL{map->data, map->stride_n, map->stride_c, map->stride_h, map->stride_w};
+    sd.C = C;
+    sd.NCH = (C + KC - 1) / KC;
+    sd.panels = static_cast<half_t*>(panels);
+    sd.row_scale = row_scale;
+    sd.rows_out = rows_out;
+    sd.inv_out = inv_out;
+    return sd;
+}
+
+// one map (map2 == nullptr) or two maps of the same H x W sampled at the same points
+hipError_t launch_sample_panels2(const StegoMap* map, int C, void* panels, float* row_scale, float* rows_out, float* inv_out,
+                                 const StegoMap* map2, int C2, void* panels2, float* row_scale2, float* rows_out2, float* inv_out2,
+                                 const long long* index, int N, int H, int W, const float* coords, int n_coords, int S, int normalize, hipStream_t stream)
+{
+    if (N == 0) return hipSuccess;
+    PanelParams pp;
+    pp.g = make_params(map, reinterpret_cast<const int64_t*>(index), N, C, H, W, coords, n_coords, S, nullptr, nullptr);
+    pp.side[0] = panel_side(map, C, panels, row_scale, rows_out, inv_out);
+    pp.side[1] = map2 ? panel_side(map2, C2, panels2, row_scale2, rows_out2, inv_out2) : pp.side[0];
+    pp.nb = (pp.g.P + TP - 1) / TP;
+    pp.normalize = normalize ? 1 : 0;
+    const int v1 = panel_vw(map, C, rows_out), v2 = map2 ? panel_vw(map2, C2, rows_out2) : -1;
     const dim3 grid((unsigned)(((long long)N * pp.g.P + 3) / 4)), block(256);
-    if (aligned(4)) hipLaunchKernelGGL(sample_panels_kernel<4>, grid, block, 0, stream, pp);
-    else if (aligned(2)) hipLaunchKernelGGL(sample_panels_kernel<2>, grid, block, 0, stream, pp);
-    else hipLaunchKernelGGL(sample_panels_kernel<0>, grid, block, 0, stream, pp);
+#define STEGO_SP_CASE(A, B) if (v1 == A && v2 == B) hipLaunchKernelGGL((sample_panels_kernel<A, B>), grid, block, 0, stream, pp)
+    STEGO_SP_CASE(4, -1); else STEGO_SP_CASE(2, -1); else STEGO_SP_CASE(0, -1);
+    else STEGO_SP_CASE(4, 4); else STEGO_SP_CASE(4, 2); else STEGO_SP_CASE(4, 0);
+    else STEGO_SP_CASE(2, 4); else STEGO_SP_CASE(2, 2); else STEGO_SP_CASE(2, 0);
+    else STEGO_SP_CASE(0, 4); else STEGO_SP_CASE(0, 2); else STEGO_SP_CASE(0, 0);
+#undef STEGO_SP_CASE
     return hipGetLastError();
+}
+
+hipError_t launch_sample_panels(const StegoMap* map, const long long* index, int N, int C, int H, int W, const float* coords, int n_coords, int S,
+                                int normalize, void* panels, float* row_scale, float* rows_out, float* inv_out, hipStream_t stream)
+{
+    return launch_sample_panels2(map, C, panels, row_scale, rows_out, inv_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, index, N, H, W, coords,
+                                 n_coords, S, normalize, stream);
 }
 
 hipError_t launch_sample_scatter(const float* g_rows, const float* rows_n, const float* inv, const StegoMap* d_map, const long long* index, int N, int C,
@@ -294,6 +357,7 @@ hipError_t launch_sample_scatter(const float* g_rows, const float* rows_n, const
     p.extra = extra;
     p.n_extra = extra ? n_extra : 0;
     p.extra_stride = extra_stride;
+    if (knob(KNOB_DEBUG_BWD) & (1 << 19)) p.n_coords = -p.n_coords;
     const dim3 grid((unsigned)(((long long)N * p.P + 3) / 4)), block(256);
     hipLaunchKernelGGL(sample_scatter_kernel, grid, block, 0, stream, p);
     return hipGetLastError();

@@ -478,7 +478,7 @@ def test_feature_samples_above_11_and_wide_codes(S, K, C, layout):
     if native:
         tt = {k: torch.from_numpy(v).to(DEV) for k, v in inputs.items()}
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), capi.PREC_F16X3)
-        assert capi.corr_fwd_launches(desc, tt["feats"], tt["feats_pos"], tt["code"], tt["code_pos"]) == 11
+        assert capi.corr_fwd_launches(desc, tt["feats"], tt["feats_pos"], tt["code"], tt["code_pos"]) == 8
     r = _run(inputs, d["perms"], cfg, layout=layout, precision="f16x3")
     ref = O.corr_loss_forward(**inputs, perms=d["perms"], cfg=cfg)
     assert_close(r["out"][1], ref.pos_intra_cd, atol_frac=5e-4, what="intra_cd")
