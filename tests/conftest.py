@@ -53,7 +53,8 @@ class GoldenCase:
 
 
 ALL_CASES = ["small_default", "small_nopointwise", "small_noclamp_stab", "small_stab",
-             "small_dinolike_S11", "small_noneg", "cfg1_B4_vits8", "cfg1_B4_vits8_dinolike", "cfg4_B2_vitb8"]
+             "small_dinolike_S11", "small_noneg", "cfg1_B4_vits8", "cfg1_B4_vits8_dinolike", "cfg4_B2_vitb8",
+             "wide_S12_small", "wide_S16_vits8"]        # (round 5: feature_samples 12 / 16, the shapes of csrc/corr_wide.hip)
 SMALL_CASES = [c for c in ALL_CASES if c.startswith("small")]
 
 
