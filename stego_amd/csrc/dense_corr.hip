@@ -431,6 +431,152 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
     }
 }
 
+// ---------------------------------------------------------------------------------------------- round 5: two row blocks per workgroup
+// dense_rowpair_kernel (operands of <= MAXCH = 2 chunks: the codes - eight waves have 256 registers each, the 192 of a C = 384 row do not fit):
+// the row-block kernel for prepared A operands with EIGHT waves - 256 rows of A in registers (two 128-row blocks, 32 rows
+// per wave), the B chunks of the image streamed ONCE for both (the point sets of the loss have two row blocks per image: each B chunk was
+// read by two workgroups before), two waves per SIMD that cover each other's LDS reads.  Two ring stages (one copy in flight), the output
+// slabs of all eight waves parked in a region of their own (no barrier in front of the park), 16-byte stores, row sums as above.
+constexpr int DR2_THREADS = 512;
+template <int MAXCH>
+__global__ void __launch_bounds__(DR2_THREADS) dense_rowpair_kernel(const DenseParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ra_s = reinterpret_cast<float*>(smem + 2 * DC_SIDE);              // [256] 1 / row scale of the two A blocks
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NCH = prm.NCH;
+    const int nsb = (prm.nbA + 1) >> 1;                                      // row super-blocks per image
+    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int n = (sl / nsb) * 8 + x, sb = sl % nsb;
+    if (n >= prm.B) return;
+    const int r = lane & 31, half = lane >> 5;
+    const int mi = 2 * sb + (wave >> 2), wq = wave & 3;                      // my 128-row block and my 32 rows of it
+    const bool live = mi < prm.nbA && mi * TP + 32 * wq < prm.M;            // (a wave whose rows are all beyond M only keeps the barriers)
+    const int na = prm.a_mod > 0 ? n % prm.a_mod : n;
+    f16x8 Ah[MAXCH][KC / 16], Al[MAXCH][KC / 16];
+    {
+        const int mia = mi < prm.nbA ? mi : 0;
+        const half_t* ap = static_cast<const half_t*>(prm.imgA) + ((size_t)na * prm.nbA + mia) * NCH * (2 * TP * LDH) + (32 * wq + r) * LDH + 8 * half;
+        if (half == 0) ra_s[32 * wave + r] = prm.rsA[((size_t)na * prm.nbA + mia) * TP + 32 * wq + r];
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                if (c < NCH && live) {
+                    Ah[c][ks] = *reinterpret_cast<const f16x8*>(ap + (size_t)c * (2 * TP * LDH) + 16 * ks);
+                    Al[c][ks] = *reinterpret_cast<const f16x8*>(ap + (size_t)c * (2 * TP * LDH) + TP * LDH + 16 * ks);
+                } else {
+                    Ah[c][ks] = f16x8{};
+                    Al[c][ks] = f16x8{};
+                }
+            }
+    }
+    __syncthreads();                                       // ra_s
+    const unsigned char* Bimg = static_cast<const unsigned char*>(prm.imgB) + (size_t)n * prm.nbB * NCH * DC_SIDE;
+    const unsigned smem_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)smem);
+    const int nstage = prm.nbB * NCH;
+    auto issue = [&](int g) {
+        const unsigned char* src = Bimg + (size_t)g * DC_SIDE + lane * 16;
+        const unsigned dst = smem_addr + (g & 1) * DC_SIDE;
+        for (int pc = wave; pc < DC_SIDE / 1024; pc += DR2_THREADS / 64) dense_dma_piece(src + pc * 1024, dst + pc * 1024);
+    };
+    issue(0);
+    float* outn = prm.out + (size_t)n * prm.M * prm.N;
+    if (prm.seg > 0 && n >= prm.seg) outn = n < 2 * prm.seg ? prm.out1 + (size_t)(n - prm.seg) * prm.M * prm.N : prm.out2 + (size_t)(n - 2 * prm.seg) * prm.M * prm.N;
+    constexpr int LO = TP * LDH;
+    float* park = reinterpret_cast<float*>(smem + 2 * DC_SIDE + 1024) + wave * (32 * DR_PKS);
+    int g = 0;
+    float rsum[8];                     // row 4 k + (lane >> 4) of the wave's 32
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rsum[e] = 0.f;
+    for (int nj = 0; nj < prm.nbB; ++nj) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (c < NCH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // chunk g landed (and this wave's stores of the previous block left)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (g + 1 < nstage) issue(g + 1);
+                if (live) {
+                    const half_t* bp = reinterpret_cast<const half_t*>(smem + (g & 1) * DC_SIDE) + r * LDH + 8 * half;
+#pragma unroll
+                    for (int ks = 0; ks < KC / 16; ++ks) {
+                        f16x8 bh[4], bl[4];
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                            bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                    }
+                }
+                ++g;
+            }
+        }
+        if (!live) continue;
+        // ---- my 32 x 128 slab through the wave's own park region, 64 columns at a time: 16-byte stores, 256 contiguous bytes per quarter wave
+        const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
+        const int c4 = 4 * (lane & 15);
+        const bool v4 = (prm.N & 3) == 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int ni = 2 * pass + nh;
+                const float sb2 = rb[32 * ni + (lane & 31)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    park[rl * DR_PKS + 32 * nh + (lane & 31)] = acc[ni][e] * (ra_s[32 * wave + rl] * sb2);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // (one wave: its LDS operations execute in order)
+            const int col = nj * TP + 64 * pass + c4;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rl = 4 * k + (lane >> 4);
+                const int row = mi * TP + 32 * wq + rl;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(park + rl * DR_PKS + c4);
+                float sm = 0.f;
+                if (row < prm.M) {
+                    float* o = outn + (size_t)row * prm.N + col;
+                    if (v4 && col < prm.N) {
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
+                        sm = (v[0] + v[1]) + (v[2] + v[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < prm.N) { __builtin_nontemporal_store(v[q], o + q); sm += v[q]; }
+                    }
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) sm += __shfl_xor(sm, m, 64);
+                rsum[k] += sm;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the reads are done before the next pass overwrites the slab
+        }
+    }
+    if (prm.rowsum && live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = mi * TP + 32 * wq + 4 * k + (lane >> 4);
+            if ((lane & 15) == 0 && row < prm.M) prm.rowsum[(size_t)n * prm.M + row] = rsum[k];
+        }
+    }
+}
+
 size_t dense_workspace_bytes(int B, int C, int M, int N)
 {
     const size_t nbA = (M + TP - 1) / TP, nbB = (N + TP - 1) / TP, NCH = (C + KC - 1) / KC;
@@ -498,6 +644,13 @@ hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int 
     prm.out1 = out1; prm.out2 = out2; prm.seg = seg;
     prm.normalize = (knob(KNOB_DEBUG) >> 16) & 7;          // (tools: ablations of the row-block kernel)
     if (prm.NCH <= DR_MAXCH && !(knob(KNOB_DEBUG) & 8192)) {
+        if (prm.nbA >= 2 && prm.NCH <= 2 && !(knob(KNOB_DEBUG) & (1 << 20))) {  // (debug bit 20: one row block per workgroup)
+            const int ldsp = 2 * DC_SIDE + 1024 + (DR2_THREADS / 64) * 32 * DR_PKS * 4;
+            hipError_t ep = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowpair_kernel<2>), ldsp);
+            if (ep != hipSuccess) return ep;
+            hipLaunchKernelGGL(dense_rowpair_kernel<2>, dim3((unsigned)(((B + 7) / 8) * 8 * ((prm.nbA + 1) / 2))), dim3(DR2_THREADS), ldsp, stream, prm);
+            return hipGetLastError();
+        }
         const dim3 grid((unsigned)(((B + 7) / 8) * 8 * prm.nbA));
         if (knob(KNOB_DEBUG) & (1 << 19)) {                     // (tools: three ring stages, one workgroup per CU)
             const int lds3 = 3 * DC_SIDE + 512;
