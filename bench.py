@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (B)")
     ap.add_argument("--workload", default="vits8_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--feature-samples", type=int, default=0,
+                    help="cfg.feature_samples (default: the reference's 11); 12 .. 16 run the multi-launch path of csrc/corr_wide.hip")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="contraction arithmetic of the feature correlation: f16x3 = fp16 hi+lo split products on the matrix "
                          "cores with f32 accumulation (22-bit products; measured error equals the f32 path); f32 = "
@@ -296,6 +298,8 @@ def main():
 
     cfg = Cfg()
     cfg.corr_precision = args.precision
+    if args.feature_samples:
+        cfg.feature_samples = args.feature_samples
     C, H, W, K = WORKLOADS[args.workload]
     B, S, n_neg = args.batch, cfg.feature_samples, cfg.neg_samples
     # the DDP exchange of the training loop: the trainer's own FlatGradReducer over a bucket of the head's size
@@ -551,8 +555,9 @@ def main():
             except Exception:       # noqa: BLE001
                 traffic = None
         d0 = sets[0]
-        fused = capi.corr_fwd_launches(desc, as_channels_last(d0["feats"]), as_channels_last(d0["feats_pos"]),
-                                       as_channels_last(d0["code"]), as_channels_last(d0["code_pos"])) == 1
+        n_launch = capi.corr_fwd_launches(desc, as_channels_last(d0["feats"]), as_channels_last(d0["feats_pos"]),
+                                          as_channels_last(d0["code"]), as_channels_last(d0["code_pos"]))
+        fused = n_launch == 1
         peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_F16_PEAK / 3.0
         if fused:
             # ONE launch does the whole forward (every distinct tensor of SURVEY.md 8(d) once): its duration prices all
@@ -568,6 +573,17 @@ def main():
             roof_mfma = dict(bound="mfma", kernel="corr_fused_kernel", achieved=fl / t_fwd / 1e12, peak=peak / 1e12,
                              unit="TFLOP/s", frac=fl / t_fwd / peak, algorithmic_flops=fl,
                              note="f32: v_mfma_f32_32x32x2_f32 peak; f16x3: dense fp16 peak / 3 (three MFMAs per product)")
+        elif n_launch > 3:
+            # feature_samples 12 .. 16 (csrc/corr_wide.hip): the whole multi-launch forward between two events
+            t_fwd = ms_main * 1e-3
+            ach = ab / t_fwd
+            what = "forward = %d launches (csrc/corr_wide.hip: samplers, two correlations, three elementwise)" % n_launch
+            roof = dict(bound="hbm", kernel=what, dominant_kernel="dense_rowblock_kernel", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=ach / HBM_PEAK, frac_of_achievable=ach / HBM_ACHIEVABLE, achievable_peak=HBM_ACHIEVABLE / 1e9,
+                        traffic=traffic, traffic_source=traffic_source, algorithmic_bytes=ab, us_per_launch={"forward (%d launches)" % n_launch: ms_main * 1e3},
+                        timing="HIP events on the launch stream around the forward's launches, input sets rotated")
+            roof_mfma = dict(bound="mfma", kernel=what, achieved=fl / t_fwd / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=fl / t_fwd / peak,
+                             algorithmic_flops=fl, note="dense fp16 peak / 3 (three MFMAs per product)")
         else:
             fin_us = ms_fin * 1e3
             kernels = {"sample_norm_kernel": ms_samp * 1e3, "corr_tile_kernel": ms_main * 1e3,
