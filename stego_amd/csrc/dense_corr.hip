@@ -307,8 +307,18 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
     auto issue = [&](int g) {
         const unsigned char* src = Bimg + (size_t)g * DC_SIDE + lane * 16;
         const unsigned dst = smem_addr + (g % NST) * DC_SIDE;
+        if constexpr (APANELS && NST == 2) {
+            // a last block with few points (144 = 128 + 16): only the rows that exist, of the hi and of the lo plane (whole 1 KB pieces)
+            const int rvb = min(TP, prm.N - (g / NCH) * TP);
+            const int np = (rvb * LDH * 2 + 1023) >> 10;               // pieces per plane, <= 18
+            for (int pc = wave; pc < 2 * np; pc += 4) {
+                const int o = (pc < np ? pc : pc - np + DC_SIDE / 2048) * 1024;
+                dense_dma_piece(src + o, dst + o);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < DC_SIDE / 4096; ++i) dense_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
+            for (int i = 0; i < DC_SIDE / 4096; ++i) dense_dma_piece(src + (wave + 4 * i) * 1024, dst + (wave + 4 * i) * 1024);
+        }
     };
     for (int s0 = 0; s0 < NST - 1 && s0 < nstage; ++s0) issue(s0);
     float* outn = prm.out + (size_t)n * prm.M * prm.N;
@@ -334,21 +344,25 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 asm volatile("" ::: "memory");
                 if (g + NST - 1 < nstage) issue(g + NST - 1);
                 const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % NST) * DC_SIDE) + r * LDH + 8 * half;
+                // (prepared operands: 32-column groups beyond the block's points and waves whose rows are all beyond M have nothing to multiply)
+                const int nlive = APANELS ? ((mi * TP + 32 * wave < prm.M) ? (min(TP, prm.N - nj * TP) + 31) >> 5 : 0) : 4;
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ++ks) {
                     if (APANELS && (prm.normalize & 4)) break;
                     f16x8 bh[4], bl[4];
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
-                        bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
-                        bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                        if (ni < nlive) {
+                            bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                            bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                        }
                     }
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
                 }
                 ++g;
             }
@@ -366,6 +380,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
             const bool v4 = (prm.N & 3) == 0;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
+                if (nj * TP + 64 * pass >= prm.N || mi * TP + 32 * wave >= prm.M) continue;          // nothing of this half slab exists
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     const int ni = 2 * pass + nh;
@@ -479,7 +494,12 @@ __global__ void __launch_bounds__(DR2_THREADS) dense_rowpair_kernel(const DenseP
     auto issue = [&](int g) {
         const unsigned char* src = Bimg + (size_t)g * DC_SIDE + lane * 16;
         const unsigned dst = smem_addr + (g & 1) * DC_SIDE;
-        for (int pc = wave; pc < DC_SIDE / 1024; pc += DR2_THREADS / 64) dense_dma_piece(src + pc * 1024, dst + pc * 1024);
+        const int rvb = min(TP, prm.N - (g / NCH) * TP);               // (a last block with few points: only the rows that exist, per plane)
+        const int np = (rvb * LDH * 2 + 1023) >> 10;
+        for (int pc = wave; pc < 2 * np; pc += DR2_THREADS / 64) {
+            const int o = (pc < np ? pc : pc - np + DC_SIDE / 2048) * 1024;
+            dense_dma_piece(src + o, dst + o);
+        }
     };
     issue(0);
     float* outn = prm.out + (size_t)n * prm.M * prm.N;
@@ -506,20 +526,23 @@ __global__ void __launch_bounds__(DR2_THREADS) dense_rowpair_kernel(const DenseP
                 if (g + 1 < nstage) issue(g + 1);
                 if (live) {
                     const half_t* bp = reinterpret_cast<const half_t*>(smem + (g & 1) * DC_SIDE) + r * LDH + 8 * half;
+                    const int nlive = (min(TP, prm.N - nj * TP) + 31) >> 5;          // 32-column groups of this block that exist
 #pragma unroll
                     for (int ks = 0; ks < KC / 16; ++ks) {
                         f16x8 bh[4], bl[4];
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
-                            bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
-                            bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                            if (ni < nlive) {
+                                bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                                bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                            }
                         }
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
                     }
                 }
                 ++g;
@@ -532,6 +555,7 @@ __global__ void __launch_bounds__(DR2_THREADS) dense_rowpair_kernel(const DenseP
         const bool v4 = (prm.N & 3) == 0;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
+            if (nj * TP + 64 * pass >= prm.N) continue;                      // nothing of this half slab exists
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
                 const int ni = 2 * pass + nh;
