@@ -346,23 +346,36 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % NST) * DC_SIDE) + r * LDH + 8 * half;
                 // (prepared operands: 32-column groups beyond the block's points and waves whose rows are all beyond M have nothing to multiply)
                 const int nlive = APANELS ? ((mi * TP + 32 * wave < prm.M) ? (min(TP, prm.N - nj * TP) + 31) >> 5 : 0) : 4;
+                if (nlive == 4) {                                      // (the full block: nothing predicated between the MFMAs)
 #pragma unroll
-                for (int ks = 0; ks < KC / 16; ++ks) {
-                    if (APANELS && (prm.normalize & 4)) break;
-                    f16x8 bh[4], bl[4];
+                    for (int ks = 0; ks < KC / 16; ++ks) {
+                        if (APANELS && (prm.normalize & 4)) break;
+                        f16x8 bh[4], bl[4];
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        if (ni < nlive) {
+                        for (int ni = 0; ni < 4; ++ni) {
                             bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
                             bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
                         }
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
                     }
+                } else {
+                    for (int ni = 0; ni < nlive; ++ni) {
+                        f32x16 a2 = ni == 0 ? acc[0] : ni == 1 ? acc[1] : acc[2];
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                        for (int ks = 0; ks < KC / 16; ++ks) {
+                            const f16x8 bh = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                            const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh, a2, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl, a2, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh, a2, 0, 0, 0);
+                        }
+                        if (ni == 0) acc[0] = a2; else if (ni == 1) acc[1] = a2; else acc[2] = a2;
+                    }
                 }
                 ++g;
             }
@@ -527,22 +540,35 @@ __global__ void __launch_bounds__(DR2_THREADS) dense_rowpair_kernel(const DenseP
                 if (live) {
                     const half_t* bp = reinterpret_cast<const half_t*>(smem + (g & 1) * DC_SIDE) + r * LDH + 8 * half;
                     const int nlive = (min(TP, prm.N - nj * TP) + 31) >> 5;          // 32-column groups of this block that exist
+                    if (nlive == 4) {
 #pragma unroll
-                    for (int ks = 0; ks < KC / 16; ++ks) {
-                        f16x8 bh[4], bl[4];
+                        for (int ks = 0; ks < KC / 16; ++ks) {
+                            f16x8 bh[4], bl[4];
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) {
-                            if (ni < nlive) {
+                            for (int ni = 0; ni < 4; ++ni) {
                                 bh[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
                                 bl[ni] = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
                             }
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
                         }
+                    } else {
+                        for (int ni = 0; ni < nlive; ++ni) {
+                            f32x16 a2 = ni == 0 ? acc[0] : ni == 1 ? acc[1] : acc[2];
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) if (ni < nlive) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh[ni], acc[ni], 0, 0, 0);
+                            for (int ks = 0; ks < KC / 16; ++ks) {
+                                const f16x8 bh = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + 16 * ks);
+                                const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + ni * 32 * LDH + LO + 16 * ks);
+                                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[c][ks], bh, a2, 0, 0, 0);
+                                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bl, a2, 0, 0, 0);
+                                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[c][ks], bh, a2, 0, 0, 0);
+                            }
+                            if (ni == 0) acc[0] = a2; else if (ni == 1) acc[1] = a2; else acc[2] = a2;
+                        }
                     }
                 }
                 ++g;
