@@ -165,7 +165,6 @@ struct WideBwdParams {
     const float* g_cd[3];       // optional dense upstreams of the three cd outputs
     float* d_rows;              // [n_img][P][K] gradient of image n's rows as the second operand of pair n
     float* d_anchor;            // [n_img][P][K] gradient of the anchors (image n % B) from pair n
-    int debug;                  // (tools: STEGO_DEBUG_BWD bits 16..18 - 1 no matrix products, 2 no w loads, 4 no code-tile copies)
     int g_neg_stride;           // 1 dense [n_neg B][P][P], 0 one scalar per element, -1 one scalar = the upstream of loss_means[2]
     int B, P, K, Kr, n_sets;
 };
@@ -299,7 +298,6 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
     auto stage_codes = [&](const half_t* T, int img, int blk) {
         const unsigned char* src = p.tiles + ((size_t)img * nbp + blk) * p.tile_bytes + lane * 16;
         const unsigned dst = smem_addr + (unsigned)(reinterpret_cast<const unsigned char*>(T) - smem);
-        if (p.debug & 4) return;
         for (int pc = wave; pc < p.tile_bytes / 1024; pc += WB_THREADS / 64) wide_dma_piece(src + pc * 1024, dst + pc * 1024);
     };
     // the w values of tile (mi, nj) this thread turns into G: rows (tid >> 5) + 16 it, columns 4 (tid & 31) .. + 3.  Loaded one tile AHEAD, while
@@ -312,7 +310,7 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
         for (int it = 0; it < 8; ++it) {
             const int il = (tid >> 5) + 16 * it;
             wv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i0 + il < P && !(p.debug & 2)) {
+            if (i0 + il < P) {
                 const float* wr = wn + (size_t)(i0 + il) * P + j0 + jl;
                 if ((P & 3) == 0) {
                     if (j0 + jl < P) wv[it] = *reinterpret_cast<const f32x4*>(wr);
@@ -361,8 +359,7 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
                     const int nj2 = nj + 1 < nbp ? nj + 1 : 0, mi2 = nj + 1 < nbp ? mi : mi + 1;
                     if (mi2 < nbp) fetch(mi2, nj2);
                 }
-                if (p.debug & 1) {
-                } else if (role == 0) {
+                if (role == 0) {
                     // ---- d anchors: rows i (32 per wave) x channels, contraction over the tile's columns j
 #pragma unroll 1
                     for (int ks = 0; ks < TP / 16; ++ks) {
@@ -562,7 +559,6 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     p.d_rows = reinterpret_cast<float*>(ws + g.b_rows);
     p.d_anchor = reinterpret_cast<float*>(ws + g.b_anchor);
     p.B = B; p.P = P; p.K = K; p.Kr = g.Kr; p.n_sets = g.n_sets;
-    p.debug = (knob(KNOB_DEBUG_BWD) >> 16) & 7;
     p.tiles_out = ws + g.b_tiles;
     p.tiles = p.tiles_out;
     p.tile_bytes = g.tile_bytes;

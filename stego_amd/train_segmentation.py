@@ -53,6 +53,8 @@ def load_config(path=None, overrides=()):
 
 MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
+MAX_FEATURE_SAMPLES_WIDE = 16    # 12 .. 16: csrc/corr_wide.hip behind the same entry points (a few launches instead of one), dim <= 88
+MAX_CODE_DIM_WIDE = 88
 MAX_CODE_DIM_ANY_PATH = 72       # above it: the single-launch forward only (its conditions are checked in __init__)
 
 
@@ -90,12 +92,12 @@ class LitUnsupervisedSegmenter(nn.Module):
                 warnings.warn("cfg.dim=%d: the fused loss kernels cover code dimensions up to %d (train_config.yml:39 ships 70; "
                               "include/stego_corr.h); this configuration runs on ContrastiveCorrelationLoss.generic_forward: same "
                               "results, several times slower" % (dim, MAX_CODE_DIM))
-            if cfg.feature_samples > MAX_FEATURE_SAMPLES:
+            if cfg.feature_samples > MAX_FEATURE_SAMPLES_WIDE or (cfg.feature_samples > MAX_FEATURE_SAMPLES and dim > MAX_CODE_DIM_WIDE):
                 import warnings
-                warnings.warn("cfg.feature_samples=%d: the fused loss kernels cover S*S <= 128 sample points per image (S <= %d; "
-                              "train_config.yml:51 ships 11); this configuration runs on ContrastiveCorrelationLoss.generic_forward "
-                              "(torch sampling + the native dense-correlation kernel): same results, several times slower"
-                              % (cfg.feature_samples, MAX_FEATURE_SAMPLES))
+                warnings.warn("cfg.feature_samples=%d, cfg.dim=%d: the single-launch loss kernels cover S <= %d (train_config.yml:51 ships 11), the "
+                              "multi-launch kernels S <= %d with dim <= %d; this configuration runs on ContrastiveCorrelationLoss.generic_forward "
+                              "(the same native samplers and correlation kernels composed in Python): same results, slower and host-bound"
+                              % (cfg.feature_samples, dim, MAX_FEATURE_SAMPLES, MAX_FEATURE_SAMPLES_WIDE, MAX_CODE_DIM_WIDE))
             if MAX_CODE_DIM_ANY_PATH < dim <= MAX_CODE_DIM:
                 # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
                 # csrc/corr_fused.hip); what it does not take runs on generic_forward like dim > 128 does (fused_kernels_cover decides per

@@ -108,3 +108,42 @@ def test_backward_kernels_do_not_spill(tmp_path):
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
     assert kernels["_ZN5stego26corr_bwd_tile_build_kernelILi5EEEvNS_9BwdParamsE"]["Occupancy [waves/SIMD]"] >= 2        # 512 threads: one workgroup per CU
     assert kernels["_ZN5stego25corr_unsample_list_kernelILi1ELi1EEEvNS_9BwdParamsE"]["Occupancy [waves/SIMD]"] >= 2     # 256 threads: two per CU
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_wide_path_kernels_spill_nothing(tmp_path):
+    """feature_samples 12 .. 16 (csrc/corr_wide.hip, csrc/dense_corr.hip): the eight-wave kernels run on 256 registers per lane - the backward
+    GEMM kernel holds 96 accumulators + 32 prefetched values, the row-pair correlation kernel the A fragments of two chunks; a scratch reload in
+    either loop drains the prefetch / the ring (an unroll of 2 in wide_bwd_kernel spilled 17 registers; the row-pair kernel at six chunks 62)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(name):
+        src = os.path.join(ROOT, "stego_amd", "csrc", name)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "stego_amd", "csrc"),
+               "-I", os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / (name + ".o")), "-Rpass-analysis=kernel-resource-usage"]
+        return subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+
+    with ThreadPoolExecutor(3) as ex:
+        results = list(ex.map(compile_one, ["corr_wide.hip", "dense_corr.hip", "sample_sets.hip"]))
+    kernels = {}
+    for res in results:
+        assert res.returncode == 0, res.stderr[-2000:]
+        name = None
+        for line in res.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                kernels[name] = {}
+                continue
+            m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+            if m and name:
+                kernels[name][m.group(1)] = int(m.group(2))
+    want = ["wide_bwd_kernel", "wide_code_tiles_kernel", "wide_pointwise_kernel", "dense_rowpair_kernel", "dense_rowblock_kernelILb1ELi2",
+            "sample_panels_kernel", "sample_scatter_kernel"]
+    for w in want:
+        hits = {k: v for k, v in kernels.items() if w in k}
+        assert hits, (w, sorted(kernels))
+        for k, v in hits.items():
+            assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (k, v)
+    bwd = [v for k, v in kernels.items() if "wide_bwd_kernel" in k][0]
+    assert bwd["Occupancy [waves/SIMD]"] >= 2, bwd               # eight waves per workgroup = two per SIMD
