@@ -20,11 +20,13 @@ for case in range(n_cases):
     B = int(rng.integers(1, max(2, 256 // (2 + n_neg)) + 1))
     B = min(B, int(os.environ.get("FUZZ_MAX_B", 12)))     # keep the fp64 oracle quick
     C = int(rng.choice([384, 768, 384, 64]))
-    S = int(rng.integers(1, 12))
+    S = int(rng.integers(1, int(os.environ.get("FUZZ_S_MAX", 11)) + 1))          # FUZZ_S_MAX=16: also the multi-launch path (csrc/corr_wide.hip)
     H, W = int(rng.integers(1, 20)), int(rng.integers(1, 20))
     K = int(rng.integers(1, 65)) * 2 if C != 64 else int(rng.integers(1, 73))
     if C == 64:
         K = min(K, 72)
+    if S > 11:                                      # 144 .. 256 points: keep the fp64 oracle quick; K <= 88 is the native limit there
+        B, K = min(B, 3), min(K, 88 if rng.random() < 0.85 else 128)
     layout = "cl" if rng.random() < 0.8 else "nchw"
     precision = "f16x3" if rng.random() < 0.6 else "f32"
     precision = os.environ.get("FUZZ_PREC", precision)
@@ -67,11 +69,18 @@ for case in range(n_cases):
         dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.67, g_inter=0.25, g_neg_loss=g_nl)
         # gradients: d loss / d cd jumps at the clamp bounds, so an element of cd within fp32 rounding of 0 / 0.8 may flip its mask
         # against the fp64 oracle and move the ~4 K gradient entries of one sample point: tolerate 0.3 % such entries
+        # (on a small problem ONE flipped element is already 1 % of the entries - 2 points x 4 taps x K channels: count the oracle's cd elements
+        # within fp32 rounding of a clamp bound and allow their taps; fuzz seed 7 case 28, tools/exp/fuzz_case28.py)
+        cmin, cmax = (0.0 if cfg.zero_clamp else -9999.0), (0.8 if cfg.stabalize else np.inf)
+        cds = [ref.pos_intra_cd, ref.pos_inter_cd] + ([ref.neg_inter_cd] if n_neg else [])
+        near = sum(int(((np.abs(c - cmin) < 1e-6) | (np.abs(c - cmax) < 1e-6)).sum()) for c in cds)
         for got, want, what in ((code.grad.cpu().numpy(), dc, "d_code"), (code_pos.grad.cpu().numpy(), dcp, "d_code_pos")):
             want = np.asarray(want, dtype=np.float64)
             tol = 1e-3 * np.abs(want).mean() + 1e-3 * np.abs(want)
-            frac = float((np.abs(got - want) > tol).mean())
-            assert frac <= 3e-3, "%s: %.4f %% of the entries off" % (what, 100 * frac)
+            badm = np.abs(got - want) > tol
+            frac = float(badm.mean())
+            pixels = int(badm.any(axis=1).sum())
+            assert frac <= 3e-3 or pixels <= 8 * near, "%s: %.4f %% of the entries off (%d pixels, %d cd elements at a clamp bound)" % (what, 100 * frac, pixels, near)
             assert np.abs(got - want).max() <= 0.2 * np.abs(want).max() + 1e-12, what
         desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46))
         tag["launches"] = capi.corr_fwd_launches(desc, M.as_channels_last(t["feats"]), M.as_channels_last(t["feats_pos"]),
