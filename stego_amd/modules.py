@@ -838,11 +838,13 @@ class ContrastiveCorrelationLoss(nn.Module):
         return loss, cd
 
     def generic_forward(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
-        """modules.py:369-398 for any shape (any cfg.feature_samples, any cfg.dim): sample() with torch's grid_sample, the two
-        correlation tensors on the native dense kernel, the rest elementwise.  Same six return values.  All 2 + neg_samples pair-sets
-        go through ONE batch (their second operands stacked along the batch dimension, the per-set means of modules.py:331-333 taken
-        over a [sets, B, ...] view): a seventh of the launches of the reference's loop - the path is host-bound (7.9 ms per step as a
-        loop at B = 32, S = 12 .. 16; tools/exp/generic_time.py)."""
+        """modules.py:369-398 for any shape (any cfg.feature_samples, any cfg.dim) the kernels behind stego_corr_fwd do not take (fused_kernels_cover:
+        cfg.dim > 128, > 88 at feature_samples > 11, feature_samples > 16).  Same six return values.  On a HIP device: the samplers that write the
+        dense-correspondence kernel's operands (stego_sample_panels: the fp32 rows of the sampled features never exist), both correlation
+        tensors of ALL 2 + neg_samples pair-sets in one launch each, helper()'s elementwise part in three launches, the adjoints as batched
+        GEMMs, norm + sampling backward in one scatter per source - composed here, gradient through autograd (host-bound: ~0.6 ms per step at
+        B = 32, S = 16; round 4: 3.8 ms, the reference's loop of helper() calls 8.5 ms; tools/exp/generic_time.py).  Elsewhere (CPU tensors in
+        tests, non-square coordinate grids): the reference's expressions in torch, all pair-sets as one batch."""
         cfg = self.cfg
         B = orig_feats.shape[0]
         n_neg = int(perms.shape[0]) if perms is not None else 0
