@@ -201,13 +201,14 @@ struct RowSampler {
     {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { ss += __shfl_xor(ss, m, 64); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
-        const float invn = pp.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;             // norm(), modules.py:276
+        const float invn = (pp.normalize & 1) ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;       // norm(), modules.py:276
         const float rs = mx * invn > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * invn)) : 1.f;
         const float inv = invn * rs;
         if (lane == 0) {
             sd.row_scale[((size_t)n * pp.nb + blk) * TP + rl] = 1.f / rs;
             if (sd.inv_out) sd.inv_out[gw] = invn;
         }
+        if (pp.normalize & 2) return;                 // (tools: no row stores - what the stores cost)
         const int CP = sd.NCH * KC;
         half_t* dst = sd.panels + ((size_t)n * pp.nb + blk) * sd.NCH * (2 * TP * LDH) + rl * LDH;
         float* rows = sd.rows_out ? sd.rows_out + (size_t)gw * sd.C : nullptr;
@@ -326,7 +327,7 @@ hipError_t launch_sample_panels2(const StegoMap* map, int C, void* panels, float
     pp.side[0] = panel_side(map, C, panels, row_scale, rows_out, inv_out);
     pp.side[1] = map2 ? panel_side(map2, C2, panels2, row_scale2, rows_out2, inv_out2) : pp.side[0];
     pp.nb = (pp.g.P + TP - 1) / TP;
-    pp.normalize = normalize ? 1 : 0;
+    pp.normalize = (normalize ? 1 : 0) | ((knob(KNOB_DEBUG_SAMPLE) & (1 << 16)) ? 2 : 0);
     const int v1 = panel_vw(map, C, rows_out), v2 = map2 ? panel_vw(map2, C2, rows_out2) : -1;
     const dim3 grid((unsigned)(((long long)N * pp.g.P + 3) / 4)), block(256);
 #define STEGO_SP_CASE(A, B) if (v1 == A && v2 == B) hipLaunchKernelGGL((sample_panels_kernel<A, B>), grid, block, 0, stream, pp)
