@@ -21,6 +21,7 @@ namespace stego {
 hipError_t launch_rowsum(const float* x, float* out, long long rows, int P, hipStream_t stream);          // loss_pointwise.hip
 
 constexpr int DC_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] fp16
+constexpr int DT_PKS = 68;                         // floats per row of a wave's parked 32 x 64 half quadrant (272 B: conflict-free 16-byte reads along a row)
 
 struct DenseParams {
     MapV a, b;                  // [B,C,H1,W1], [B,C,H2,W2]
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
     const unsigned char* A = static_cast<const unsigned char*>(prm.imgA) + ((size_t)na * prm.nbA + mi) * NCH * DC_SIDE;
     const unsigned char* Bm = static_cast<const unsigned char*>(prm.imgB) + ((size_t)n * prm.nbB + nj) * NCH * DC_SIDE;
     auto issue = [&](int c) {
-        unsigned char* dst = smem + (c & 1) * (2 * DC_SIDE);
+        unsigned char* dst = smem;
         for (int pc = wave; pc < DC_SIDE / 1024; pc += 4) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)c * DC_SIDE + (size_t)pc * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
@@ -144,13 +145,15 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    issue(0);
     constexpr int LO = TP * LDH;
     const int r = lane & 31, half = lane >> 5;
     for (int c = 0; c < NCH; ++c) {
-        sync_after_lds_dma();                             // chunk c landed; chunk c-1 is free
-        if (c + 1 < NCH) issue(c + 1);
-        const half_t* As = reinterpret_cast<const half_t*>(smem + (c & 1) * (2 * DC_SIDE));
+        // ONE stage per workgroup (73.7 KB) and two workgroups per CU that cover each other's copies - as the backbone's GEMM does; with two
+        // stages and one workgroup per CU a tile took 47 us for 7.7 us of MFMA time at C = 768 (round 5: 0.99 -> see profiles/r05i)
+        if (c > 0) __syncthreads();                       // everyone is done reading chunk c - 1
+        issue(c);
+        sync_after_lds_dma();                             // chunk c landed
+        const half_t* As = reinterpret_cast<const half_t*>(smem);
         const half_t* Bs = As + DC_SIDE / 2;
         const half_t* a0p = As + (64 * wr + r) * LDH + 8 * half;
         const half_t* a1p = a0p + 32 * LDH;
@@ -176,24 +179,46 @@ __global__ void __launch_bounds__(NTHREADS) dense_tile_kernel(const DenseParams 
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
         }
     }
-    // ---- store: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- store through LDS (the stage is free behind a barrier): a wave parks half of its 64 x 64 quadrant at a time and a lane then owns 4
+    // consecutive columns of a row - 16-byte stores, 256 contiguous bytes per quarter wave (4-byte stores in 128-byte pieces before)
     float* out = prm.out + (size_t)n * prm.M * prm.N;
     const float* ra = prm.rsA + ((size_t)na * prm.nbA + mi) * TP;      // undo the rows' staging scales
     const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
+    __syncthreads();
+    float* park = reinterpret_cast<float*>(smem) + wave * (32 * DT_PKS);
+    const int c4 = 4 * (lane & 15);
+    const bool v4 = (prm.N & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int cl = 64 * wc + 32 * j + (lane & 31);
-            const int col = nj * TP + cl;
-            const float sb = rb[cl];
+            const float sb = rb[64 * wc + 32 * j + (lane & 31)];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rw = 64 * wr + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int row = mi * TP + rw;
-                if (row < prm.M && col < prm.N) out[(size_t)row * prm.N + col] = acc[i][j][e] * (ra[rw] * sb);
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                park[rl * DT_PKS + 32 * j + (lane & 31)] = acc[i][j][e] * (ra[64 * wr + 32 * i + rl] * sb);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // (one wave: its LDS operations execute in order)
+        const int col = nj * TP + 64 * wc + c4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rl = 4 * k + (lane >> 4);
+            const int row = mi * TP + 64 * wr + 32 * i + rl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(park + rl * DT_PKS + c4);
+            if (row < prm.M) {
+                float* o = out + (size_t)row * prm.N + col;
+                if (v4 && col < prm.N) {
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < prm.N) o[q] = v[q];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the reads are done before the next half overwrites the slab
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- round 4: row-block kernel
@@ -382,8 +407,8 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
         }
         // ---- my 32 x 128 slab.  C/D layout: col = lane & 31 (+ 32 ni), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
         const float* rb = prm.rsB + ((size_t)n * prm.nbB + nj) * TP;
-        if constexpr (APANELS) {
-            // through LDS: a lane then owns 4 consecutive columns of a row - 16-byte stores, 256 contiguous bytes per quarter wave - instead of
+        {
+            // through LDS (round 5; the map variant too: the 78.7 MB correspondence tensor of a 28 x 28 pair batch left as 4-byte stores before): a lane then owns 4 consecutive columns of a row - 16-byte stores, 256 contiguous bytes per quarter wave - instead of
             // 4-byte stores in 128-byte pieces (59 MB left at 2.2 TB/s that way: tools/exp/r5_rowblock_abl.py), and the row sums of the loss's
             // pointwise shift (modules.py:332) are one 4-step reduction per row.  The slab is parked in the ring slot the block's last chunk was
             // read from (free until the next copy is issued, behind the next barrier), in two passes of 64 columns
@@ -429,19 +454,6 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next pass overwrites the slab
             }
-        } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int cl = 32 * ni + (lane & 31);
-            const int col = nj * TP + cl;
-            const float sb = rb[cl];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rw = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int row = mi * TP + rw;
-                if (row < prm.M && col < prm.N) __builtin_nontemporal_store(acc[ni][e] * (ra_s[rw] * sb), outn + (size_t)row * prm.N + col);
-            }
-        }
         }
         // (the stores and the rb loads above are vector-memory operations too: they complete in order IN FRONT of the copies issued
         // after them only if none of those is waited for by count - the copies of the next chunks were issued before them, so the
@@ -664,7 +676,7 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
         return hipGetLastError();
     }
     hipLaunchKernelGGL(dense_prep_kernel, dim3((unsigned)(B * (prm.nbA + prm.nbB))), dim3(NTHREADS), 0, stream, prm, vec);
-    const int lds = 4 * DC_SIDE;
+    const int lds = 2 * DC_SIDE;
     hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tile_kernel), lds);
     if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
@@ -716,7 +728,7 @@ hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int 
         return hipGetLastError();
     }
     if (seg > 0) return hipErrorInvalidValue;                 // (segmented outputs: the row-block kernel only - codes, K <= 384)
-    const int lds = 4 * DC_SIDE;
+    const int lds = 2 * DC_SIDE;
     hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tile_kernel), lds);
     if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(dense_tile_kernel, dim3(prm.nbB, prm.nbA, B), dim3(NTHREADS), lds, stream, prm);
