@@ -1688,3 +1688,17 @@ def test_wide_path_forward_is_repeatable_and_capturable():
         assert torch.equal(x, y)
     for x, y in zip(a[1:], got[1:]):
         assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())
+
+
+def test_wide_path_expanded_scalar_upstream():
+    """feature_samples 13 with `neg_inter_loss.sum()` as the caller's reduction: autograd hands the backward ONE expanded scalar for the whole
+    tensor (g_neg_loss_stride = 0 of the C ABI) - the third form of that upstream next to dense and "the mean's" (the other wide-path tests)."""
+    B, C, H, W, K, S, n_neg = 2, 64, 7, 9, 70, 13, 3
+    d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=313, dino_like=True)
+    cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
+    inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
+    r = _run(inputs, d["perms"], cfg, layout="cl", precision="f16x3", upstream=lambda out: 0.4 * out[0] + 3e-4 * out[4].sum())
+    g_nl = np.full((n_neg * B,) + (S,) * 4, 3e-4)
+    dc, dcp = O.corr_loss_backward(**inputs, perms=d["perms"], cfg=cfg, g_intra=0.4, g_inter=0.0, g_neg_loss=g_nl)
+    assert_close(r["d_code"], dc, rtol=2e-3, atol_frac=1e-3, what="d_code")
+    assert_close(r["d_code_pos"], dcp, rtol=2e-3, atol_frac=1e-3, what="d_code_pos")
