@@ -96,8 +96,8 @@ enum {
 /* Limits of this build: S*S <= 128 (S <= 11): K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
  * channels-last maps with C = 192 / 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
  * helper()); 128 < S*S <= 256 (S = 12 .. 16, ABI 7): K <= 88, any C and layout - the same entry points run the multi-launch kernels of
- * csrc/corr_wide.hip (stego_corr_fwd_launches says 8; split-fp16 products in both precision modes; the code gradients are accumulated with
- * fp32 atomics, so their last bits are not repeatable - everything below is about S <= 11); every per-image element offset < 2^31.
+ * csrc/corr_wide.hip (stego_corr_fwd_launches says 8; split-fp16 products in both precision modes; bitwise repeatable like S <= 11 unless a
+ * pixel of a map receives more than 64 sample taps or the map has more than 4096 pixels); every per-image element offset < 2^31.
  * Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
  * GEMMs are split-fp16 products in both precision modes (their fp32 operand images no longer fit LDS).
  * Determinism: every kernel sums in a fixed order (bitwise repeatable results), with ONE exception: the backward of maps

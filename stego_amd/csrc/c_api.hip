@@ -137,7 +137,7 @@ int hip_rc(hipError_t e) { return e == hipSuccess ? STEGO_OK : STEGO_ERR_HIP + (
 
 // feature_samples 12 .. 16: more points than one tile holds - the multi-launch path of corr_wide.hip behind the same entry points
 bool is_wide(const StegoCorrDesc* d) { return d->S * d->S > TP; }
-WideGeom wide_geom(const StegoCorrDesc* d) { return wide_geometry(d->B, d->C, d->K, d->S, d->n_neg); }
+WideGeom wide_geom(const StegoCorrDesc* d) { return wide_geometry(d->B, d->C, d->K, d->H, d->W, d->S, d->n_neg); }
 
 int wide_fwd(const StegoCorrDesc* d, const StegoMap* feats, const StegoMap* feats_pos, const StegoMap* code, const StegoMap* code_pos,
              const float* coords1, const float* coords2, const int64_t* perms, float* loss_means, float* pos_intra_cd, float* pos_inter_cd,

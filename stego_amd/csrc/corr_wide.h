@@ -11,7 +11,7 @@ struct WideGeom {
     size_t fimg, cimg;                                   // bytes of one operand image (features / codes)
     size_t o_fpan, o_frs, o_cpan, o_crs, o_rowsum, o_lrowsum, o_fd, o_mean, o_ctx, ws_bytes;        // forward workspace offsets
     size_t c_cn, c_inv, c_co1, c_co2, ctx_bytes;        // saved context offsets
-    size_t b_rows, b_anchor, b_tiles, bwd_ws_bytes;      // backward workspace offsets
+    size_t b_rows, b_anchor, b_tiles, b_v, b_ent, b_off, bwd_ws_bytes;      // backward workspace offsets
     int tile_bytes;                                      // one transposed code tile (hi | lo), a multiple of 1 KB
 };
 
@@ -39,7 +39,7 @@ struct WideBwdArgs {
 };
 
 bool wide_supported(int B, int C, int K, int S, int n_neg);
-WideGeom wide_geometry(int B, int C, int K, int S, int n_neg);
+WideGeom wide_geometry(int B, int C, int K, int H, int W, int S, int n_neg);
 hipError_t launch_wide_fwd(const WideFwdArgs& a, hipStream_t stream);
 hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream);
 
