@@ -24,9 +24,9 @@
 //                             the code correlation on the fp16 matrix cores (split-fp16 x 3 like the forward): d anchors(n) = G . rows(n),
 //                             d rows(n) = G^T . anchors - G is staged once per tile in LDS (its w values loaded one tile ahead) and read along rows
 //                             by four waves for the first product, along columns by four more for the second
-//   wide_lists_rows_kernel    the backward of norm() and of the bilinear sampling as a GATHER: per (gradient map, image) the (point, tap) pairs that land in
-//                             every pixel, as a counting sort in LDS (+, as a second role of the launch, the gradient of every un-normalised row)
-//   wide_gather_kernel        one wave per pixel sums its entries in key order: no atomics, nothing to zero, bitwise repeatable (maps beyond 4096
+//   wide_rows_kernel          the backward of norm() and of the bilinear sampling as a GATHER: the gradient of every un-normalised row ...
+//   wide_gather_kernel        ... and one wave per pixel that sums the entries of its list (built beside the code tiles: a counting sort of the (point, tap)
+//                             pairs per (gradient map, image) in LDS) in key order: no atomics, nothing to zero, bitwise repeatable (maps beyond 4096
 //                             pixels fall back to the one-wave-per-point scatter with fp32 atomics, stego_sample_bwd_rows)
 #include "corr_common.h"
 #include "host_util.h"
@@ -190,21 +190,132 @@ __device__ __forceinline__ void wide_dma_piece(const unsigned char* gsrc_lane, u
                  : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
 }
 
+struct WideGatherParams {
+    const float* d_rows;        // [n_img][P][K]
+    const float* d_anchor;      // [n_img][P][K]
+    const float* cn;            // [n_img][P][K]
+    const float* inv;           // [n_img][P]
+    const float* co1;           // [B][P][2]
+    const float* co2;
+    const long long* perms;     // [n_neg * B]
+    float* V;                   // [n_img][P][K]
+    int* off;                   // [2][B][HW + 1] absolute entry indices
+    unsigned* ent;              // pool of {key, weight bits}
+    float* d_map[2];            // d_code, d_code_pos: channels-last dense [B][H][W][K]
+    int B, P, S, K, H, W, n_sets, n_neg;
+};
+
+// the (point, tap) pairs that land in every pixel of image m of gradient map `which`, sorted by pixel: a counting sort in LDS by the calling workgroup
+// (T threads).  See "backward: norm() and the sampling, gathered" below.
+template <int T>
+__device__ __forceinline__ void wide_build_lists(const WideGatherParams& p, int which, int m, unsigned char* smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int P = p.P, HW = p.H * p.W;
+    constexpr int WG_THREADS = T;
+    int* cnt = reinterpret_cast<int*>(smem);            // [HW]
+    int* off = cnt + HW;                                // [HW + 1]
+    int* srcs = off + HW + 1;                           // [n_neg * B]
+    int* misc = srcs + p.n_neg * p.B;                   // [0] sources, [1] negatives of lower images, [2 ..] wave totals of the scan
+    for (int i = tid; i < HW; i += WG_THREADS) cnt[i] = 0;
+    if (tid < 2) misc[tid] = 0;
+    __syncthreads();
+    if (which == 0) {
+        for (int t = tid; t < p.n_neg * p.B; t += WG_THREADS) {
+            const long long pm = p.perms[t];
+            if (pm == (long long)m) srcs[atomicAdd(&misc[0], 1)] = t;
+            else if (pm < (long long)m) atomicAdd(&misc[1], 1);
+        }
+        __syncthreads();
+    }
+    const int n_src = which == 0 ? 1 + misc[0] : 1;
+    const int items = n_src * P;
+    const long long base = which == 0 ? 4ll * P * (m + misc[1]) : 4ll * P * ((long long)p.B * (1 + p.n_neg) + m);
+    auto taps_of = [&](int it, int& rowi, int4& yx, float4& tw) {
+        const int src = it / P, q = it - src * P;
+        int slot, crow;
+        const float* co;
+        if (which == 1) { slot = p.B + m; crow = m; co = p.co2; }
+        else if (src == 0) { slot = m; crow = m; co = p.co1; }
+        else { const int t = srcs[src - 1]; slot = 2 * p.B + t; crow = t % p.B; co = p.co2; }
+        const int hh = q / p.S, ww = q - hh * p.S;                      // point (h, w) reads coords[w][h] (the permute of modules.py:288)
+        const float* c = co + ((size_t)crow * P + (size_t)ww * p.S + hh) * 2;
+        make_taps(c[0], c[1], p.H, p.W, yx, tw);
+        rowi = slot * P + q;
+    };
+    // counts per pixel (taps of weight zero - beyond the border - are not entries)
+    for (int it = tid; it < items; it += WG_THREADS) {
+        int rowi;
+        int4 yx;
+        float4 tw;
+        taps_of(it, rowi, yx, tw);
+        const int px[4] = {yx.x, yx.y, yx.z, yx.w};
+        const float wt[4] = {tw.x, tw.y, tw.z, tw.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (wt[t] != 0.f) atomicAdd(&cnt[(px[t] >> 16) * p.W + (px[t] & 0xffff)], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the pixels: E consecutive pixels per thread, wave scan, wave totals
+    const int E = (HW + WG_THREADS - 1) / WG_THREADS;
+    int loc = 0;
+    for (int e = 0; e < E; ++e) { const int i = tid * E + e; if (i < HW) loc += cnt[i]; }
+    int inc = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+    if (lane == 63) misc[2 + (tid >> 6)] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w2 = 0; w2 < (tid >> 6); ++w2) wbase += misc[2 + w2];
+    int run = wbase + inc - loc;
+    for (int e = 0; e < E; ++e) { const int i = tid * E + e; if (i < HW) { off[i] = run; run += cnt[i]; } }
+    if (tid == WG_THREADS - 1) off[HW] = run;
+    __syncthreads();
+    int* goff = p.off + (size_t)(which * p.B + m) * (HW + 1);
+    for (int i = tid; i <= HW; i += WG_THREADS) goff[i] = (int)base + off[i];
+    for (int i = tid; i < HW; i += WG_THREADS) cnt[i] = 0;
+    __syncthreads();
+    // fill
+    for (int it = tid; it < items; it += WG_THREADS) {
+        int rowi;
+        int4 yx;
+        float4 tw;
+        taps_of(it, rowi, yx, tw);
+        const int px[4] = {yx.x, yx.y, yx.z, yx.w};
+        const float wt[4] = {tw.x, tw.y, tw.z, tw.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (wt[t] != 0.f) {
+                const int pix = (px[t] >> 16) * p.W + (px[t] & 0xffff);
+                const long long pos = base + off[pix] + atomicAdd(&cnt[pix], 1);
+                p.ent[2 * pos] = (unsigned)(rowi * 4 + t);
+                p.ent[2 * pos + 1] = __builtin_bit_cast(unsigned, wt[t]);
+            }
+        }
+    }
+}
+
 // The operands of the backward's GEMMs that come from the codes, once per backward: tile (image, 128-point block) = the block's normalised rows
 // TRANSPOSED ([channel][point]: a fragment of either product is then 8 consecutive points of one channel = one 16-byte LDS read) and split
 // into fp16 hi | lo, in the layout the GEMM kernel keeps in LDS - staging a tile there is a linear LDS-DMA copy.
 constexpr int WB_ZERO_CHUNK = 16384;      // floats per zeroing workgroup
-__global__ void __launch_bounds__(512) wide_code_tiles_kernel(const WideBwdParams p)
+__global__ void __launch_bounds__(512) wide_code_tiles_kernel(const WideBwdParams p, const WideGatherParams q, const int list_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int nbp = (p.P + TP - 1) / TP;
     const int n_tiles = p.n_sets * p.B * nbp;
+    if ((int)blockIdx.x >= n_tiles && (int)blockIdx.x < n_tiles + list_blocks) {
+        // the lists of the pixel gather (they depend on the coordinates and permutations only: built here, beside the tiles, in front of the GEMMs)
+        const int lb = blockIdx.x - n_tiles;
+        wide_build_lists<512>(q, lb / q.B, lb % q.B, smem);
+        return;
+    }
     if ((int)blockIdx.x >= n_tiles) {
-        // the scatter launches ADD into the code gradients: zero them here
+        // (maps beyond 4096 pixels) the scatter launches ADD into the code gradients: zero them here
         const long long per = (p.zero_floats + WB_ZERO_CHUNK - 1) / WB_ZERO_CHUNK;
-        const long long c = (long long)blockIdx.x - n_tiles;
+        const long long c = (long long)blockIdx.x - n_tiles - list_blocks;
         const int which = (int)(c / per);
         const long long beg = (c - which * per) * WB_ZERO_CHUNK, end = min(beg + (long long)WB_ZERO_CHUNK, p.zero_floats);
         float* z = p.zero[which];
@@ -453,152 +564,50 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
 // ------------------------------------------------------------------------------------------------ backward: norm() and the sampling, gathered
 // The adjoint of norm() (F.normalize, modules.py:275-276) and of the bilinear sampling (:287-288, incl. the orig_code[perm] gather of :385) as a
 // GATHER per destination pixel - no atomics, nothing to zero, a fixed summation order:
-//   wide_lists_rows_kernel   two roles in one launch.  (a) one workgroup per (gradient map, image): the (point, tap) pairs that land in every pixel
+//   wide_build_lists         (workgroups of the code-tile launch) one workgroup per (gradient map, image): the (point, tap) pairs that land in every pixel
 //                            of the image - its own anchors and the negative sets that drew it (a scan of the permutations) for orig_code, the
 //                            positive set for orig_code_pos - as a counting sort by pixel in LDS: counts, prefix, fill; entry = {4 (row) + tap,
-//                            weight}; the image's slice of the pool starts at 4 P (m + #{negatives of lower images}): no allocation.  (b) one
-//                            wave per sampled row: V = the gradient of the UN-normalised row (norm backward applied, the anchors' first-operand
-//                            gradients of all pair-sets summed in)
+//                            weight}; the image's slice of the pool starts at 4 P (m + #{negatives of lower images}): no allocation
+//   wide_rows_kernel         one wave per sampled row: V = the gradient of the UN-normalised row (norm backward applied, the anchors'
+//                            first-operand gradients of all pair-sets summed in)
 //   wide_gather_kernel       one wave per pixel: its <= 64 entries sorted by key (so that the sum has one order whatever order the fill took),
 //                            then out[pixel][:] = sum w * V[row][:], K floats per entry in one or two coalesced loads.  A pixel with more than 64
 //                            taps is summed chunk by chunk (order of the chunks as filled)
 // Against the one-wave-per-point scatter with global fp32 atomics (88 us for three launches at S = 16, 52 us of them the atomics).
-constexpr int WG_THREADS = 1024;
-struct WideGatherParams {
-    const float* d_rows;        // [n_img][P][K]
-    const float* d_anchor;      // [n_img][P][K]
-    const float* cn;            // [n_img][P][K]
-    const float* inv;           // [n_img][P]
-    const float* co1;           // [B][P][2]
-    const float* co2;
-    const long long* perms;     // [n_neg * B]
-    float* V;                   // [n_img][P][K]
-    int* off;                   // [2][B][HW + 1] absolute entry indices
-    unsigned* ent;              // pool of {key, weight bits}
-    float* d_map[2];            // d_code, d_code_pos: channels-last dense [B][H][W][K]
-    int B, P, S, K, H, W, n_sets, n_neg;
-};
-
-__global__ void __launch_bounds__(WG_THREADS) wide_lists_rows_kernel(const WideGatherParams p)
+__global__ void __launch_bounds__(256) wide_rows_kernel(const WideGatherParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // V rows, one wave per (image slot, point): the gradient of the UN-normalised sampled row
     const int tid = threadIdx.x, lane = tid & 63;
-    const int P = p.P, K = p.K, HW = p.H * p.W;
-    if ((int)blockIdx.x >= 2 * p.B) {
-        // ---- role (b): V rows, one wave per (image slot, point)
-        const long long row = (long long)(blockIdx.x - 2 * p.B) * (WG_THREADS / 64) + (tid >> 6);
-        if (row >= (long long)p.n_sets * p.B * P) return;
-        const size_t o = (size_t)row * K;
-        const bool anchor = row < (long long)p.B * P;
-        const size_t set_stride = (size_t)p.B * P * K;
-        float g[2], y[2];
+    const int P = p.P, K = p.K;
+    const long long row = (long long)blockIdx.x * 4 + (tid >> 6);
+    if (row >= (long long)p.n_sets * p.B * P) return;
+    const size_t o = (size_t)row * K;
+    const bool anchor = row < (long long)p.B * P;
+    const size_t set_stride = (size_t)p.B * P * K;
+    float g[2], y[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = lane + 64 * e;
-            g[e] = 0.f;
-            y[e] = 0.f;
-            if (c < K) {
-                float gg = p.d_rows[o + c];
-                if (anchor)
-                    for (int s2 = 0; s2 < p.n_sets; ++s2) gg += p.d_anchor[(size_t)s2 * set_stride + o + c];
-                g[e] = gg;
-                y[e] = p.cn[o + c];
-            }
+    for (int e = 0; e < 2; ++e) {
+        const int c = lane + 64 * e;
+        g[e] = 0.f;
+        y[e] = 0.f;
+        if (c < K) {
+            float gg = p.d_rows[o + c];
+            if (anchor)
+                for (int s2 = 0; s2 < p.n_sets; ++s2) gg += p.d_anchor[(size_t)s2 * set_stride + o + c];
+            g[e] = gg;
+            y[e] = p.cn[o + c];
         }
-        // norm() backward: y = x / max(|x|, eps) -> dx = (g - y <y, g>) / |x|, or g / eps below eps
-        float proj = __builtin_fmaf(y[0], g[0], y[1] * g[1]);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) proj += __shfl_xor(proj, m, 64);
-        const float iv = p.inv[row];
-        if (iv > 0.99e10f) proj = 0.f;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = lane + 64 * e;
-            if (c < K) p.V[o + c] = iv * (g[e] - y[e] * proj);
-        }
-        return;
     }
-    // ---- role (a): the lists of one (map, image)
-    int* cnt = reinterpret_cast<int*>(smem);            // [HW]
-    int* off = cnt + HW;                                // [HW + 1]
-    int* srcs = off + HW + 1;                           // [n_neg * B]
-    int* misc = srcs + p.n_neg * p.B;                   // [0] sources, [1] negatives of lower images, [2 ..] wave totals of the scan
-    const int which = blockIdx.x / p.B, m = blockIdx.x - which * p.B;
-    for (int i = tid; i < HW; i += WG_THREADS) cnt[i] = 0;
-    if (tid < 2) misc[tid] = 0;
-    __syncthreads();
-    if (which == 0) {
-        for (int t = tid; t < p.n_neg * p.B; t += WG_THREADS) {
-            const long long pm = p.perms[t];
-            if (pm == (long long)m) srcs[atomicAdd(&misc[0], 1)] = t;
-            else if (pm < (long long)m) atomicAdd(&misc[1], 1);
-        }
-        __syncthreads();
-    }
-    const int n_src = which == 0 ? 1 + misc[0] : 1;
-    const int items = n_src * P;
-    const long long base = which == 0 ? 4ll * P * (m + misc[1]) : 4ll * P * ((long long)p.B * (1 + p.n_neg) + m);
-    auto taps_of = [&](int it, int& rowi, int4& yx, float4& tw) {
-        const int src = it / P, q = it - src * P;
-        int slot, crow;
-        const float* co;
-        if (which == 1) { slot = p.B + m; crow = m; co = p.co2; }
-        else if (src == 0) { slot = m; crow = m; co = p.co1; }
-        else { const int t = srcs[src - 1]; slot = 2 * p.B + t; crow = t % p.B; co = p.co2; }
-        const int hh = q / p.S, ww = q - hh * p.S;                      // point (h, w) reads coords[w][h] (the permute of modules.py:288)
-        const float* c = co + ((size_t)crow * P + (size_t)ww * p.S + hh) * 2;
-        make_taps(c[0], c[1], p.H, p.W, yx, tw);
-        rowi = slot * P + q;
-    };
-    // counts per pixel (taps of weight zero - beyond the border - are not entries)
-    for (int it = tid; it < items; it += WG_THREADS) {
-        int rowi;
-        int4 yx;
-        float4 tw;
-        taps_of(it, rowi, yx, tw);
-        const int px[4] = {yx.x, yx.y, yx.z, yx.w};
-        const float wt[4] = {tw.x, tw.y, tw.z, tw.w};
+    // norm() backward: y = x / max(|x|, eps) -> dx = (g - y <y, g>) / |x|, or g / eps below eps
+    float proj = __builtin_fmaf(y[0], g[0], y[1] * g[1]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (wt[t] != 0.f) atomicAdd(&cnt[(px[t] >> 16) * p.W + (px[t] & 0xffff)], 1);
-    }
-    __syncthreads();
-    // exclusive prefix over the pixels: E consecutive pixels per thread, wave scan, wave totals
-    const int E = (HW + WG_THREADS - 1) / WG_THREADS;
-    int loc = 0;
-    for (int e = 0; e < E; ++e) { const int i = tid * E + e; if (i < HW) loc += cnt[i]; }
-    int inc = loc;
+    for (int m = 32; m >= 1; m >>= 1) proj += __shfl_xor(proj, m, 64);
+    const float iv = p.inv[row];
+    if (iv > 0.99e10f) proj = 0.f;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
-    if (lane == 63) misc[2 + (tid >> 6)] = inc;
-    __syncthreads();
-    int wbase = 0;
-    for (int w2 = 0; w2 < (tid >> 6); ++w2) wbase += misc[2 + w2];
-    int run = wbase + inc - loc;
-    for (int e = 0; e < E; ++e) { const int i = tid * E + e; if (i < HW) { off[i] = run; run += cnt[i]; } }
-    if (tid == WG_THREADS - 1) off[HW] = run;
-    __syncthreads();
-    int* goff = p.off + (size_t)(which * p.B + m) * (HW + 1);
-    for (int i = tid; i <= HW; i += WG_THREADS) goff[i] = (int)base + off[i];
-    for (int i = tid; i < HW; i += WG_THREADS) cnt[i] = 0;
-    __syncthreads();
-    // fill
-    for (int it = tid; it < items; it += WG_THREADS) {
-        int rowi;
-        int4 yx;
-        float4 tw;
-        taps_of(it, rowi, yx, tw);
-        const int px[4] = {yx.x, yx.y, yx.z, yx.w};
-        const float wt[4] = {tw.x, tw.y, tw.z, tw.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (wt[t] != 0.f) {
-                const int pix = (px[t] >> 16) * p.W + (px[t] & 0xffff);
-                const long long pos = base + off[pix] + atomicAdd(&cnt[pix], 1);
-                p.ent[2 * pos] = (unsigned)(rowi * 4 + t);
-                p.ent[2 * pos + 1] = __builtin_bit_cast(unsigned, wt[t]);
-            }
-        }
+    for (int e = 0; e < 2; ++e) {
+        const int c = lane + 64 * e;
+        if (c < K) p.V[o + c] = iv * (g[e] - y[e] * proj);
     }
 }
 
@@ -767,31 +776,31 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     p.tiles_out = ws + g.b_tiles;
     p.tiles = p.tiles_out;
     p.tile_bytes = g.tile_bytes;
-    if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_code_tiles_kernel), g.tile_bytes)) != hipSuccess) return e;
-    const bool gather = a.H * a.W <= 4096 && !(knob(KNOB_DEBUG_BWD) & (1 << 20));
+    const int HW = a.H * a.W;
+    const bool gather = HW <= 4096 && !(knob(KNOB_DEBUG_BWD) & (1 << 20));             // (debug bit 20: the scatter with global atomics)
+    WideGatherParams q{};
+    q.d_rows = p.d_rows; q.d_anchor = p.d_anchor; q.cn = cn; q.inv = inv; q.co1 = co1; q.co2 = co2; q.perms = a.perms;
+    q.V = reinterpret_cast<float*>(ws + g.b_v);
+    q.off = reinterpret_cast<int*>(ws + g.b_off);
+    q.ent = reinterpret_cast<unsigned*>(ws + g.b_ent);
+    q.d_map[0] = a.d_code; q.d_map[1] = a.d_code_pos;
+    q.B = B; q.P = P; q.S = a.S; q.K = K; q.H = a.H; q.W = a.W; q.n_sets = g.n_sets; q.n_neg = a.n_neg;
+    const int list_blocks = gather ? 2 * B : 0;
+    const int lds_lists = (2 * HW + 1 + nnb + 2 + 512 / 64 + 4) * 4;
+    const int lds_tiles = gather && lds_lists > g.tile_bytes ? lds_lists : g.tile_bytes;
+    if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_code_tiles_kernel), lds_tiles)) != hipSuccess) return e;
     p.zero[0] = a.d_code; p.zero[1] = a.d_code_pos;
     p.zero_floats = gather ? 0 : (long long)B * a.H * a.W * K;      // (the gather writes every pixel)
     const int zero_blocks = 2 * (int)((p.zero_floats + WB_ZERO_CHUNK - 1) / WB_ZERO_CHUNK);
-    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb + zero_blocks), dim3(512), g.tile_bytes, stream, p);
+    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb + list_blocks + zero_blocks), dim3(512), lds_tiles, stream, p, q, list_blocks);
     const int lds = 128 * WB_GS * 4 + 2 * g.tile_bytes;
     if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_bwd_kernel), lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(WB_THREADS), lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // the backward of norm() and of the sampling
-    const int HW = a.H * a.W;
-    if (HW <= 4096 && !(knob(KNOB_DEBUG_BWD) & (1 << 20))) {             // (debug bit 20: the scatter with global atomics)
-        WideGatherParams q{};
-        q.d_rows = p.d_rows; q.d_anchor = p.d_anchor; q.cn = cn; q.inv = inv; q.co1 = co1; q.co2 = co2; q.perms = a.perms;
-        q.V = reinterpret_cast<float*>(ws + g.b_v);
-        q.off = reinterpret_cast<int*>(ws + g.b_off);
-        q.ent = reinterpret_cast<unsigned*>(ws + g.b_ent);
-        q.d_map[0] = a.d_code; q.d_map[1] = a.d_code_pos;
-        q.B = B; q.P = P; q.S = a.S; q.K = K; q.H = a.H; q.W = a.W; q.n_sets = g.n_sets; q.n_neg = a.n_neg;
-        const int lds2 = (2 * HW + 1 + nnb + 2 + WG_THREADS / 64 + 4) * 4;
-        if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_lists_rows_kernel), lds2)) != hipSuccess) return e;
+    if (gather) {
         const long long rows_total = (long long)g.n_img * P;
-        const unsigned row_blocks = (unsigned)((rows_total + WG_THREADS / 64 - 1) / (WG_THREADS / 64));
-        hipLaunchKernelGGL(wide_lists_rows_kernel, dim3(2 * B + row_blocks), dim3(WG_THREADS), lds2, stream, q);
+        hipLaunchKernelGGL(wide_rows_kernel, dim3((unsigned)((rows_total + 3) / 4)), dim3(256), 0, stream, q);
         hipLaunchKernelGGL(wide_gather_kernel, dim3((unsigned)((2ll * B * HW + 3) / 4)), dim3(256), 0, stream, q);
         return hipGetLastError();
     }

@@ -138,7 +138,7 @@ def test_wide_path_kernels_spill_nothing(tmp_path):
             m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
             if m and name:
                 kernels[name][m.group(1)] = int(m.group(2))
-    want = ["wide_bwd_kernel", "wide_code_tiles_kernel", "wide_pointwise_kernel", "wide_lists_rows_kernel", "wide_gather_kernel", "dense_rowpair_kernel",
+    want = ["wide_bwd_kernel", "wide_code_tiles_kernel", "wide_pointwise_kernel", "wide_rows_kernel", "wide_gather_kernel", "dense_rowpair_kernel",
             "dense_rowblock_kernelILb1ELi2", "sample_panels_kernel", "sample_scatter_kernel"]
     for w in want:
         hits = {k: v for k, v in kernels.items() if w in k}
