@@ -362,8 +362,12 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
 #pragma unroll
         for (int c = 0; c < DR_MAXCH; ++c) {
             if (c < NCH) {
-                if (NST == 3 && nstage - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                {   // my pieces of stage g have landed: at most min(NST - 2, stages left) later stages (9 pieces per wave each) may still fly
+                    const int ahead = NST >= 3 ? min(nstage - 1 - g, NST - 2) : 0;
+                    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -714,11 +718,11 @@ hipError_t launch_dense_corr_panels_seg(const void* imgA, const float* rsA, int 
             return hipGetLastError();
         }
         const dim3 grid((unsigned)(((B + 7) / 8) * 8 * prm.nbA));
-        if (knob(KNOB_DEBUG) & (1 << 19)) {                     // (tools: three ring stages, one workgroup per CU)
-            const int lds3 = 3 * DC_SIDE + 512;
-            hipError_t e3 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel<true, 3>), lds3);
+        if (knob(KNOB_DEBUG) & (1 << 19)) {                     // (tools: four ring stages - three copies in flight -, one workgroup per CU)
+            const int lds3 = 4 * DC_SIDE + 512;
+            hipError_t e3 = ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_rowblock_kernel<true, 4>), lds3);
             if (e3 != hipSuccess) return e3;
-            hipLaunchKernelGGL((dense_rowblock_kernel<true, 3>), grid, dim3(NTHREADS), lds3, stream, prm);
+            hipLaunchKernelGGL((dense_rowblock_kernel<true, 4>), grid, dim3(NTHREADS), lds3, stream, prm);
             return hipGetLastError();
         }
         const int lds2 = 2 * DC_SIDE + 512;

@@ -17,7 +17,7 @@ for C in (384, 70):
     capi.sample_panels(ps, B, t, coords)
     capi.sample_panels(ps, 2 * B, t, coords, idx)
     for dbg, name in ((0, "full"), (1, "no A loads"), (2, "no stores"), (4, "no MFMA"), (6, "no stores, no MFMA"), (7, "nothing but the B stream"),
-                      (8, "three stages, one workgroup per CU"), (8 + 7, "three stages: nothing but the B stream")):
+                      (8, "four stages (three copies in flight), one workgroup per CU"), (8 + 7, "four stages: nothing but the B stream")):
         capi.debug_set("STEGO_DEBUG", dbg << 16)
         for _ in range(3):
             capi.dense_corr_panels(ps, B, ps, n_sets * B, want_rowsum=True)
