@@ -12,14 +12,14 @@
 //                             fp32 rows and 1 / |row| also go to the saved context (the backward needs them).  Both maps in one launch: the same
 //                             points, the code map's taps ride in the feature row's round trip
 //   dense_rowblock_kernel     fd[n] = anchors(n % B) . image(n)^T for all pair-sets in one launch, row sums on the way     -> saved_w (raw fd)
-//   dense_rowblock_kernel     cd[n], written straight into the three cd outputs
+//   dense_rowpair_kernel      cd[n] (both row blocks of a pair in one workgroup: every B chunk streamed once), written straight into the three cd outputs
 //   wide_set_mean_kernel      old_mean of every pair-set (modules.py:331) from the row sums -> saved_mean; the coordinates -> saved context
 //   wide_pointwise_kernel     helper()'s elementwise part (:330-345) in place: loss (negative sets), the row sums of the loss of every set, and
 //                             w = fd - rowmean + old_mean - shift with the clamp's pass mask in its mantissa LSB             -> saved_w
 //   wide_loss_means_kernel    the three means the caller gets (:393-398)
 // Backward (4 launches):
 //   wide_code_tiles_kernel    the codes' side of the backward's GEMMs: per (image, 128-point block) the normalised rows transposed and split into
-//                             fp16 hi | lo, in the layout the GEMM kernel keeps in LDS
+//                             fp16 hi | lo, in the layout the GEMM kernel keeps in LDS; 2 B more workgroups build the gather's lists (wide_build_lists)
 //   wide_bwd_kernel           one workgroup per pair (set, image) walks its <= 2 x 2 tiles of G = -w * mask * upstream and takes both adjoints of
 //                             the code correlation on the fp16 matrix cores (split-fp16 x 3 like the forward): d anchors(n) = G . rows(n),
 //                             d rows(n) = G^T . anchors - G is staged once per tile in LDS (its w values loaded one tile ahead) and read along rows
