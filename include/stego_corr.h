@@ -95,7 +95,7 @@ enum {
 
 /* Limits of this build: S*S <= 128 (S <= 11): K (cfg.dim; the reference ships 70) <= 128 on the fused path (any parity,
  * channels-last maps with C = 192 / 384 / 768, i.e. what DinoFeaturizer emits) and <= 72 elsewhere (other layouts / widths,
- * helper()); 128 < S*S <= 256 (S = 12 .. 16, ABI 7): K <= 88, any C and layout - the same entry points run the multi-launch kernels of
+ * helper()); 128 < S*S <= 256 (S = 12 .. 16, ABI 7): K <= 128, any C and layout - the same entry points run the multi-launch kernels of
  * csrc/corr_wide.hip (stego_corr_fwd_launches says 8; split-fp16 products in both precision modes; bitwise repeatable like S <= 11 unless a
  * pixel of a map receives more than 64 sample taps or the map has more than 4096 pixels); every per-image element offset < 2^31.
  * Anything else returns STEGO_ERR_UNSUPPORTED.  For K > 80 the backward's
@@ -345,7 +345,7 @@ int stego_dense_corr(const StegoMap* a, const StegoMap* b, int32_t B, int32_t C,
  *   NULL: map[n]) at coords[n % n_coords][w][h][:] ([..., 0] = x, [..., 1] = y in [-1, 1]).
  * stego_sample_bwd adds the adjoint into d_map (same shape and strides as the forward's map; the caller zeroes it): fp32 atomic adds,
  * so the summation order is not fixed.  Any strides; 16-byte loads when the map is channels-last.  Used by the loss for shapes the fused
- * kernels do not take (dim > 128, dim > 88 at feature_samples > 11: stego_amd.modules.ContrastiveCorrelationLoss.generic_forward). */
+ * kernels do not take (dim > 128: stego_amd.modules.ContrastiveCorrelationLoss.generic_forward). */
 int stego_sample(const StegoMap* map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W, const float* coords,
                  int32_t n_coords, int32_t S, float* out, stego_stream_t stream);
 int stego_sample_bwd(const float* g_out, const StegoMap* d_map, const int64_t* index, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -349,7 +349,7 @@ const char* stego_error_string(int code)
         case STEGO_OK: return "ok";
         case STEGO_ERR_NULL: return "required pointer is NULL";
         case STEGO_ERR_SHAPE: return "bad or inconsistent dimension";
-        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S<=16 (S*S>128: K<=88), K<=128 (K>72: channels-last maps with C = 192 / 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
+        case STEGO_ERR_UNSUPPORTED: return "unsupported configuration (limits: S<=16, K<=128 (K>72: channels-last maps with C = 192 / 384 / 768, B <= compute units), n_neg<=254, fp32 maps, <2^31 elements per image, no unknown flags)";
         case STEGO_ERR_WORKSPACE: return "workspace too small";
         case STEGO_ERR_ALIGN: return "pointer not 4-byte aligned";
         default: return code >= STEGO_ERR_HIP ? "HIP runtime error (code - 1000 = hipError_t)" : "unknown error";

@@ -7,7 +7,7 @@
 namespace stego {
 
 struct WideGeom {
-    int n_sets, n_img, P, nb, Kr;
+    int n_sets, n_img, P, nb, Kr, Kc, nwin;
     size_t fimg, cimg;                                   // bytes of one operand image (features / codes)
     size_t o_fpan, o_frs, o_cpan, o_crs, o_rowsum, o_lrowsum, o_fd, o_mean, o_ctx, ws_bytes;        // forward workspace offsets
     size_t c_cn, c_inv, c_co1, c_co2, ctx_bytes;        // saved context offsets

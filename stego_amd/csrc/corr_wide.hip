@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(1024) wide_loss_means_kernel(const WidePwParam
 constexpr int WB_GS = 132;      // floats per row of the G tile (528 B: conflict-free 16-byte reads along a row, column walks hit 64 banks)
 constexpr int WB_TS = 136;      // halves per row of a transposed code tile [channel][128 points] (272 B: conflict-free 16-byte reads)
 constexpr int WB_MAXNB = 2;     // point blocks per side: S * S <= 256
-constexpr int WB_MAXKB = 3;     // 32-channel blocks: K <= 88 (the tiles of both sides + G in 160 KB of LDS)
+constexpr int WB_MAXKB = 3;     // 32-channel blocks of one pass: <= 88 channels (the tiles of both sides + G in 160 KB of LDS); K <= 128 in two passes
 
 struct WideBwdParams {
     const float* w;             // saved_w [n_img][P][P]
@@ -169,6 +169,7 @@ struct WideBwdParams {
     float* d_anchor;            // [n_img][P][K] gradient of the anchors (image n % B) from pair n
     int g_neg_stride;           // 1 dense [n_neg B][P][P], 0 one scalar per element, -1 one scalar = the upstream of loss_means[2]
     int B, P, K, Kr, n_sets;
+    int k0, Kc;                 // the channel window [k0, k0 + Kc) of this pass (Kc <= 88: both code tiles + G in 160 KB of LDS; K > 88 takes two passes); Kr = Kc rounded up to 8
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, f16x8& hi, f16x8& lo)
@@ -326,24 +327,25 @@ __global__ void __launch_bounds__(512) wide_code_tiles_kernel(const WideBwdParam
         return;
     }
     const int img = blockIdx.x / nbp, blk = blockIdx.x - img * nbp;
-    const int P = p.P, K = p.K, Kr = p.Kr, p0 = blk * TP;
+    const int P = p.P, K = p.K, Kc = p.Kc, Kr = p.Kr, p0 = blk * TP;
     half_t* T = reinterpret_cast<half_t*>(smem);
     for (int i = tid; i < p.tile_bytes / 16; i += 512) reinterpret_cast<du32x4*>(smem)[i] = du32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    const float* src = p.cn + ((size_t)img * P + p0) * K;
+    const float* src = p.cn + ((size_t)img * P + p0) * K + p.k0;       // channels [k0, k0 + Kc) of the block's rows
     const int rows = min(TP, P - p0);
     constexpr int UN = 22;                                              // 128 x 88 / 512: every load of a thread in flight at once
     float v[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int idx = u * 512 + tid;
-        v[u] = idx < rows * K ? src[idx] : 0.f;                         // (the rows of a block are contiguous: [point][K])
+        const int jl = idx / Kc, k = idx - jl * Kc;
+        v[u] = idx < rows * Kc ? src[(size_t)jl * K + k] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int idx = u * 512 + tid;
-        if (idx < rows * K) {
-            const int jl = idx / K, k = idx - jl * K;
+        if (idx < rows * Kc) {
+            const int jl = idx / Kc, k = idx - jl * Kc;
             unsigned hh, ll;
             split_f16_pair(v[u] * WB_CSCALE, 0.f, hh, ll);
             reinterpret_cast<unsigned short*>(T)[k * WB_TS + jl] = (unsigned short)(hh & 0xffffu);
@@ -524,11 +526,11 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
         }
         if (role == 0) {
             // the anchors' rows of block mi are complete.  C/D layout: column (channel) = lane & 31 (+ 32 kb), row = (e & 3) + 8 (e >> 2) + 4 h
-            float* da = p.d_anchor + (size_t)n * P * K;
+            float* da = p.d_anchor + (size_t)n * P * K + p.k0;
 #pragma unroll
             for (int kb = 0; kb < WB_MAXKB; ++kb) {
                 const int k = 32 * kb + r;
-                if (kb < NK && k < K) {
+                if (kb < NK && k < p.Kc) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int i = mi * TP + 32 * wq + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -541,14 +543,14 @@ __global__ void __launch_bounds__(WB_THREADS) wide_bwd_kernel(const WideBwdParam
         }
     }
     if (role == 1) {
-        float* dr = p.d_rows + (size_t)n * P * K;
+        float* dr = p.d_rows + (size_t)n * P * K + p.k0;
 #pragma unroll
         for (int nj = 0; nj < WB_MAXNB; ++nj) {
             if (nj < nbp) {
 #pragma unroll
                 for (int kb = 0; kb < WB_MAXKB; ++kb) {
                     const int k = 32 * kb + r;
-                    if (kb < NK && k < K) {
+                    if (kb < NK && k < p.Kc) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const int j = nj * TP + 32 * wq + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(256) wide_gather_kernel(const WideGatherParams
 bool wide_supported(int B, int C, int K, int S, int n_neg)
 {
     const int P = S * S;
-    return P > TP && P <= WB_MAXNB * TP && K <= 32 * WB_MAXKB - 8 && B >= 1 && C >= 1 && n_neg >= 0 &&
+    return P > TP && P <= WB_MAXNB * TP && K <= 128 && B >= 1 && C >= 1 && n_neg >= 0 &&
            (long long)(2 + n_neg) * B <= 65535 && (long long)(2 + n_neg) * B * P < (1ll << 31) / 4;
 }
 
@@ -676,7 +678,10 @@ WideGeom wide_geometry(int B, int C, int K, int H, int W, int S, int n_neg)
     g.n_img = g.n_sets * B;
     g.P = S * S;
     g.nb = (g.P + TP - 1) / TP;
-    g.Kr = (K + 7) & ~7;
+    // the backward's GEMM kernel takes the code channels in windows of <= 88 (its LDS): one pass up to K = 88, two beyond
+    g.nwin = (K + 87) / 88;
+    g.Kc = (((K + g.nwin - 1) / g.nwin) + 7) & ~7;
+    g.Kr = g.Kc;
     g.fimg = dense_panel_image_bytes(C, g.P);
     g.cimg = dense_panel_image_bytes(K, g.P);
     const size_t rows = (size_t)g.n_img * g.P;
@@ -792,10 +797,17 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     p.zero[0] = a.d_code; p.zero[1] = a.d_code_pos;
     p.zero_floats = gather ? 0 : (long long)B * a.H * a.W * K;      // (the gather writes every pixel)
     const int zero_blocks = 2 * (int)((p.zero_floats + WB_ZERO_CHUNK - 1) / WB_ZERO_CHUNK);
-    hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb + list_blocks + zero_blocks), dim3(512), lds_tiles, stream, p, q, list_blocks);
     const int lds = 128 * WB_GS * 4 + 2 * g.tile_bytes;
     if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wide_bwd_kernel), lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(WB_THREADS), lds, stream, p);
+    for (int win = 0; win < g.nwin; ++win) {
+        // one pass per window of code channels (K <= 88: one): its tiles, then both GEMMs into the window's columns of the row gradients.  The
+        // lists / the zeroing ride with the first pass
+        p.k0 = win * g.Kc;
+        p.Kc = K - p.k0 < g.Kc ? K - p.k0 : g.Kc;
+        const int extra = win == 0 ? list_blocks + zero_blocks : 0;
+        hipLaunchKernelGGL(wide_code_tiles_kernel, dim3(g.n_img * g.nb + extra), dim3(512), lds_tiles, stream, p, q, win == 0 ? list_blocks : 0);
+        hipLaunchKernelGGL(wide_bwd_kernel, dim3(g.n_img), dim3(WB_THREADS), lds, stream, p);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // the backward of norm() and of the sampling
     if (gather) {

@@ -808,13 +808,14 @@ class ContrastiveCorrelationLoss(nn.Module):
     def fused_kernels_cover(B, C, K, H, W, S, device=None):
         """Does the hand-written loss path (stego_corr_fwd / _bwd, include/stego_corr.h "Limits of this build") take this shape?
         S * S <= 128 sample points per image: K <= 72 on any layout, 72 < K <= 128 on the single-launch forward (any parity, ViT widths, B and the
-        map within its bounds); 128 < S * S <= 256 (cfg.feature_samples 12 .. 16): K <= 88.  Everything else is computed by generic_forward()."""
+        map within its bounds); 128 < S * S <= 256 (cfg.feature_samples 12 .. 16): any K <= 128, any layout.  Everything else is computed by
+        generic_forward()."""
         if K > 128 or H > 32767 or W > 32767:
             return False
         if S * S > 128:
             # 129 .. 256 points per image (cfg.feature_samples 12 .. 16): the multi-launch kernels of csrc/corr_wide.hip behind the same entry
             # points (round 5)
-            return S <= 16 and K <= 88 and (2 + 253) * B <= 65535
+            return S <= 16 and (2 + 253) * B <= 65535
         if K > 72:
             return C in (192, 384, 768) and B <= _pair_set_bound(device) and H <= 256 and W <= 256
         return True
@@ -839,7 +840,7 @@ class ContrastiveCorrelationLoss(nn.Module):
 
     def generic_forward(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms):
         """modules.py:369-398 for any shape (any cfg.feature_samples, any cfg.dim) the kernels behind stego_corr_fwd do not take (fused_kernels_cover:
-        cfg.dim > 128, > 88 at feature_samples > 11, feature_samples > 16).  Same six return values.  On a HIP device: the samplers that write the
+        cfg.dim > 128, feature_samples > 16).  Same six return values.  On a HIP device: the samplers that write the
         dense-correspondence kernel's operands (stego_sample_panels: the fp32 rows of the sampled features never exist), both correlation
         tensors of ALL 2 + neg_samples pair-sets in one launch each, helper()'s elementwise part in three launches, the adjoints as batched
         GEMMs, norm + sampling backward in one scatter per source - composed here, gradient through autograd (host-bound: ~0.6 ms per step at

@@ -53,8 +53,8 @@ def load_config(path=None, overrides=()):
 
 MAX_CODE_DIM = 128               # include/stego_corr.h "Limits of this build" (above 72: channels-last ViT-width maps)
 MAX_FEATURE_SAMPLES = 11
-MAX_FEATURE_SAMPLES_WIDE = 16    # 12 .. 16: csrc/corr_wide.hip behind the same entry points (a few launches instead of one), dim <= 88
-MAX_CODE_DIM_WIDE = 88
+MAX_FEATURE_SAMPLES_WIDE = 16    # 12 .. 16: csrc/corr_wide.hip behind the same entry points (a few launches instead of one)
+MAX_CODE_DIM_WIDE = 128
 MAX_CODE_DIM_ANY_PATH = 72       # above it: the single-launch forward only (its conditions are checked in __init__)
 
 

@@ -216,8 +216,10 @@ def test_library_validates_before_enqueueing():
     assert lib.stego_corr_workspace_bytes(ctypes.byref(w16)) >= n_img * P * (384 + 70) * 4           # the operand images of both correlations
     assert lib.stego_corr_saved_ctx_bytes(ctypes.byref(w16)) >= n_img * P * (70 + 1) * 4             # the normalised code rows + 1 / |row|
     assert lib.stego_corr_bwd_workspace_bytes(ctypes.byref(w16)) >= 2 * n_img * P * 70 * 4
+    w96 = capi.make_desc(4, 384, 96, 28, 28, 12, 5, cfg, (.18, .12, .46))                           # K > 88 beyond 128 points: two passes of the backward's GEMMs
+    assert lib.stego_corr_fwd(ctypes.byref(w96), *args_null) == 1 and lib.stego_corr_workspace_bytes(ctypes.byref(w96)) > 0
     for bad in (capi.make_desc(4, 384, 70, 28, 28, 17, 5, cfg, (.18, .12, .46)),                    # S * S > 256
-                capi.make_desc(4, 384, 96, 28, 28, 12, 5, cfg, (.18, .12, .46))):                   # K > 88 beyond 128 points
+                capi.make_desc(4, 384, 130, 28, 28, 12, 5, cfg, (.18, .12, .46))):                  # K > 128
         assert lib.stego_corr_fwd(ctypes.byref(bad), *args_null) == 3     # STEGO_ERR_UNSUPPORTED
         assert lib.stego_corr_workspace_bytes(ctypes.byref(bad)) == 0
     d0 = capi.make_desc(0, 384, 70, 28, 28, 11, 5, cfg, (.18, .12, .46))

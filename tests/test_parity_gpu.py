@@ -463,16 +463,17 @@ def test_salience_path_on_device_matches_oracle():
 
 
 @pytest.mark.parametrize("S,K,C,layout", [(12, 70, 384, "cl"), (13, 70, 384, "cl"), (16, 70, 384, "cl"), (16, 70, 768, "cl"), (16, 24, 64, "cl"),
-                                          (15, 88, 384, "cl"), (14, 70, 192, "nchw"), (16, 101, 384, "cl"), (5, 130, 384, "cl"), (3, 96, 16, "cl")])
+                                          (15, 88, 384, "cl"), (14, 70, 192, "nchw"), (16, 101, 384, "cl"), (13, 128, 64, "cl"), (12, 89, 64, "nchw"), (5, 130, 384, "cl"),
+                                          (3, 96, 16, "cl")])
 def test_feature_samples_above_11_and_wide_codes(S, K, C, layout):
     """cfg.feature_samples and cfg.dim are free in the reference (train_config.yml:39,51).  feature_samples 12 .. 16 (144 .. 256 points per
-    image, K <= 88) run on the multi-launch kernels of csrc/corr_wide.hip behind stego_corr_fwd / _bwd - the same entry points as S <= 11 (maps of one pixel row or column, any layout);
-    beyond those limits (K > 88 at S > 11, K > 128) generic_forward computes the loss (native samplers + dense-correlation kernel +
+    image, any K <= 128) run on the multi-launch kernels of csrc/corr_wide.hip behind stego_corr_fwd / _bwd - the same entry points as S <= 11 (maps of one pixel row or column, any layout);
+    beyond those limits (K > 128, or K > 72 on maps the S <= 11 kernels do not take) generic_forward computes the loss (native samplers + dense-correlation kernel +
     elementwise launches, gradient through autograd).  Forward and gradients against the fp64 oracle, any map layout."""
     B, H, W, n_neg = 3, 10, 9, 2
     d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=900 + S + K, dino_like=True)
     cfg = O.CorrCfg(feature_samples=S, neg_samples=n_neg)
-    native = S * S > 128 and K <= 88
+    native = S * S > 128 and K <= 128
     assert M.ContrastiveCorrelationLoss.fused_kernels_cover(B, C, K, H, W, S) == native
     inputs = {k: d[k] for k in ("feats", "feats_pos", "code", "code_pos", "coords1", "coords2")}
     if native:

@@ -337,7 +337,7 @@ def test_bench_multi_rank_protocol_two_processes_gloo():
 
 
 def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the_cfg_key_named():
-    """cfg.dim > 128 / cfg.feature_samples > 16 (or > 11 with dim > 88) are valid in the reference (train_config.yml:39,51 are free): they run
+    """cfg.dim > 128 / cfg.feature_samples > 16 are valid in the reference (train_config.yml:39,51 are free): they run
     on the generic path (ContrastiveCorrelationLoss.generic_forward) - the constructor says so, naming the key; so does 72 < dim <= 128 on
     feature maps the single-launch kernel does not take (the feature-pyramid arch: 2048 channels): valid in the reference, it runs on the
     generic path too.  (Odd code dimensions and vit_tiny's 192 channels are served by the single-launch kernel since round 4,
@@ -348,7 +348,7 @@ def test_shapes_outside_the_fused_kernels_are_announced_at_construction_with_the
         warnings.simplefilter("always")
         LitUnsupervisedSegmenter(5, cfg)
     assert not [w for w in rec if "feature_samples" in str(w.message)]
-    for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=17"], "cfg.feature_samples=17"), (["feature_samples=12", "dim=96"], "cfg.feature_samples=12, cfg.dim=96")):
+    for ov, key in ((["dim=130"], "cfg.dim=130"), (["feature_samples=17"], "cfg.feature_samples=17")):
         cfg = load_config(overrides=["model_type=vit_tiny", "dino_patch_size=16", "res=32"] + ov)
         with pytest.warns(UserWarning, match=key):
             LitUnsupervisedSegmenter(5, cfg)
