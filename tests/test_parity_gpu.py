@@ -1675,6 +1675,10 @@ def test_wide_path_forward_is_repeatable_and_capturable():
         assert torch.equal(x, y)
     for x, y in zip(a[1:], b[1:]):
         assert torch.equal(x, y)
+    with torch.no_grad():                        # nothing kept for a backward: fd and the context live in the workspace
+        ng = loss.forward_explicit(f, fp, c.detach(), cp.detach(), coords1, coords2, perms)
+    for x, y in zip(a[0], ng):
+        assert torch.equal(x, y.detach().float())
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
