@@ -496,8 +496,8 @@ def test_feature_samples_above_11_and_wide_codes(S, K, C, layout):
     assert_close(r["d_code_pos"], dcp, rtol=2e-3, atol_frac=1e-3, what="d_code_pos")
 
 
-@pytest.mark.parametrize("native_backbone", [False, True])
-def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
+@pytest.mark.parametrize("native_backbone,S", [(False, 5), (True, 5), (True, 12)])
+def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone, S):
     """The drop-in surface end to end on the MI355X: LitUnsupervisedSegmenter.training_step (reference
     train_segmentation.py:112-245) with the HIP loss inside, against the same step computed on CPU with the
     oracle-backed backend double (same weights, same batch, same RNG draws fed explicitly)."""
@@ -505,7 +505,8 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
     import oracle_backend
     from stego_amd.train_segmentation import LitUnsupervisedSegmenter, SyntheticContrastiveDataset, load_config
     warnings.filterwarnings("ignore", message="DinoFeaturizer")
-    ov = ["model_type=vit_tiny", "dino_patch_size=16", "res=64", "batch_size=4", "feature_samples=5", "neg_samples=2",
+    # (S = 12: the multi-launch loss path of csrc/corr_wide.hip inside the same training step)
+    ov = ["model_type=vit_tiny", "dino_patch_size=16", "res=64", "batch_size=4", "feature_samples=%d" % S, "neg_samples=2",
           "dim=10", "dropout=False", "native_backbone=%s" % native_backbone]
     cfg = load_config(overrides=ov)
     # native_backbone=False isolates the loss path (fp32 torch backbone on both sides); True (the default) runs the whole device step
@@ -523,8 +524,8 @@ def test_training_loop_on_device_matches_cpu_oracle_step(native_backbone):
     batch = torch.utils.data.default_collate([ds[i] for i in range(4)])
     # identical RNG draws on both sides
     g = torch.Generator().manual_seed(5)
-    coords1 = torch.rand(4, 5, 5, 2, generator=g) * 2 - 1
-    coords2 = torch.rand(4, 5, 5, 2, generator=g) * 2 - 1
+    coords1 = torch.rand(4, S, S, 2, generator=g) * 2 - 1
+    coords2 = torch.rand(4, S, S, 2, generator=g) * 2 - 1
     perms = torch.tensor([[1, 2, 3, 0], [2, 3, 0, 1]])
 
     def patched_draw(dev):            # (training_step goes through loss.total() -> loss.draw(): feed the same draws to both sides)
