@@ -516,6 +516,46 @@ def main():
     if rank == 0 and not args.no_alt and not dry:
         product = product_path(sets, cfg, args, dt / args.steps)
 
+    # ---- the other native path, for the record: cfg.feature_samples = 16 (256 points per image: 8 + 4 launches of csrc/corr_wide.hip behind the
+    # same two C-ABI calls), one input set, eager launches (the host needs ~0.16 ms per step, the kernels ~0.36)
+    wide = None
+    if rank == 0 and not args.no_alt and not dry and S <= 11 and not args.fwd_only:
+        try:
+            S16 = 16
+            cfg16 = Cfg()
+            cfg16.corr_precision = args.precision
+            cfg16.feature_samples = S16
+            d16 = make_inputs(B, C, H, W, K, S16, n_neg, 4242, dev, args.layout)
+            desc16 = capi.make_desc(B, C, K, H, W, S16, n_neg, cfg16, (cfg16.pos_intra_shift, cfg16.pos_inter_shift, cfg16.neg_inter_shift),
+                                    capi.PREC_F32 if args.precision == "f32" else capi.PREC_F16X3)
+            gi, ge = (torch.full((1,), w_, device=dev) for w_ in (cfg16.pos_intra_weight, cfg16.pos_inter_weight))
+            gn = torch.full((1,), cfg16.neg_inter_weight / (n_neg * B * S16 ** 4), device=dev).expand(n_neg * B, S16, S16, S16, S16)
+            maps16 = [as_channels_last(d16[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+
+            def step16():
+                out16 = capi.corr_fwd(desc16, *maps16, d16["coords1"], d16["coords2"], d16["perms"], True)
+                lm, icd, ecd, nl, ncd, saved = out16
+                return capi.corr_bwd(desc16, d16["code"], d16["code_pos"], d16["coords1"], d16["coords2"], d16["perms"], saved, icd, ecd, ncd,
+                                     gi, ge, gn, None, None, None)
+
+            for _ in range(4):
+                step16()
+            torch.cuda.synchronize()
+            n16 = 30
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n16):
+                step16()
+            e1.record()
+            torch.cuda.synchronize()
+            ms16 = e0.elapsed_time(e1) / n16
+            wide = {"feature_samples": S16, "ms_per_step": ms16, "value": B / (ms16 * 1e-3), "unit": "image-pairs/s", "steps": n16,
+                    "forward_launches": capi.corr_fwd_launches(desc16, *maps16), "launch": "eager",
+                    "path": "csrc/corr_wide.hip: the multi-launch kernels behind stego_corr_fwd / stego_corr_bwd (4.5 x the pair products of feature_samples = 11)"}
+            del d16, maps16
+        except Exception as e:       # noqa: BLE001 - a record for the reader, never the reason a bench run fails
+            wide = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
     roof = roof_mfma = roof_bwd = None
     fin_us = None
@@ -680,7 +720,7 @@ def main():
                        if dist is not None else None,
                        "shared_device": (args.shared_device == "1" or (args.shared_device == "auto" and dist is not None)) and not dry},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
-            "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt,
+            "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt, "feature_samples_16": wide,
             "cpu_baseline": cpu,
         }
         if dry:

@@ -472,7 +472,8 @@ def test_bench_denominators_are_the_contract_s_numbers():
     # and for N > 1 what every rank saw and what the all-reduce costs on its own
     assert bench.HBM_PEAK == 8.0e12 and bench.HBM_ACHIEVABLE == 6.3e12
     src = open(bench.__file__).read()
-    for key in ("frac_of_achievable", "traffic_source", 'alt["roofline"]', "ms_per_step_by_rank", "ms_per_step_rank_min", "ms_per_step_rank_max", "allreduce_us"):
+    for key in ("frac_of_achievable", "traffic_source", 'alt["roofline"]', "ms_per_step_by_rank", "ms_per_step_rank_min", "ms_per_step_rank_max", "allreduce_us",
+                '"feature_samples_16": wide', "--feature-samples"):          # (the multi-launch path of cfg.feature_samples 12 .. 16 in the same line)
         assert key in src, key
     import json
     tj = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "traffic.json")))
