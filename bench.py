@@ -192,9 +192,11 @@ def _product_path(sets, cfg, args, kernel_step_s, total=False):
 
 
 def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
-    """The reference's CPU path (torch CPU port of modules.py:349-398, oracle/torch_cpu_port.py),
-    forward+backward, on the host cores of this box.  Bounded sample."""
-    from oracle.torch_cpu_port import corr_loss_torch_cpu
+    """The reference's CPU path, forward+backward, on the host cores of this box; a bounded sample.  BASELINE.md 2: "imported
+    unmodified" - when /root/reference is present (the build container) the timed callable IS the reference's own
+    ContrastiveCorrelationLoss.forward (src/modules.py:349-398, through oracle/ref_shim.py; kind "reference", its own RNG draws);
+    on the GPU box the reference does not exist and the torch CPU port of the same lines is timed (oracle/torch_cpu_port.py, checked
+    against the reference-generated goldens; kind "port")."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -202,12 +204,26 @@ def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
     d = make_inputs(B, C, H, W, K, S, n_neg, 4321, torch.device("cpu"))
     code = d["code"].clone().requires_grad_(True)
     code_pos = d["code_pos"].clone().requires_grad_(True)
+    kind, what = "port", "port = oracle/torch_cpu_port.py (the ATen CPU kernels the reference calls)"
+    ref_loss = None
+    try:
+        from oracle import ref_shim
+        if ref_shim.available():
+            ref_loss = ref_shim.load_reference_modules().ContrastiveCorrelationLoss(cfg)
+            kind, what = "reference", "reference = the unmodified /root/reference/src/modules.py:349-398 through oracle/ref_shim.py (its own torch.rand / randperm draws)"
+    except Exception:       # noqa: BLE001 - the port is the fallback, and says so
+        ref_loss = None
+    if ref_loss is None:
+        from oracle.torch_cpu_port import corr_loss_torch_cpu
 
     def step():
         code.grad = None
         code_pos.grad = None
-        out = corr_loss_torch_cpu(d["feats"], d["feats_pos"], code, code_pos, d["coords1"], d["coords2"],
-                                  list(d["perms"]), cfg)
+        if ref_loss is not None:
+            out = ref_loss(d["feats"], d["feats_pos"], None, None, code, code_pos)
+        else:
+            out = corr_loss_torch_cpu(d["feats"], d["feats_pos"], code, code_pos, d["coords1"], d["coords2"],
+                                      list(d["perms"]), cfg)
         (cfg.pos_intra_weight * out[0] + cfg.pos_inter_weight * out[2] + cfg.neg_inter_weight * out[4].mean()).backward()
 
     # intra-op thread count: the ATen CPU kernels stop scaling (and then collapse) well below the 256
@@ -234,11 +250,10 @@ def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=B / med, unit="image-pairs/s", cores=cores, kind="port",
+    return dict(value=B / med, unit="image-pairs/s", cores=cores, kind=kind,
                 sample="%d fwd+bwd steps of the same B=%d workload (median %.1f ms), torch %s CPU, %d threads "
-                       "(fastest of 8/16/32/64 tried; %d hardware threads visible); port = "
-                       "oracle/torch_cpu_port.py (the ATen CPU kernels the reference calls)"
-                       % (len(times), B, med * 1e3, torch.__version__, cores, avail))
+                       "(fastest of 8/16/32/64 tried; %d hardware threads visible); %s"
+                       % (len(times), B, med * 1e3, torch.__version__, cores, avail, what))
 
 
 def main():
@@ -560,10 +575,13 @@ def main():
     roof = roof_mfma = roof_bwd = None
     fin_us = None
 
+    fwd_samples = {}                          # id(desc) -> every single-launch duration of the main forward kernel (ms)
+
     def forward_launch_ms(desc_):
         """(ms in front of, of, behind the main forward kernel) per launch: HIP events on the launch stream around single launches."""
         ms = [0.0, 0.0, 0.0]
         rounds = 5
+        samples = fwd_samples.setdefault(id(desc_), [])
         for r in range(rounds + 1):
             acc = [0.0, 0.0, 0.0]
             for i in range(args.sets):
@@ -574,9 +592,53 @@ def main():
                                           as_channels_last(d["code"]), as_channels_last(d["code_pos"]),
                                           d["coords1"], d["coords2"], d["perms"], not args.fwd_only, 1)
                 acc = [x + y for x, y in zip(acc, k)]
+                if r > 0:
+                    samples.append(k[1])
             if r > 0:
                 ms = [x + y / args.sets for x, y in zip(ms, acc)]
         return [x / rounds for x in ms]
+
+    def pctl(xs, scale=1.0):
+        """p10 / p50 / p90 of a list of durations (median and p10 / p90, not only a mean)."""
+        if not xs:
+            return None
+        v = sorted(xs)
+        at = lambda q: v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))] * scale      # noqa: E731
+        return {"p10": at(0.10), "p50": at(0.50), "p90": at(0.90), "min": v[0] * scale, "max": v[-1] * scale, "n": len(v)}
+
+    # ---- per-step distribution (outside the timed region): one HIP event behind every eagerly launched step on torch's current
+    # stream - the stream capi launches on -, consecutive differences = what each step took incl. its launch gaps
+    step_dist = None
+    if rank == 0 and not dry:
+        try:
+            prec_ = capi.PREC_F32 if args.precision == "f32" else capi.PREC_F16X3
+            desc_d = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift), prec_)
+
+            def one_step(i):
+                d = sets[i]
+                out = capi.corr_fwd(desc_d, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]), as_channels_last(d["code"]),
+                                    as_channels_last(d["code_pos"]), d["coords1"], d["coords2"], d["perms"], not args.fwd_only)
+                if not args.fwd_only:
+                    lm, icd, ecd, nl, ncd, saved = out
+                    capi.corr_bwd(desc_d, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved, icd, ecd, ncd,
+                                  g_intra, g_inter, g_neg, None, None, None)
+
+            nd = 200
+            for k in range(20):
+                one_step(k % args.sets)
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
+            evs[0].record()
+            for k in range(nd):
+                one_step(k % args.sets)
+                evs[k + 1].record()
+            torch.cuda.synchronize()
+            step_dist = pctl([evs[k].elapsed_time(evs[k + 1]) for k in range(nd)], 1e3)
+            step_dist["unit"] = "us"
+            step_dist["what"] = "%d eager steps (%s), one HIP event behind each on the launch stream: consecutive differences" % (
+                nd, "forward only" if args.fwd_only else "forward+backward")
+        except Exception as e:       # noqa: BLE001 - a record for the reader, never the reason a bench run fails
+            step_dist = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and not dry:
         ms_samp, ms_main, ms_fin = forward_launch_ms(desc)
@@ -589,7 +651,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("%s_%s_B%d" % (args.workload, args.precision, B))
+                # (the constants are counter passes of the feature_samples = 11 single-launch kernel: any other S is a different set of
+                # kernels with different traffic - no constant rather than the wrong one)
+                traffic = tj.get("%s_%s_B%d" % (args.workload, args.precision, B)) if S == 11 else tj.get("%s_%s_B%d_S%d" % (args.workload, args.precision, B, S))
                 if traffic is not None:
                     traffic_source = "static: profiles/traffic.json (%s) - builder-run rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE per launch; not measured in this run" % tj.get("_source", "see its _note")
             except Exception:       # noqa: BLE001
@@ -609,6 +673,7 @@ def main():
                         frac_of_achievable=ach / HBM_ACHIEVABLE, achievable_peak=HBM_ACHIEVABLE / 1e9,
                         traffic=traffic, traffic_source=traffic_source,
                         algorithmic_bytes=ab, us_per_launch={"corr_fused_kernel": ms_main * 1e3},
+                        us_per_launch_dist=pctl(fwd_samples.get(id(desc), []), 1e3),
                         timing="HIP events on the launch stream around single launches, input sets rotated")
             roof_mfma = dict(bound="mfma", kernel="corr_fused_kernel", achieved=fl / t_fwd / 1e12, peak=peak / 1e12,
                              unit="TFLOP/s", frac=fl / t_fwd / peak, algorithmic_flops=fl,
@@ -720,6 +785,7 @@ def main():
                        if dist is not None else None,
                        "shared_device": (args.shared_device == "1" or (args.shared_device == "auto" and dist is not None)) and not dry},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
+            "step_us_dist": step_dist,
             "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt, "feature_samples_16": wide,
             "cpu_baseline": cpu,
         }

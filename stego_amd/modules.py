@@ -934,7 +934,9 @@ class ContrastiveCorrelationLoss(nn.Module):
         else:
             out = _CorrLossFunction.apply(orig_feats, orig_feats_pos, orig_code, orig_code_pos, coords1, coords2, perms, desc)
         neg_loss = out[4]
-        lazy = getattr(cfg, "lazy_loss_sums", True)               # (off: the three scalars are plain tensors)
+        # OPT-IN (round 6: the default is the reference's contract - three plain 0-dim tensors, so that ``w * loss + ...`` in the
+        # reference's own training_step (train_segmentation.py:179-181,227) is a torch.Tensor): cfg.lazy_loss_sums = True wraps them
+        lazy = getattr(cfg, "lazy_loss_sums", False)
         o_intra, o_inter, o_neg = _lazy_scalars(out[0], out[2], out[6] if n_neg > 0 else None, out[7] if len(out) > 7 else None) \
             if lazy else (out[0], out[2], out[6])
         if n_neg > 0:

@@ -1335,8 +1335,8 @@ def test_without_the_torch_glue_extension_the_product_is_the_same(monkeypatch):
 
 def test_lazy_loss_sum_gives_the_plain_gradients_eagerly_and_inside_a_captured_graph():
     """The reference's weighted sum of the three loss scalars (train_segmentation.py:178-181) written on the outputs of forward():
-    with cfg.lazy_loss_sums (default) the coefficients reach the loss op's backward as its upstream gradients without a kernel;
-    values and gradients equal the plain tensor expression's (cfg.lazy_loss_sums = False), eagerly and replayed from a HIP graph."""
+    with cfg.lazy_loss_sums = True (opt-in since round 6) the coefficients reach the loss op's backward as its upstream gradients without
+    a kernel; values and gradients equal the plain tensor expression's (the default), eagerly and replayed from a HIP graph."""
     import copy
     B, C, H, W, K, S, n_neg = 8, 384, 28, 28, 70, 11, 5
     d = O.synth_inputs(B, C, H, W, K, S, n_neg, seed=4)
@@ -1344,8 +1344,9 @@ def test_lazy_loss_sum_gives_the_plain_gradients_eagerly_and_inside_a_captured_g
     f, fp = _channels_last(t["feats"]), _channels_last(t["feats_pos"])
     cfg = O.CorrCfg()
     cfg.corr_precision = "f16x3"
-    plain_cfg = copy.copy(cfg)
-    plain_cfg.lazy_loss_sums = False
+    plain_cfg = copy.copy(cfg)                 # the default: three plain 0-dim tensors
+    assert not getattr(plain_cfg, "lazy_loss_sums", False)
+    cfg.lazy_loss_sums = True
 
     def run(cfg_, c, cp):
         out = M.ContrastiveCorrelationLoss(cfg_).forward_explicit(f, fp, c, cp, t["coords1"], t["coords2"], t["perms"])
@@ -1359,6 +1360,7 @@ def test_lazy_loss_sum_gives_the_plain_gradients_eagerly_and_inside_a_captured_g
         cp = _channels_last(t["code_pos"]).detach().requires_grad_(True)
         out, loss = run(cfg_, c, cp)
         assert isinstance(loss, M._LazyLoss) == (name == "lazy")
+        assert isinstance(loss, torch.Tensor) == (name == "plain")
         val = float(loss)                      # (evaluates a copy of the sum; the lazy object itself stays lazy for backward())
         out, loss = run(cfg_, c, cp)
         loss.backward()
