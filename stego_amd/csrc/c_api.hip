@@ -87,6 +87,7 @@ int check_desc(const StegoCorrDesc* d, bool helper)
 struct Geometry {
     int n_roles, nset, NCH, KQ, LDK;
     int NCH2, NKC, kper;            // fused forward: C / 32 feature stages, code K-chunks of kper channels
+    size_t rowg_off;
     size_t stats_bytes, sync_bytes, fs_bytes, csf_bytes, cs_bytes, nrm_bytes, tap_bytes, ctx_bytes, ws_bytes, bwd_ws_bytes;
     size_t bwd_dt_bytes, bwd_slots_bytes, bwd_pool_bytes;    // lists-first backward: DT rows, list slots, overflow pool (0: not covered)
 };
@@ -101,7 +102,7 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.KQ = (d->K + 7) & ~7;
     g.LDK = g.KQ + 4;
     const size_t n_tiles = (size_t)(helper ? 1 : 2 + d->n_neg) * d->B;
-    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * (128 + 1024), 256);     // tail: debug stamps (16 + 128 per tile)
+    g.stats_bytes = round_up(n_tiles * 4 * sizeof(float) + 1024 + n_tiles * (128 + 1024) + 40960, 256);     // tail: debug stamps (16 + 128 per tile; the column-half launch: 16 per workgroup of a whole-device grid)
     const size_t fside = d->precision == STEGO_PREC_F16X3 ? (size_t)2 * TP * LDH * 2 : (size_t)TP * LDA * 4;
     g.fs_bytes = round_up((size_t)d->B * g.NCH * fside + 1024, 256);            // anchor sets only (three-launch layout)
     // fused forward: anchor operands as ring stages of 16 KB (32 channels: fp16 hi + lo, or fp32), codes as K-chunks
@@ -117,7 +118,8 @@ Geometry geometry(const StegoCorrDesc* d, bool helper)
     g.tap_bytes = round_up((size_t)g.nset * TP * 16, 256);        // each of tapyx / tapw
     g.ctx_bytes = g.cs_bytes + g.nrm_bytes + 2 * g.tap_bytes;
     // in-launch hand-off words of the fused forward: one counter per anchor + one 8-byte granule per tile
-    g.sync_bytes = round_up((size_t)d->B * 256 + n_tiles * 8 * 4, 256) + 256;   // + 3 more granules per tile: sum lp, sum clamp, applied;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
+    g.rowg_off = round_up((size_t)d->B * 256 + 2 * n_tiles * 8 * 4, 256);       // column-half launch: 2 x tiles items, 4 granules each, then 128 row-sum granules per item
+    g.sync_bytes = g.rowg_off + round_up(2 * n_tiles * (size_t)TP * 8, 256) + 256;   // + 3 more granules per tile: sum lp, sum clamp, applied;   // counters 256 B apart (ANCHOR_CNT_STRIDE); + the done counter
     g.ws_bytes = g.stats_bytes + g.sync_bytes + g.fs_bytes + g.csf_bytes + g.ctx_bytes;
     g.bwd_dt_bytes = round_up(n_tiles * 2 * TP * g.LDK * sizeof(float), 256);
     g.bwd_slots_bytes = g.bwd_pool_bytes = 0;
@@ -287,6 +289,7 @@ int plan_fwd(const StegoCorrDesc* d, bool helper, const StegoMap* feats, const S
     fp.anchor_cnt = reinterpret_cast<unsigned*>(sync);
     fp.gran = reinterpret_cast<unsigned long long*>(sync + (size_t)d->B * 256);
     fp.done_cnt = reinterpret_cast<unsigned*>(sync + g.sync_bytes - 256);
+    fp.rowg = reinterpret_cast<unsigned long long*>(sync + g.rowg_off);
     fp.fs = fs;
     fp.csf = csf;
     fp.cs = sp.cs; fp.nrm = sp.nrm; fp.tapyx = sp.tapyx; fp.tapw = sp.tapw;

@@ -141,6 +141,8 @@ struct FusedParams {
     unsigned* anchor_cnt;                      // [B] points published per anchor           } zeroed before the launch
     unsigned long long* gran;                  // [4][n_sets*B] {tag = 1, value} granules   }  (the last workgroup of a
     unsigned* done_cnt;                        // workgroups that finished                  }   launch zeroes them again)
+    unsigned long long* rowg;                  // column-half launch (corr_fused_half.hip): [2 * n_sets * B][128] {tag, value} partial row sums of fd, zeroed by their one reader
+    int n_anchor_wg;                           // column-half launch: workgroups at the front of the grid that only sample anchors (a multiple of 8)
     unsigned char* fs;                         // anchor feature operand stages [B][NCH2][16 KB] (ring format H, or F in f32 mode)
     unsigned char* csf;                        // anchor code operand stages    [B][NKC][16 KB]  (ring format F)
     float* cs;                                 // normalised sampled codes of every set [nset][128][LDK] (the backward's context)

@@ -53,6 +53,7 @@
 // This file is compiled three times (the 44 instantiations of the kernel take two minutes in one translation unit): as itself - the host
 // side and the even-K kernels of C = 384 / 768 (the BASELINE configs) - and, included by corr_fused_odd.hip / corr_fused_c192.hip with
 // STEGO_FUSED_PART = 1 / 2, for the odd-K kernels and the C = 192 kernels with their two launch functions.  Same template, same code.
+// STEGO_FUSED_PART = 3 (corr_fused_half.hip): the device functions only - the column-half kernel of small batches is built from them.
 #ifndef STEGO_FUSED_PART
 #define STEGO_FUSED_PART 0
 #endif
@@ -91,9 +92,11 @@ __device__ __forceinline__ unsigned long long lanes_below(int lane) { return lan
 
 // ------------------------------------------------------------------------------------------ tile placement
 // XCD preference of tile t = (p, b): the image its B side is gathered from, modulo 8.
-__device__ __forceinline__ int tile_pref(const FusedParams& prm, int t, int t_end)
+template <int HS = 0>                                   // HS = 1: work items are column halves, item t = 2 * tile + half (corr_fused_half.hip)
+__device__ __forceinline__ int tile_pref(const FusedParams& prm, int t_, int t_end)
 {
-    if (t >= t_end) return -1;
+    if (t_ >= t_end) return -1;
+    const int t = t_ >> HS;
     const int B = prm.B;
     const int p = t / B, b = t - p * B;
     int src = b;
@@ -109,15 +112,15 @@ __device__ __forceinline__ int tile_pref(const FusedParams& prm, int t, int t_en
 constexpr int ASSIGN_NB = 4;
 
 // the loads of the first block, issued at the top of the kernel so that they fly together with phase 1's
-template <bool WINDOW>
+template <bool WINDOW, int HS = 0>
 __device__ __forceinline__ void assign_prefetch(const FusedParams& prm, int lane, int w0_, int n_tiles, int (&pref)[ASSIGN_NB])
 {
     const int w0 = WINDOW ? w0_ : 0;
 #pragma unroll
-    for (int i = 0; i < ASSIGN_NB; ++i) pref[i] = tile_pref(prm, w0 + 64 * i + lane, w0 + n_tiles);
+    for (int i = 0; i < ASSIGN_NB; ++i) pref[i] = tile_pref<HS>(prm, w0 + 64 * i + lane, w0 + n_tiles);
 }
 
-template <bool WINDOW>                                   // (false: one round, w0 = 0 folded - the common case keeps its old code)
+template <bool WINDOW, int HS = 0>                       // (false: one round, w0 = 0 folded - the common case keeps its old code)
 __device__ int assign_tile(const FusedParams& prm, int me, int lane, int w0_, int n_tiles, const int (&pref0)[ASSIGN_NB])
 {
     constexpr int NB = ASSIGN_NB;
@@ -130,7 +133,7 @@ __device__ int assign_tile(const FusedParams& prm, int me, int lane, int w0_, in
     int pref[NB];
     for (int c0 = 0; c0 < n_tiles; c0 += 64 * NB) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
+        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref<HS>(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -153,7 +156,7 @@ __device__ int assign_tile(const FusedParams& prm, int me, int lane, int w0_, in
     const unsigned long long below = lanes_below(lane);
     for (int c0 = 0; c0 < n_tiles; c0 += 64 * NB) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
+        for (int i = 0; i < NB; ++i) pref[i] = c0 == 0 ? pref0[i] : tile_pref<HS>(prm, w0 + c0 + 64 * i + lane, w0 + n_tiles);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int myrank = 0, myslots = 0;
@@ -1558,6 +1561,21 @@ hipError_t prepare_corr_fused(const FusedParams& prm, size_t sync_bytes, hipStre
 }
 
 hipError_t launch_fused_odd(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream);      // corr_fused_odd.hip
+hipError_t launch_fused_half(const FusedParams& prm, int precision, hipStream_t stream);                                     // corr_fused_half.hip
+
+// The column-half launch (corr_fused_half.hip): small batches - every column half of every tile gets a compute unit of its own (16 B <= CUs
+// with five negatives: the reference's batch size of 16), the device is ours alone, the BASELINE widths with an even code dimension, more
+// than 64 sample points (below that the second half would be padding).  Any STEGO_DEBUG bit but the stamps (256) keeps the full-tile
+// kernel - its ablation / forced-path bits mean that kernel; bit 16384 has no other meaning: same-process A/B of the two launches.
+static bool half_launch_covers(const FusedParams& prm, bool shared, int all, int* n_anchor_wg)
+{
+    if (shared || (prm.debug & ~256) != 0 || !prm.rowg) return false;
+    if (!(prm.C == 384 || prm.C == 768) || (prm.K & 1) || prm.P <= 64) return false;
+    const int n_items = 2 * prm.n_sets * prm.B;
+    if (n_items + 8 > all) return false;
+    *n_anchor_wg = (all - n_items) & ~7;
+    return true;
+}
 hipError_t launch_fused_c192(const FusedParams& prm, int precision, dim3 grid, dim3 block, int lds, hipStream_t stream);     // corr_fused_c192.hip
 
 // one instantiation: dynamic LDS attribute, launch
@@ -1618,6 +1636,12 @@ hipError_t launch_corr_fused(const FusedParams& prm_in, int precision, size_t sy
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (!prepared && (e = prepare_corr_fused(prm, sync_bytes, stream)) != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], stream);
+    if (half_launch_covers(prm, sd != 0, all, &prm.n_anchor_wg)) {
+        if ((e = launch_fused_half(prm, precision, stream)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (ev) { (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
+        return hipGetLastError();
+    }
     const dim3 grid(n_tiles > prm.n_owner ? n_tiles : prm.n_owner), block(FUSED_THREADS);
     e = prm.C == 192 ? launch_fused_c192(prm, precision, grid, block, lds, stream)
         : (prm.K & 1) ? launch_fused_odd(prm, precision, grid, block, lds, stream) : launch_fused_even(prm, precision, grid, block, lds, stream);
@@ -1651,7 +1675,7 @@ hipError_t launch_fused_odd(const FusedParams& prm, int precision, dim3 grid, di
 }
 #undef STEGO_FUSED_NK
 #undef STEGO_FUSED_ONE
-#else
+#elif STEGO_FUSED_PART == 2
 // one instantiation: dynamic LDS attribute, launch
 #define STEGO_FUSED_ONE(PR, N, NK, ODD)                                                                \
     do {                                                                                               \

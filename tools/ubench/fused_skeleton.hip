@@ -46,6 +46,7 @@ struct SK {
     const int4* taps;            // [NSETS*B][128] pixel indices of the 4 taps (set s = role * B + b; role 0 anchors @coords1)
     const float4* tapw;          // [NSETS*B][128]
     const int* tile_src;         // [NSETS*B] source image of the tile's B side
+    const int* tile_rank;        // [NSETS*B] rank of the tile among the tiles that gather from the same image
     const int* wg_item;          // [grid] work item of workgroup w: FULL: tile or -1; HALF: 2 * tile + half, or -1
     unsigned char* fs;           // anchor feature operand [B][NCH2][16 KB]
     unsigned char* csf;          // anchor code operand    [B][NKC][16 KB]
@@ -55,6 +56,10 @@ struct SK {
     float* cd; float* w; float* loss;     // [NSETS*B][P2] each (loss: only sets >= 2B are written)
     unsigned long long* stamps;  // [grid][4]
     int B, NCH2, flags, n_anchor_wg;
+    const float* cold;           // experiment pool: one feature image per workgroup that nobody else reads
+    int src_mode;                // 0 the real sources; 1 every tile gathers from ONE image per XCD (L2-resident); 2 inter tiles cold-unique, others hot;
+                                 // 3 every tile: points 0..63 hot, 64..127 cold-unique (hits and misses mixed in every wave); 4 everything cold-unique
+    int rot_mul;                 // feature stages start at (rank * rot_mul) % NCH2: tiles that share an image do not ask for the same lines at the same time
 };
 
 __device__ __forceinline__ void dma_piece_sc1(const unsigned char* gsrc_lane, unsigned lds_addr)
@@ -253,16 +258,22 @@ __global__ void __launch_bounds__(HALF ? 512 : 768, HALF ? 4 : 3) skeleton_kerne
                 __syncthreads();
                 if (tid == 0) publish_rows(p, x, beg, end - beg);
             }
-        } else if (me < p.n_anchor_wg) {
-            const int x = me & 7, r = me >> 3;                     // two workgroups per anchor: 64 rows each
+        } else {
+            // the samplers of XCD x: its anchor workgroups (front of the grid) and the workgroups that hold a self-correlation half
+            // (no gather stream of their own; the placement puts them on the first 2 nb tile slots of the XCD)
+            const int x = me & 7;
             const int nb = (B - x + 7) >> 3;
-            const int per = (p.n_anchor_wg / 8);                   // workgroups of this XCD
-            const int R = nb * TP;
-            const int beg = R * r / per, end = R * (r + 1) / per;
-            sample_anchor_rows<NJ, 1>(p, x, beg, end, wave8, 4 + GW, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) publish_rows(p, x, beg, end - beg);
+            const int na = p.n_anchor_wg / 8;
+            const int r = me < p.n_anchor_wg ? me >> 3 : na + ((me - p.n_anchor_wg) >> 3);
+            const int ns = na + 2 * nb;
+            if (r < ns && nb > 0) {
+                const int R = nb * TP;
+                const int beg = R * r / ns, end = R * (r + 1) / ns;
+                sample_anchor_rows<NJ, 1>(p, x, beg, end, wave8, 4 + GW, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) publish_rows(p, x, beg, end - beg);
+            }
         }
     }
     if (item < 0) { if (tid == 0) { st[1] = st[2] = st[3] = __builtin_amdgcn_s_memrealtime(); } return; }
@@ -277,6 +288,8 @@ __global__ void __launch_bounds__(HALF ? 512 : 768, HALF ? 4 : 3) skeleton_kerne
     const unsigned char* fsA = p.fs + (size_t)b * NCH2 * RS_SIDE;
     const unsigned char* csfA = p.csf + (size_t)b * NKC * RS_SIDE;
     const int q0 = half * 64;                                      // first B point of my half
+    const int rot = __builtin_amdgcn_readfirstlane((p.tile_rank[tile] * p.rot_mul + (HALF ? half * (p.rot_mul ? NCH2 / 2 : 0) : 0)) % NCH2);
+    auto fstage = [&](int f) { const int g = f + rot; return g >= NCH2 ? g - NCH2 : g; };     // feature stage visited at step f
 
     f32x16 acc[2][HALF ? 1 : 2], accc[2][HALF ? 1 : 2];
 #pragma unroll
@@ -287,7 +300,7 @@ __global__ void __launch_bounds__(HALF ? 512 : 768, HALF ? 4 : 3) skeleton_kerne
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accc[i][j][e] = 0.f; }
 
     if (mfma_team) {
-        auto stage_src = [&](int n) { return n < NKC ? csfA + (size_t)n * RS_SIDE : fsA + (size_t)(n - NKC) * RS_SIDE; };
+        auto stage_src = [&](int n) { return n < NKC ? csfA + (size_t)n * RS_SIDE : fsA + (size_t)fstage(n - NKC) * RS_SIDE; };
         const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_address(ring));
         if (wave == 0 && (p.flags & F_P1)) {
             for (;;) {
@@ -373,7 +386,12 @@ __global__ void __launch_bounds__(HALF ? 512 : 768, HALF ? 4 : 3) skeleton_kerne
             co[j][2] = (unsigned)(tp.z * p.c_sp) * 4u; co[j][3] = (unsigned)(tp.w * p.c_sp) * 4u;
             if (g8 == 0) { p.o_taps[(size_t)sB * TP + q] = tp; p.o_tapw[(size_t)sB * TP + q] = tw[j]; }
         }
-        const __amdgpu_buffer_rsrc_t imgB_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(imgB), 0, 0x7fffffff, 0x00020000);
+        const float* hot = p.feats + (long long)(me & 7) * p.f_sn;
+        const float* uniq = p.cold + (long long)me * p.f_sn;
+        const float* i0 = p.src_mode == 0 ? imgB : (p.src_mode == 1 || p.src_mode == 3) ? hot : p.src_mode == 2 ? (pset == 1 ? uniq : hot) : uniq;
+        const float* i1 = p.src_mode == 0 ? imgB : p.src_mode == 1 ? hot : p.src_mode == 2 ? (pset == 1 ? uniq : hot) : uniq;
+        const __amdgpu_buffer_rsrc_t imgB_r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(i0), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t imgB_r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(i1), 0, 0x7fffffff, 0x00020000);
         struct GSet { f32x4 tv[GI][4]; };
         auto issue = [&](GSet& g, int m) {
             if (m < NKC) {
@@ -391,12 +409,12 @@ __global__ void __launch_bounds__(HALF ? 512 : 768, HALF ? 4 : 3) skeleton_kerne
                         g.tv[j][t] = f32x4{v0 ? lo[0] : 0.f, v0 ? lo[1] : 0.f, v1 ? hi[0] : 0.f, v1 ? hi[1] : 0.f};
                     }
             } else {
-                const int so = __builtin_amdgcn_readfirstlane((m - NKC) * 128);
+                const int so = __builtin_amdgcn_readfirstlane(fstage(m - NKC) * 128);
 #pragma unroll
                 for (int j = 0; j < GI; ++j)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        g.tv[j][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(imgB_r, (int)fo[j][t], so, 0));
+                        g.tv[j][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(j == 0 ? imgB_r0 : imgB_r1, (int)fo[j][t], so, 0));
             }
         };
         float ss[GI] = {0.f, 0.f};
@@ -566,14 +584,15 @@ int main(int argc, char** argv)
     const int C = argc > 2 ? atoi(argv[2]) : 384;
     const int HW = argc > 3 ? atoi(argv[3]) : 28;
     const int launches = argc > 4 ? atoi(argv[4]) : 40;
-    const int NJ = C / 128, NCH2 = C / 32, NPIX = HW * HW, NSET_IN = 4;
+    const int NJ = C / 128, NCH2 = C / 32, NPIX = HW * HW, NSET_IN = getenv("SKEL_SETS") ? atoi(getenv("SKEL_SETS")) : 4;
     if (!(C == 384 || C == 768) || B % 8 != 0 || NSETS * B > 256) { printf("C in {384, 768}, B a multiple of 8, 7 B <= 256\n"); return 1; }
     int cus = 0;
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     const int n_tiles = NSETS * B;
     const size_t f_img = (size_t)(NPIX + 1) * C, c_img = (size_t)NPIX * K;       // features: token stride of the ViT (CLS token in front)
     const size_t f_elems = f_img * B, c_elems = c_img * B;
-    std::vector<float*> d_f(NSET_IN), d_fp(NSET_IN), d_c(NSET_IN), d_cp(NSET_IN);
+    std::vector<float*> d_f(NSET_IN), d_fp(NSET_IN), d_c(NSET_IN), d_cp(NSET_IN), d_cold(NSET_IN);
+    const bool want_cold = getenv("SKEL_MODES") != nullptr;
     {
         std::vector<float> h(f_elems);
         srand(1);
@@ -585,6 +604,8 @@ int main(int argc, char** argv)
             CK(hipMemcpy(d_fp[s], h.data(), f_elems * 4, hipMemcpyHostToDevice));
             CK(hipMemcpy(d_c[s], h.data(), c_elems * 4, hipMemcpyHostToDevice));
             CK(hipMemcpy(d_cp[s], h.data(), c_elems * 4, hipMemcpyHostToDevice));
+            d_cold[s] = nullptr;
+            if (want_cold) { CK(hipMalloc(&d_cold[s], f_img * 512 * 4)); CK(hipMemset(d_cold[s], 0, f_img * 512 * 4)); }
         }
     }
     // draws: coords1 / coords2 per image, 5 permutations without fixed points
@@ -608,6 +629,14 @@ int main(int argc, char** argv)
         const float* cc = (pset == 0 ? c1.data() : c2.data()) + (size_t)b * P * 2;
         for (int q = 0; q < P; ++q) make_taps(cc[2 * q], cc[2 * q + 1], HW, HW, &h_taps[((size_t)t * TP + q) * 4], &h_tapw[((size_t)t * TP + q) * 4]);
     }
+    std::vector<int> h_rank(n_tiles, 0);
+    {
+        std::vector<int> cnt(2 * B, 0);
+        for (int t = B; t < n_tiles; ++t) { const int key = (t / B == 1 ? B : 0) + h_src[t]; h_rank[t] = cnt[key]++; }
+    }
+    int* d_rank;
+    CK(hipMalloc(&d_rank, n_tiles * 4));
+    CK(hipMemcpy(d_rank, h_rank.data(), n_tiles * 4, hipMemcpyHostToDevice));
     int4* d_taps; float4* d_tapw; int* d_src;
     CK(hipMalloc(&d_taps, h_taps.size() * 4)); CK(hipMalloc(&d_tapw, h_tapw.size() * 4)); CK(hipMalloc(&d_src, n_tiles * 4));
     CK(hipMemcpy(d_taps, h_taps.data(), h_taps.size() * 4, hipMemcpyHostToDevice));
@@ -617,7 +646,7 @@ int main(int argc, char** argv)
     SK p{};
     p.B = B; p.NCH2 = NCH2;
     p.f_sn = (long long)f_img; p.c_sn = (long long)c_img; p.f_sp = C; p.c_sp = K;
-    p.taps = d_taps; p.tapw = d_tapw; p.tile_src = d_src;
+    p.taps = d_taps; p.tapw = d_tapw; p.tile_src = d_src; p.tile_rank = d_rank;
     CK(hipMalloc(&p.fs, (size_t)B * NCH2 * RS_SIDE)); CK(hipMalloc(&p.csf, (size_t)B * NKC * RS_SIDE));
     CK(hipMemset(p.fs, 0, (size_t)B * NCH2 * RS_SIDE)); CK(hipMemset(p.csf, 0, (size_t)B * NKC * RS_SIDE));
     CK(hipMalloc(&p.cs, (size_t)n_tiles * TP * LDK * 4));
@@ -660,21 +689,28 @@ int main(int argc, char** argv)
     printf("# B=%d C=%d %dx%d: algorithmic bytes %.2f MB (roofline 8 TB/s: %.1f us)\n", B, C, HW, HW, alg / 1e6, alg / 8e6);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    struct Var { const char* name; int half; int flags; };
+    struct Var { const char* name; int half; int flags; int rot; int mode; };
     const Var vars[] = {
-        {"FULL all", 0, F_ALL}, {"HALF all", 1, F_ALL},
-        {"FULL no-wait (p1 off)", 0, F_ALL & ~F_P1}, {"HALF no-wait (p1 off)", 1, F_ALL & ~F_P1},
-        {"FULL no mfma", 0, F_ALL & ~F_MFMA}, {"HALF no mfma", 1, F_ALL & ~F_MFMA},
-        {"FULL no mfma, no-wait", 0, F_ALL & ~F_MFMA & ~F_P1}, {"HALF no mfma, no-wait", 1, F_ALL & ~F_MFMA & ~F_P1},
-        {"FULL gather only", 0, F_GATHER}, {"HALF gather only", 1, F_GATHER},
-        {"FULL gather + astream", 0, F_GATHER | F_ASTREAM}, {"HALF gather + astream", 1, F_GATHER | F_ASTREAM},
-        {"FULL out only", 0, F_OUT}, {"HALF out only", 1, F_OUT},
-        {"FULL p1 only", 0, F_P1}, {"HALF p1 only", 1, F_P1},
-        {"FULL all but out", 0, F_ALL & ~F_OUT}, {"HALF all but out", 1, F_ALL & ~F_OUT},
+        {"FULL all", 0, F_ALL, 0}, {"FULL all rot1", 0, F_ALL, 1}, {"FULL all rot2", 0, F_ALL, 2}, {"FULL all rot5", 0, F_ALL, 5},
+        {"HALF all", 1, F_ALL, 0}, {"HALF all rot2", 1, F_ALL, 2},
+        {"FULL no-wait (p1 off)", 0, F_ALL & ~F_P1, 0}, {"FULL no-wait rot2", 0, F_ALL & ~F_P1, 2}, {"HALF no-wait (p1 off)", 1, F_ALL & ~F_P1, 0}, {"HALF no-wait rot2", 1, F_ALL & ~F_P1, 2},
+        {"FULL no mfma", 0, F_ALL & ~F_MFMA, 0}, {"HALF no mfma", 1, F_ALL & ~F_MFMA, 0},
+        {"FULL gather only", 0, F_GATHER, 0}, {"FULL gather only rot1", 0, F_GATHER, 1}, {"FULL gather only rot2", 0, F_GATHER, 2}, {"FULL gather only rot5", 0, F_GATHER, 5},
+        {"HALF gather only", 1, F_GATHER, 0}, {"HALF gather only rot2", 1, F_GATHER, 2},
+        {"FULL gather + astream", 0, F_GATHER | F_ASTREAM, 0}, {"FULL gather + astream rot2", 0, F_GATHER | F_ASTREAM, 2}, {"HALF gather + astream", 1, F_GATHER | F_ASTREAM, 0},
+        {"FULL out only", 0, F_OUT, 0}, {"HALF out only", 1, F_OUT, 0},
+        {"FULL p1 only", 0, F_P1, 0}, {"HALF p1 only", 1, F_P1, 0},
+        {"FULL gather mode1 all-hot", 0, F_GATHER, 0, 1}, {"FULL gather mode2 inter cold", 0, F_GATHER, 0, 2}, {"FULL gather mode3 mixed waves", 0, F_GATHER, 0, 3}, {"FULL gather mode4 all cold", 0, F_GATHER, 0, 4},
+        {"HALF gather mode1 all-hot", 1, F_GATHER, 0, 1}, {"HALF gather mode3 mixed waves", 1, F_GATHER, 0, 3}, {"HALF gather mode4 all cold", 1, F_GATHER, 0, 4},
+        {"FULL all but out", 0, F_ALL & ~F_OUT, 0}, {"FULL all but out rot2", 0, F_ALL & ~F_OUT, 2}, {"HALF all but out", 1, F_ALL & ~F_OUT, 0},
     };
     for (int rep = 0; rep < 2; ++rep)
         for (const Var& v : vars) {
             p.flags = v.flags;
+            p.rot_mul = v.rot;
+            p.src_mode = v.mode;
+            if (v.mode && !want_cold) continue;
+            if (!v.mode && want_cold && !(v.flags == F_GATHER && v.rot == 0)) continue;
             p.wg_item = v.half ? d_wg_half : d_wg_full;
             p.n_anchor_wg = n_anchor_wg;
             const int grid = v.half ? grid_half : grid_full;
@@ -683,7 +719,7 @@ int main(int argc, char** argv)
             double ph[3] = {0, 0, 0}, ph_max[3] = {0, 0, 0};
             for (int it = 0; it < launches + 4; ++it) {
                 const int s = it % NSET_IN;
-                p.feats = d_f[s] + C; p.feats_pos = d_fp[s] + C; p.code = d_c[s]; p.code_pos = d_cp[s];
+                p.feats = d_f[s] + C; p.feats_pos = d_fp[s] + C; p.code = d_c[s]; p.code_pos = d_cp[s]; p.cold = d_cold[s] ? d_cold[s] + C : nullptr;
                 CK(hipMemsetAsync(p.anchor_cnt, 0, (size_t)B * 64 * 4, 0));
                 CK(hipEventRecord(e0, 0));
                 if (v.half) hipLaunchKernelGGL(khalf, dim3(grid), dim3(512), lds_half, 0, p);
@@ -703,6 +739,31 @@ int main(int argc, char** argv)
                     for (int w = 0; w < grid; ++w) {
                         if (items[w] < 0) continue;
                         for (int k = 0; k < 3; ++k) a[k].push_back((double)(hs[(size_t)w * 4 + 1 + k] - t0) / 100.0);
+                    }
+                    if (rep == 1 && getenv("SKEL_VERBOSE") && strstr(getenv("SKEL_VERBOSE"), v.name)) {
+                        printf("  [%s] loop end per XCD (median / max, n; tiles whose source image lives on another XCD):", v.name);
+                        for (int x = 0; x < 8; ++x) {
+                            std::vector<double> e;
+                            int foreign = 0;
+                            for (int w = x; w < grid; w += 8) {
+                                if (items[w] < 0) continue;
+                                const int t = v.half ? items[w] >> 1 : items[w];
+                                if (t < B) continue;
+                                e.push_back((double)(hs[(size_t)w * 4 + 2] - t0) / 100.0);
+                                foreign += (h_src[t] & 7) != x;
+                            }
+                            std::sort(e.begin(), e.end());
+                            if (!e.empty()) printf("  x%d %.1f/%.1f n%zu f%d", x, e[e.size() / 2], e.back(), e.size(), foreign);
+                        }
+                        printf("\n  slowest:");
+                        std::vector<std::pair<double, int>> sl;
+                        for (int w = 0; w < grid; ++w) if (items[w] >= 0) sl.push_back({(double)(hs[(size_t)w * 4 + 2] - t0) / 100.0, w});
+                        std::sort(sl.begin(), sl.end());
+                        for (size_t i = sl.size() - std::min<size_t>(12, sl.size()); i < sl.size(); ++i) {
+                            const int w = sl[i].second, t = v.half ? items[w] >> 1 : items[w];
+                            printf(" [%.1f wg%d x%d p%d src%d(x%d) rank%d]", sl[i].first, w, w & 7, t / B, h_src[t], h_src[t] & 7, h_rank[t]);
+                        }
+                        printf("\n");
                     }
                     for (int k = 0; k < 3; ++k) {
                         std::sort(a[k].begin(), a[k].end());
