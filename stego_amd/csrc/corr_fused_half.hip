@@ -59,6 +59,34 @@ __device__ __forceinline__ void mma_half_h(const unsigned char* __restrict__ As,
     }
 }
 
+// One k-step (16 channels) of a feature stage in format H as two halves - the six fragment reads, the six MFMAs - so that the
+// kernel can put OTHER work between them: the LDS pipe needs as long for a stage's twelve 1 KB fragment reads as the matrix core for its
+// twelve MFMAs (tools/ubench/mfma_rate.hip: 13.4 ns per MFMA from registers, 27-29 ns with a read per MFMA, one wave per SIMD), and a wave
+// that reads, waits and multiplies in turn pays both.
+struct HFrag { f16x8 ah0, al0, ah1, al1, bh, bl; };
+__device__ __forceinline__ void half_frag_read(HFrag& f, const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow,
+                                               int blo, int ks, int lane, int wr)
+{
+    const int r = lane & 31, half = lane >> 5;
+    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb = brow + r;
+    const int u = 2 * ks + half;
+    f.al0 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra0, u));
+    f.al1 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra1, u));
+    f.bh = *reinterpret_cast<const f16x8*>(Bs + swz_h(rb, u));
+    f.ah0 = *reinterpret_cast<const f16x8*>(As + swz_h(ra0, u));
+    f.ah1 = *reinterpret_cast<const f16x8*>(As + swz_h(ra1, u));
+    f.bl = *reinterpret_cast<const f16x8*>(Bs + blo + swz_h(rb, u));
+}
+__device__ __forceinline__ void half_frag_mma(const HFrag& f, f32x16 (&acc)[2])
+{
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al0, f.bh, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al1, f.bh, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah0, f.bl, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah1, f.bl, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah0, f.bh, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah1, f.bh, acc[1], 0, 0, 0);
+}
+
 __device__ __forceinline__ void mma_half_f(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow, int kper,
                                            f32x16 (&acc)[2], int lane, int wr)
 {
@@ -301,9 +329,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         return;
     }
 
-    // ---- which item am I
+    // ---- which item am I.  A sampler on a tile slot holds a self-correlation half by construction (slot k of XCD x: the k-th item in
+    // item order that prefers x = half k & 1 of anchor x + 8 (k >> 1)): no second look at perms behind its phase 1 (2.3 us, stamps)
     int item;
-    if (wave8 == 4) {
+    const int my_slot = (me - NA) >> 3;
+    const int my_nb = (me & 7) < B ? (B - (me & 7) + 7) >> 3 : 0;
+    if (my_slot < 2 * my_nb) {
+        item = 2 * ((me & 7) + 8 * (my_slot >> 1)) + (my_slot & 1);
+    } else if (wave8 == 4) {
         int pref0[ASSIGN_NB];
         assign_prefetch<false, 1>(prm, lane, 0, n_items, pref0);
         item = assign_tile<false, 1>(prm, me - NA, lane, 0, n_items, pref0);
@@ -391,6 +424,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             else if (n + 1 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ring_barrier();                          // B(n)
+        };
+        auto stage_copy = [&](int n) {               // the A side of stage n + 3 into the slot stage n - 1 just left
             if (n + 3 < NT) {
                 const unsigned char* s3 = stage_src(n + 3);
                 const unsigned dst = ring_addr + ((n + 3) & (RS_NS - 1)) * RS_STAGE;
@@ -402,6 +437,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             }
         };
         const int brow = sameAB ? q0 + 32 * wc : 32 * wc;
+        const bool abl_mfma = prm.debug & 1;         // (timing ablation: the stream without the multiplies)
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -410,17 +446,52 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
 #pragma unroll
         for (int n = 0; n < NKC; ++n) {
             stage_head(n);
+            stage_copy(n);
             const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
+            if (abl_mfma) continue;
             if constexpr (PREC == PREC_F32) mma_half_f(As, sameAB ? As : As + RS_SIDE, brow, kper, accc, lane, wr);
             else mma_half_fh(As, sameAB ? As : As + RS_SIDE, brow, kper, accc, lane, wr);
         }
+        if constexpr (PREC == PREC_F32) {
 #pragma unroll 1
-        for (int n = NKC; n < NT; ++n) {
-            stage_head(n);
-            const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
-            const unsigned char* Bs = sameAB ? As : As + RS_SIDE;
-            if constexpr (PREC == PREC_F32) mma_half_f(As, Bs, brow, KC2, accf, lane, wr);
-            else mma_half_h(As, Bs, brow, accf, lane, wr);
+            for (int n = NKC; n < NT; ++n) {
+                stage_head(n);
+                stage_copy(n);
+                const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
+                const unsigned char* Bs = sameAB ? As : As + RS_SIDE;
+                if (abl_mfma) continue;
+                mma_half_f(As, Bs, brow, KC2, accf, lane, wr);
+            }
+        } else {
+            // Software pipeline over the k-steps, ACROSS the stage barrier: the fragments of k-step 1 are read while k-step 0 multiplies,
+            // then the wave passes B(n + 1) - every LDS read of stage n has landed by then (ring_barrier waits for lgkmcnt(0)), so its slot
+            // may be overwritten - issues the A copies and reads k-step 0 of stage n + 1 while k-step 1 of stage n multiplies.  The same
+            // 48 fragment registers, the same NT barriers; only the prologue's reads are exposed.
+            auto frag = [&](HFrag& f, int n, int ks) {
+                const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
+                half_frag_read(f, As, sameAB ? As : As + RS_SIDE, brow, 8192, ks, lane, wr);
+            };
+            HFrag x0, x1;
+            stage_head(NKC);
+            stage_copy(NKC);
+            frag(x0, NKC, 0);
+#pragma unroll 1
+            for (int n = NKC; n < NT; ++n) {
+                if (!(prm.debug & 4)) frag(x1, n, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (prm.debug & 2) { asm volatile("" :: "v"(x0.ah0), "v"(x0.al0), "v"(x0.ah1), "v"(x0.al1), "v"(x0.bh), "v"(x0.bl)); }
+                else if (!abl_mfma) half_frag_mma(x0, accf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + 1 < NT) {
+                    stage_head(n + 1);
+                    stage_copy(n + 1);
+                    if (!(prm.debug & 4)) frag(x0, n + 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (prm.debug & 2) { asm volatile("" :: "v"(x1.ah0), "v"(x1.al0), "v"(x1.ah1), "v"(x1.al1), "v"(x1.bh), "v"(x1.bl)); }
+                else if (!abl_mfma) half_frag_mma(x1, accf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     } else if (sameAB) {

@@ -23,7 +23,9 @@ na = (cus - 2 * nt) & ~7
 grid = na + 2 * nt
 names = {0: "start", 1: "phase 1 done (samplers) / skipped", 6: "item known", 11: "gather head done", 2: "anchor ready", 7: "loop end", 3: "E0",
          4: "row sums + sum fd published", 8: "row means (partner read)", 5: "sums published + ticket"}
-capi.debug_set("STEGO_DEBUG", 256)
+DBG = 256 | int(os.environ.get("DBG", 0))
+capi.debug_set("STEGO_DEBUG", DBG)
+print("STEGO_DEBUG", DBG)
 desc = capi.make_desc(B, C, K, H, W, S, n_neg, cfg, (.18, .12, .46), capi.PREC_F16X3)
 f32 = dict(dtype=torch.float32, device=dev)
 outs = [torch.empty(3, **f32), torch.empty(B, S**4, **f32), torch.empty(B, S**4, **f32), torch.empty(n_neg * B, S**4, **f32),
