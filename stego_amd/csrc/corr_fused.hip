@@ -279,7 +279,10 @@ __device__ __forceinline__ float wave_tree_sum(float v)
 
 // Samples the rows [lr0, lr0 + 2 G) of the current pass (this wave's share; global point index = blk0 + row) into the
 // staging area.
-template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false, bool ODDK = false>
+// CH (the column-half kernel in F16X3 mode): the code operand leaves in format H like the features - split into fp16 hi / lo planes of
+// 32-channel stages (kper channels + zero padding) - so that the code stages of that kernel are plain fragment reads + MFMAs (the
+// in-register split of format F costs its MFMA team 1 us per code stage: profiles/r06c_half_ablations.txt).
+template <int NJ, int PREC, int NKCT, int G, bool LIGHT = false, bool ODDK = false, bool CH = false>
 __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, int blk0, int end, int lr0, int lane,
                                                unsigned char* lds, unsigned long long* tsd)
 {
@@ -426,6 +429,27 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
         r1 = r1 * cinv;
         r2 = r2 * cinv;
         const int kall = prm.NKC * prm.kper;
+        if constexpr (CH) {
+            // staging: [stage][plane][ROWS][64 B]; a lane pair's two channels are one packed fp16 pair (4-byte stores, never 2)
+            auto put = [&](int k, float x, float y) {
+                const int sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
+                unsigned h, l;
+                split_f16_pair(x, y, h, l);
+                unsigned char* d = lds_cf + ((sc * 2) * ROWS + lr) * 64 + (((col >> 3) ^ ((qq >> 2) & 3)) << 4) + (col & 7) * 2;
+                *reinterpret_cast<unsigned*>(d) = h;
+                *reinterpret_cast<unsigned*>(d + ROWS * 64) = l;
+            };
+            if (2 * hl < kall) put(2 * hl, r0[0], r0[1]);
+            const float r1n = dpp_mov<0xB1>(r1), r2n = dpp_mov<0xB1>(r2);             // my neighbour's channel (quad_perm [1,0,3,2])
+            if (!(hl & 1) && 64 + hl < kall) put(64 + hl, r1, r1n);
+            if (!(hl & 1) && 96 + hl < kall) put(96 + hl, r2, r2n);
+            // channels kper .. 31 of every stage: zeros (nothing masks them in the MFMAs; fp16 garbage may be NaN)
+            const int pad_units = 4 - (prm.kper >> 3);
+            for (int i = hl; i < prm.NKC * 2 * pad_units; i += 32) {
+                const int pl = i / pad_units, u = (prm.kper >> 3) + (i - pl * pad_units);
+                *reinterpret_cast<u32x4*>(lds_cf + (pl * ROWS + lr) * 64 + ((u ^ ((qq >> 2) & 3)) << 4)) = u32x4{0u, 0u, 0u, 0u};
+            }
+        } else {
         if (2 * hl < kall) {
             const int k = 2 * hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<f32x2*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r0;
@@ -434,14 +458,17 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
             const int k = 64 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r1;
         }
+        }
         unsigned char* cx_row = lds_cx + lr * crow;
         if constexpr (LIGHT) cx_row = reinterpret_cast<unsigned char*>(prm.cs + ((size_t)ba[g] * TP + qq) * prm.LDK);     // straight to memory
         const bool cx_on = !LIGHT || act[g];
         if (cx_on && 2 * hl < prm.KQ) *reinterpret_cast<f32x2*>(cx_row + 8 * hl) = r0;
         if (cx_on && 64 + hl < prm.KQ) *reinterpret_cast<float*>(cx_row + 4 * (64 + hl)) = r1;
+        if constexpr (!CH) {
         if (96 + hl < kall) {
             const int k = 96 + hl, sc = (k >= prm.kper) + (k >= 2 * prm.kper) + (k >= 3 * prm.kper), col = k - sc * prm.kper;
             *reinterpret_cast<float*>(lds_cf + (sc * ROWS + lr) * 128 + (((col >> 2) ^ ((qq >> 1) & 7)) << 4) + (col & 3) * 4) = r2;
+        }
         }
         if (cx_on && 96 + hl < prm.KQ) *reinterpret_cast<float*>(cx_row + 4 * (96 + hl)) = r2;
         if (act[g] && hl == 0) prm.nrm[(size_t)ba[g] * TP + qq] = nr;
@@ -454,7 +481,7 @@ __device__ __forceinline__ void p1_sample_rows(const FusedParams& prm, int xa, i
 
 // Writes staged rows [row0, row0 + nrows) (global point index blk0 + row) out: the planes `first`, `first + step`, ...
 // of the plane list {feature planes, code stages, context} by this wave, 16 bytes per lane, write-through.
-template <int NJ, int PREC, bool LIGHT = false>
+template <int NJ, int PREC, bool LIGHT = false, bool CH = false>
 __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int blk0, int row0, int nrows, int first,
                                             int step, int lane, const unsigned char* lds, __amdgpu_buffer_rsrc_t fs_rsrc,
                                             __amdgpu_buffer_rsrc_t csf_rsrc, __amdgpu_buffer_rsrc_t cs_rsrc)
@@ -464,7 +491,9 @@ __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int 
     const int crow = prm.LDK * 4;
     const unsigned char* lds_cf = lds + LY::CF;
     const unsigned char* lds_cx = lds + LY::CX;
-    const int nplanes = NFP + prm.NKC + 1;
+    constexpr int CPL = CH ? 2 : 1, CRB = CH ? 64 : 128;             // planes and row bytes of a code stage (format H: hi + lo of 64-byte rows)
+    const int ncode = prm.NKC * CPL;
+    const int nplanes = NFP + ncode + 1;
     // all rows of a call belong to one anchor (the caller splits a pass at an anchor boundary)
     const int set = xa + 8 * ((blk0 + row0) >> 7), q0 = (blk0 + row0) & (TP - 1);
     int pl = first;
@@ -476,10 +505,11 @@ __device__ __forceinline__ void p1_copy_out(const FusedParams& prm, int xa, int 
         for (int u = lane; u < nrows * UPR; u += 64)                 // (staged rows are contiguous, and so is the run they leave as)
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), fs_rsrc, base + u * 16, 0, 16);
     }
-    for (; pl < NFP + prm.NKC; pl += step) {                         // code operand stages: 128-byte rows
-        const unsigned char* src = lds_cf + ((pl - NFP) * ROWS + row0) * 128;
-        const unsigned base = (unsigned)(((size_t)set * prm.NKC + (pl - NFP)) * RS_SIDE + q0 * 128);
-        for (int u = lane; u < nrows * 8; u += 64)
+    for (; pl < NFP + ncode; pl += step) {                           // code operand stages
+        const int cp = pl - NFP, sc = cp / CPL, pp = cp - sc * CPL;
+        const unsigned char* src = lds_cf + (cp * ROWS + row0) * CRB;
+        const unsigned base = (unsigned)(((size_t)set * prm.NKC + sc) * RS_SIDE + pp * 8192 + q0 * CRB);
+        for (int u = lane; u < nrows * (CRB / 16); u += 64)
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(src + u * 16), csf_rsrc, base + u * 16, 0, 16);
     }
     if (!LIGHT && pl < nplanes) {                                    // context rows (LDK floats: whole 16-byte units)
@@ -1569,7 +1599,7 @@ hipError_t launch_fused_half(const FusedParams& prm, int precision, hipStream_t 
 // kernel - its ablation / forced-path bits mean that kernel; bit 16384 has no other meaning: same-process A/B of the two launches.
 static bool half_launch_covers(const FusedParams& prm, bool shared, int all, int* n_anchor_wg)
 {
-    if (shared || (prm.debug & ~(256 | 7)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA)
+    if (shared || (prm.debug & ~(256 | 1)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA)
     if (!(prm.C == 384 || prm.C == 768) || (prm.K & 1) || prm.P <= 64) return false;
     const int n_items = 2 * prm.n_sets * prm.B;
     if (n_items + 8 > all) return false;

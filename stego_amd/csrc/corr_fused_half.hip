@@ -105,28 +105,6 @@ __device__ __forceinline__ void mma_half_f(const unsigned char* __restrict__ As,
     }
 }
 
-// code stage on the fp16 matrix cores: fp32 operands (format F) split in registers, as mma_stage_fh
-__device__ __forceinline__ void mma_half_fh(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow, int kper,
-                                            f32x16 (&acc)[2], int lane, int wr)
-{
-    const int r = lane & 31, half = lane >> 5;
-    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb = brow + r;
-    for (int ks = 0; 16 * ks < kper; ++ks) {
-        const int u = 4 * ks + 2 * half;
-        const bool live = 16 * ks + 8 * half < kper;
-        f16x8 ah0, al0, ah1, al1, bh, bl;
-        split_f16x8(*reinterpret_cast<const f32x4*>(As + swz_f(ra0, u)), *reinterpret_cast<const f32x4*>(As + swz_f(ra0, u + 1)), live, ah0, al0);
-        split_f16x8(*reinterpret_cast<const f32x4*>(As + swz_f(ra1, u)), *reinterpret_cast<const f32x4*>(As + swz_f(ra1, u + 1)), live, ah1, al1);
-        split_f16x8(*reinterpret_cast<const f32x4*>(Bs + swz_f(rb, u)), *reinterpret_cast<const f32x4*>(Bs + swz_f(rb, u + 1)), live, bh, bl);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, acc[1], 0, 0, 0);
-    }
-}
-
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Everything is stored (padding rows
 // and columns are inside the [128][LDT2] array): no branches.
 __device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restrict__ T, const float* colscale, int lane, int wr, int wc)
@@ -145,8 +123,10 @@ __device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restr
 // ------------------------------------------------------------------------------------------ the last workgroup of the launch
 // last_workgroup_tail for 2 B items per pair-set (item = 2 * tile + half): same sums in the same tree order, the repair of an item
 // touches its own columns only.
-__device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm, float* Tfd, float* timed_out, int tid, int n_items)
+__device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm, float* Tfd, float* timed_out, int tid, int n_items,
+                                                         unsigned long long* ts = nullptr)
 {
+    if (ts && tid == 0) ts[9] = __builtin_amdgcn_s_memrealtime();
     const int B = prm.B, PB = 2 * B, P = prm.P, P2 = P * P;
     const float cmin = prm.cmin, cmax = prm.cmax;
     unsigned long long* gst = prm.gran + n_items;                  // [n_items][3]: sum lp, sum clamp, old_mean applied
@@ -225,6 +205,7 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
         }
     }
     if (tid == 64) __hip_atomic_store(prm.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ts && tid == 0) ts[10] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
@@ -248,6 +229,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     constexpr int NCH2 = LY::NCH2;
     constexpr int NKC = NKCT;
     constexpr int NT = NKC + NCH2;
+    constexpr bool CH = PREC == PREC_F16X3;      // code operands in format H (see p1_sample_rows): the code stages are feature-like stages
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,18 +280,18 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             __builtin_amdgcn_s_setprio(3);
             for (int pb = beg; pb < end; pb += LYL::ROWS) {
                 const int pe = min(end, pb + LYL::ROWS);
-                if (pb + lr0 < pe) p1_sample_rows<NJ, PREC, NKCT, LYL::G, true, false>(prm, x, pb, pe, lr0, lane, ring, nullptr);
+                if (pb + lr0 < pe) p1_sample_rows<NJ, PREC, NKCT, LYL::G, true, false, CH>(prm, x, pb, pe, lr0, lane, ring, nullptr);
                 if constexpr (LYL::XB > 0) {
                     const int lr1 = LYL::MROWS + 8 * 2 * LYL::G + 2 * (wave8 - 4);
-                    if (!mfma_team && pb + lr1 < pe) p1_sample_rows<NJ, PREC, NKCT, 1, true, false>(prm, x, pb, pe, lr1, lane, ring, nullptr);
+                    if (!mfma_team && pb + lr1 < pe) p1_sample_rows<NJ, PREC, NKCT, 1, true, false, CH>(prm, x, pb, pe, lr1, lane, ring, nullptr);
                 }
                 epoch += FUSED_WAVES;
                 team_barrier(team_cnt, epoch, lane);
                 const int nrows = pe - pb;
                 const int to_edge = (((pb >> 7) + 1) << 7) - pb;
                 const int n0 = min(nrows, to_edge);
-                p1_copy_out<NJ, PREC, true>(prm, x, pb, 0, n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
-                if (n0 < nrows) p1_copy_out<NJ, PREC, true>(prm, x, pb, n0, nrows - n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, 0, n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                if (n0 < nrows) p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, n0, nrows - n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
                 epoch += FUSED_WAVES;
                 team_barrier(team_cnt, epoch, lane);
@@ -325,7 +307,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
         }
         __syncthreads();
-        if (fin[0] != 0.f) last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items);
+        if (fin[0] != 0.f) last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
         return;
     }
 
@@ -403,9 +385,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
                 // the samplers did not show up in time: sample the anchor here (identical bytes; see corr_fused_kernel)
                 if (lane == 0) __hip_atomic_fetch_add(prm.done_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int qq = 0; qq < TP; qq += 2 * LY::G) {
-                    p1_sample_rows<NJ, PREC, NKCT, LY::G, false, false>(prm, sA, qq, TP, 0, lane, ring, nullptr);
+                    p1_sample_rows<NJ, PREC, NKCT, LY::G, false, false, CH>(prm, sA, qq, TP, 0, lane, ring, nullptr);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    p1_copy_out<NJ, PREC>(prm, sA, qq, 0, 2 * LY::G, 0, 1, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                    p1_copy_out<NJ, PREC, false, CH>(prm, sA, qq, 0, 2 * LY::G, 0, 1, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 }
             }
             if (stamp_on) ts[2] = __builtin_amdgcn_s_memrealtime();
@@ -450,7 +432,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
             if (abl_mfma) continue;
             if constexpr (PREC == PREC_F32) mma_half_f(As, sameAB ? As : As + RS_SIDE, brow, kper, accc, lane, wr);
-            else mma_half_fh(As, sameAB ? As : As + RS_SIDE, brow, kper, accc, lane, wr);
+            else mma_half_h(As, sameAB ? As : As + RS_SIDE, brow, accc, lane, wr);       // (format H: channels kper .. 31 are zeros on both sides)
         }
         if constexpr (PREC == PREC_F32) {
 #pragma unroll 1
@@ -477,19 +459,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             frag(x0, NKC, 0);
 #pragma unroll 1
             for (int n = NKC; n < NT; ++n) {
-                if (!(prm.debug & 4)) frag(x1, n, 1);
+                frag(x1, n, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (prm.debug & 2) { asm volatile("" :: "v"(x0.ah0), "v"(x0.al0), "v"(x0.ah1), "v"(x0.al1), "v"(x0.bh), "v"(x0.bl)); }
-                else if (!abl_mfma) half_frag_mma(x0, accf);
+                if (!abl_mfma) half_frag_mma(x0, accf);
                 __builtin_amdgcn_sched_barrier(0);
                 if (n + 1 < NT) {
                     stage_head(n + 1);
                     stage_copy(n + 1);
-                    if (!(prm.debug & 4)) frag(x0, n + 1, 0);
+                    frag(x0, n + 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (prm.debug & 2) { asm volatile("" :: "v"(x1.ah0), "v"(x1.al0), "v"(x1.ah1), "v"(x1.al1), "v"(x1.bh), "v"(x1.bl)); }
-                else if (!abl_mfma) half_frag_mma(x1, accf);
+                if (!abl_mfma) half_frag_mma(x1, accf);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -581,22 +561,35 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
                 *reinterpret_cast<u32x4*>(dst + (odd ? 8192 : 0) + swz_h(prow, g8 >> 1)) = d;
             }
         };
+        f32x4 cv[NKC];                               // my point's raw code samples (4 channels per chunk): the context rows need them once the norm is known
         auto commit_code = [&](const HSet& g, int m) {
             unsigned char* dst = ring + (m & (RS_NS - 1)) * RS_STAGE + RS_SIDE;
             float v[4];
             blend(g, v);
             ssc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-            float sc = 1.f;
-            if constexpr (PREC == PREC_F16X3) {
+            cv[m] = f32x4{v[0], v[1], v[2], v[3]};
+            if constexpr (!CH) {
+                *reinterpret_cast<f32x4*>(dst + swz_f(prow, g8)) = cv[m];
+            } else {
+                // format H, as a feature stage: a power-of-two prescale per point from the first chunk in which it is non-zero among the
+                // first two, fp16 hi / lo split, one 16-byte store per lane (lanes beyond kper / 4 hold zeros: the stage's padding)
                 if (m < 2 && bscc == 0.f) {
                     float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
                     for (int mm = 4; mm >= 1; mm >>= 1) mx = fmaxf(mx, __shfl_xor(mx, mm, 64));
                     if (mx > 0.f) bscc = __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx));
                 }
-                sc = bscc == 0.f ? 1.f : bscc;
+                const float sc = bscc == 0.f ? 1.f : bscc;
+                unsigned h0, l0, h1, l1;
+                split_f16_pair(v[0] * sc, v[1] * sc, h0, l0);
+                split_f16_pair(v[2] * sc, v[3] * sc, h1, l1);
+                const bool odd = g8 & 1;
+                const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+                const u32x4 d = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
+                *reinterpret_cast<u32x4*>(dst + (odd ? 8192 : 0) + swz_h(prow, g8 >> 1)) = d;
             }
-            *reinterpret_cast<f32x4*>(dst + swz_f(prow, g8)) = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
         };
         auto finish_codes = [&]() {
             float sq = ssc;
@@ -605,16 +598,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             const bool valid = q < P;
             const float nr = valid ? sqrtf(sq) : 0.f;
             const float inv = valid ? __builtin_amdgcn_rcpf(fmaxf(nr, 1e-10f)) : 0.f;
-            const float unsc = (PREC == PREC_F16X3 && bscc != 0.f) ? 1.f / bscc : 1.f;
+            const float unsc = (CH && bscc != 0.f) ? 1.f / bscc : 1.f;
             if (g8 == 0) { cscc[prow] = inv * unsc; prm.nrm[(size_t)sB * TP + q] = nr; }
             float* crow = prm.cs + ((size_t)sB * TP + q) * prm.LDK;
 #pragma unroll
             for (int m = 0; m < NKC; ++m) {
                 const int k = m * kper + 4 * g8;
-                if (4 * g8 < kper && k < prm.KQ)
-                    *reinterpret_cast<f32x4*>(crow + k) = *reinterpret_cast<const f32x4*>(ring + m * RS_STAGE + RS_SIDE + swz_f(prow, g8)) * (inv * unsc);
+                if (4 * g8 < kper && k < prm.KQ) *reinterpret_cast<f32x4*>(crow + k) = cv[m] * inv;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         HSet ga, gb;
         auto issue = [&](HSet& g, int m) {
@@ -846,7 +837,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (fin[0] == 0.f) return;
-    last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items);
+    last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch

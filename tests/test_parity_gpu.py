@@ -1028,7 +1028,14 @@ def test_fused_forward_shared_device_mode_matches():
     """STEGO_FLAG_SHARED_DEVICE (per call; cfg.shared_device / capi.set_shared_device): the fused forward launches one
     workgroup per tile instead of one per compute unit, a third of them take a second phase-1 pass.  Same bytes out."""
     c = GoldenCase("cfg1_B4_vits8_dinolike")
-    base = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]
+    half = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]       # B = 4: the column-half launch (round 6)
+    capi.debug_set("STEGO_DEBUG", 16384)       # the full-tile launch of the same library: the launch shape the shared mode varies
+    try:
+        base = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]
+    finally:
+        capi.debug_set("STEGO_DEBUG", 0)
+    for x, y in zip(base, half):               # the two launch kinds add a row's two halves in different orders: last bits, not more
+        np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6 * float(np.abs(y).mean()))
     capi.set_shared_device(True)
     try:
         alt = _run(c.inputs, c.perms, c.cfg, layout="cl", grad=False, precision="f16x3")["out"]

@@ -21,7 +21,7 @@ nt = (2 + n_neg) * B
 cus = torch.cuda.get_device_properties(0).multi_processor_count & ~7
 na = (cus - 2 * nt) & ~7
 grid = na + 2 * nt
-names = {0: "start", 1: "phase 1 done (samplers) / skipped", 6: "item known", 11: "gather head done", 2: "anchor ready", 7: "loop end", 3: "E0",
+names = {12: "p1: taps known (wave 0)", 13: "p1: gathers landed (wave 0)", 14: "p1: rows staged (team barrier)", 15: "p1: stores landed (wave 0)", 0: "start", 1: "phase 1 done (samplers) / skipped", 6: "item known", 11: "gather head done", 2: "anchor ready", 7: "loop end", 3: "E0",
          4: "row sums + sum fd published", 8: "row means (partner read)", 5: "sums published + ticket"}
 DBG = 256 | int(os.environ.get("DBG", 0))
 capi.debug_set("STEGO_DEBUG", DBG)
@@ -39,7 +39,7 @@ for rep in range(6):
                             *[o.data_ptr() for o in outs], ctx.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
     torch.cuda.synchronize()
-ts = ws[nt * 16 + 1024: nt * 16 + 1024 + grid * 128].view(torch.int64).cpu().numpy().reshape(grid, 16)
+ts = ws[nt * 16 + 1024: nt * 16 + 1024 + grid * 128].view(torch.int64).cpu().numpy().reshape(grid, 16).copy()
 t0 = ts[:, 0].min()
 rel = (ts - t0) / 100.0
 anchor = np.arange(grid) < na
@@ -57,4 +57,18 @@ for cname, sel in (("anchor workgroups", anchor), ("self-correlation halves (sam
             continue
         v = rel[sel, k]
         print("   %-38s %7.2f %7.2f %7.2f" % ((names[k],) + tuple(np.percentile(v, [0, 50, 100]))))
+last = int(np.argmax(ts[:, 10] * (ts[:, 10] > ts[:, 0])))
+print(" last workgroup %d: tail start %.2f, tail end %.2f (us since the first workgroup started)" % (last, rel[last, 9], rel[last, 10]))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+tt = []
+for rep in range(12):
+    d = sets[rep % len(sets)]
+    maps = [capi._map(d[k]) for k in ("feats", "feats_pos", "code", "code_pos")]
+    e0.record()
+    lib.stego_corr_fwd_prepared(byref(desc), *[byref(m) for m in maps], d["coords1"].data_ptr(), d["coords2"].data_ptr(), d["perms"].data_ptr(),
+                                *[o.data_ptr() for o in outs], ctx.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    torch.cuda.synchronize()
+    tt.append(e0.elapsed_time(e1) * 1e3)
+print(" the same launch by torch events around stego_corr_fwd_prepared: %s us" % np.round(sorted(tt)[2:-2], 1))
 capi.debug_set("STEGO_DEBUG", 0)
