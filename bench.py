@@ -663,17 +663,46 @@ def main():
                                           as_channels_last(d0["code"]), as_channels_last(d0["code_pos"]))
         fused = n_launch == 1
         peak = MFMA_F32_PEAK if args.precision == "f32" else MFMA_F16_PEAK / 3.0
+        # ---- the traffic skeleton of the same launch: tools/ubench/fused_skeleton.hip, built by
+        # __graft_entry__.build() beside the library - the forward's grid, placement, gather addresses, LDS-DMA copies and output / context
+        # stores with no normalisation and no rendezvous, on rotating inputs, timed by HIP events in its own process right here.
+        # frac_of_skeleton = skeleton time / kernel time: how much of the launch is the memory system under this access pattern.
+        skeleton = None
+        if n_launch == 1 and K == 70 and S == 11 and n_neg == 5 and C in (384, 768) and H == W and B % 8 == 0 and world == 1:
+            try:
+                import subprocess
+                from stego_amd import _build as _b
+                if os.path.exists(_b.SKELETON_PATH):
+                    o = subprocess.run([_b.SKELETON_PATH, str(B), str(C), str(H), "30", "--json"], stdout=subprocess.PIPE,
+                                       stderr=subprocess.DEVNULL, timeout=120, check=True).stdout.decode().strip().splitlines()[-1]
+                    sk = json.loads(o)
+                    cus = torch.cuda.get_device_properties(dev).multi_processor_count & ~7
+                    layout = "half" if (2 * (2 + n_neg) * B + 8 <= cus and "half" in sk) else "full"
+                    skeleton = {"us": sk[layout]["us"], "p10": sk[layout]["p10"], "p90": sk[layout]["p90"],
+                                "layout": {"full": "one workgroup per 128 x 128 tile (corr_fused_kernel)",
+                                           "half": "one workgroup per 128 x 64 column half (corr_fused_half_kernel)"}[layout],
+                                "other_layout_us": sk.get("half" if layout == "full" else "full", {}).get("us"),
+                                "what": "tools/ubench/fused_skeleton.hip: same grid / placement / gather addresses / LDS-DMA copies / stores, "
+                                        "MFMAs on whatever the ring holds, no normalisation, no rendezvous; %d launches on %d rotating input sets"
+                                        % (sk.get("launches", 0), sk.get("input_sets", 0))}
+            except Exception as e:       # noqa: BLE001 - a record for the reader, never the reason a bench run fails
+                skeleton = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if fused:
             # ONE launch does the whole forward (every distinct tensor of SURVEY.md 8(d) once): its duration prices all
             # algorithmic bytes.  ms_samp / ms_fin are the empty event intervals in front of / behind it.
             t_fwd = ms_main * 1e-3
             ach = ab / t_fwd
-            roof = dict(bound="hbm", kernel="corr_fused_kernel (the whole forward, one launch)", dominant_kernel="corr_fused_kernel",
+            cus_ = torch.cuda.get_device_properties(dev).multi_processor_count & ~7
+            half_ = 2 * (2 + n_neg) * B + 8 <= cus_ and C in (384, 768) and K % 2 == 0 and S * S > 64 and not (args.shared_device == "1")
+            kname = "corr_fused_half_kernel" if half_ else "corr_fused_kernel"
+            roof = dict(bound="hbm", kernel="%s (the whole forward, one launch)" % kname, dominant_kernel=kname,
                         achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
                         frac_of_achievable=ach / HBM_ACHIEVABLE, achievable_peak=HBM_ACHIEVABLE / 1e9,
                         traffic=traffic, traffic_source=traffic_source,
-                        algorithmic_bytes=ab, us_per_launch={"corr_fused_kernel": ms_main * 1e3},
+                        algorithmic_bytes=ab, us_per_launch={kname: ms_main * 1e3},
                         us_per_launch_dist=pctl(fwd_samples.get(id(desc), []), 1e3),
+                        skeleton=skeleton,
+                        frac_of_skeleton=(skeleton["us"] / (ms_main * 1e3)) if skeleton and "us" in skeleton and ms_main > 0 else None,
                         timing="HIP events on the launch stream around single launches, input sets rotated")
             roof_mfma = dict(bound="mfma", kernel="corr_fused_kernel", achieved=fl / t_fwd / 1e12, peak=peak / 1e12,
                              unit="TFLOP/s", frac=fl / t_fwd / peak, algorithmic_flops=fl,

@@ -23,6 +23,9 @@ HEADERS = ["corr_common.h", "corr_tile.h", "host_util.h", "corr_wide.h", "corr_f
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
 # the one torch C++ extension (host only, g++): the autograd function of the loss and the generator's graph-safe Philox state, over the C ABI
+# measurement only (bench.py's roofline.frac_of_skeleton): the traffic skeleton of the fused forward, a stand-alone binary beside the library
+SKELETON_SRC = os.path.join(HERE, "..", "tools", "ubench", "fused_skeleton.hip")
+SKELETON_PATH = os.path.join(LIB_DIR, "fused_skeleton.bin")
 TORCHGLUE_SRC = os.path.join(CSRC, "torch_glue_ext.cpp")
 TORCHGLUE_PATH = os.path.join(LIB_DIR, "_stego_torchglue.so")
 
@@ -184,3 +187,19 @@ def build_asan(force=False, verbose=False):
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_torchglue(force=True, verbose=True))
+
+
+def build_skeleton(force=False, verbose=False):
+    """tools/ubench/fused_skeleton.hip -> stego_amd/lib/fused_skeleton.bin (git-ignored; travels with the snapshot like the library)."""
+    src = os.path.abspath(SKELETON_SRC)
+    if not os.path.exists(src):
+        return None
+    if not force and os.path.exists(SKELETON_PATH) and os.path.getmtime(SKELETON_PATH) >= os.path.getmtime(src):
+        return SKELETON_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-o", SKELETON_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    os.replace(SKELETON_PATH + ".tmp", SKELETON_PATH)
+    return SKELETON_PATH

@@ -584,6 +584,7 @@ int main(int argc, char** argv)
     const int C = argc > 2 ? atoi(argv[2]) : 384;
     const int HW = argc > 3 ? atoi(argv[3]) : 28;
     const int launches = argc > 4 ? atoi(argv[4]) : 40;
+    const bool json = argc > 5 && !strcmp(argv[5], "--json");      // bench.py: one JSON line with the two "all" variants only
     const int NJ = C / 128, NCH2 = C / 32, NPIX = HW * HW, NSET_IN = getenv("SKEL_SETS") ? atoi(getenv("SKEL_SETS")) : 4;
     if (!(C == 384 || C == 768) || B % 8 != 0 || NSETS * B > 256) { printf("C in {384, 768}, B a multiple of 8, 7 B <= 256\n"); return 1; }
     int cus = 0;
@@ -680,13 +681,13 @@ int main(int argc, char** argv)
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, khalf, 512, lds_half));
         hipFuncAttributes fa;
         CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(khalf)));
-        printf("# %d CUs; HALF kernel: %d workgroups per CU (occupancy API), %d VGPRs, %zu B spill; grids: full %d x 768, half %d x 512\n", cus, nb,
+        if (!json) printf("# %d CUs; HALF kernel: %d workgroups per CU (occupancy API), %d VGPRs, %zu B spill; grids: full %d x 768, half %d x 512\n", cus, nb,
                fa.numRegs, (size_t)fa.localSizeBytes, grid_full, grid_half);
         CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kfull)));
-        printf("# FULL kernel: %d VGPRs, %zu B spill\n", fa.numRegs, (size_t)fa.localSizeBytes);
+        if (!json) printf("# FULL kernel: %d VGPRs, %zu B spill\n", fa.numRegs, (size_t)fa.localSizeBytes);
     }
     const double alg = 4.0 * (2.0 * B * C * NPIX + 2.0 * B * K * NPIX + 2.0 * B * P * 2) + 8.0 * NEG * B + 4.0 * ((double)NSETS * B * P2 + (double)NEG * B * P2) + 12;
-    printf("# B=%d C=%d %dx%d: algorithmic bytes %.2f MB (roofline 8 TB/s: %.1f us)\n", B, C, HW, HW, alg / 1e6, alg / 8e6);
+    if (!json) printf("# B=%d C=%d %dx%d: algorithmic bytes %.2f MB (roofline 8 TB/s: %.1f us)\n", B, C, HW, HW, alg / 1e6, alg / 8e6);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Var { const char* name; int half; int flags; int rot; int mode; };
@@ -704,12 +705,15 @@ int main(int argc, char** argv)
         {"HALF gather mode1 all-hot", 1, F_GATHER, 0, 1}, {"HALF gather mode3 mixed waves", 1, F_GATHER, 0, 3}, {"HALF gather mode4 all cold", 1, F_GATHER, 0, 4},
         {"FULL all but out", 0, F_ALL & ~F_OUT, 0}, {"FULL all but out rot2", 0, F_ALL & ~F_OUT, 2}, {"HALF all but out", 1, F_ALL & ~F_OUT, 0},
     };
+    if (json) printf("{\"B\": %d, \"C\": %d, \"HW\": %d, ", B, C, HW);
     for (int rep = 0; rep < 2; ++rep)
         for (const Var& v : vars) {
             p.flags = v.flags;
             p.rot_mul = v.rot;
             p.src_mode = v.mode;
             if (v.mode && !want_cold) continue;
+            if (json && !(v.flags == F_ALL && v.rot == 0 && v.mode == 0)) continue;
+            if (json && v.half && grid_half > 2 * cus) continue;
             if (!v.mode && want_cold && !(v.flags == F_GATHER && v.rot == 0)) continue;
             p.wg_item = v.half ? d_wg_half : d_wg_full;
             p.n_anchor_wg = n_anchor_wg;
@@ -773,9 +777,13 @@ int main(int argc, char** argv)
                 }
             }
             std::sort(ms.begin(), ms.end());
-            if (rep == 1)
+            if (rep == 1 && json)
+                printf("\"%s\": {\"us\": %.2f, \"p10\": %.2f, \"p90\": %.2f, \"last_item_out_us\": %.2f}, ", v.half ? "half" : "full",
+                       ms[ms.size() / 2] * 1e3, ms[ms.size() / 10] * 1e3, ms[ms.size() * 9 / 10] * 1e3, ph_max[2]);
+            else if (rep == 1)
                 printf("%-28s  %6.1f us (p10 %.1f, p90 %.1f)   anchors ready %5.1f / %5.1f   loop end %5.1f / %5.1f   out %5.1f / %5.1f  (median / slowest work item, us from the first start)\n",
                        v.name, ms[ms.size() / 2] * 1e3, ms[ms.size() / 10] * 1e3, ms[ms.size() * 9 / 10] * 1e3, ph[0], ph_max[0], ph[1], ph_max[1], ph[2], ph_max[2]);
         }
+    if (json) printf("\"cus\": %d, \"launches\": %d, \"input_sets\": %d}\n", cus, launches, NSET_IN);
     return 0;
 }
