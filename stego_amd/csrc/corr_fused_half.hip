@@ -33,8 +33,6 @@
 namespace stego {
 
 constexpr int HB = 64;                           // B-side points of a work item
-constexpr int LDT2 = HB + 1;                     // row stride of the parked 128 x 64 tiles (odd: conflict-free column walks)
-static_assert(2 * TP * LDT2 * 4 + TP * 4 <= RS_NS * RS_STAGE, "the parked half tiles and the row-sum vector fit the dead ring");
 
 // ------------------------------------------------------------------------------------------ MFMA stages, 128 x 64
 // wave (wr, wc): A rows 64 wr + {0, 32} + r, B rows brow + r (brow = 32 wc in the gathered B side, q0 + 32 wc in the A side of a
@@ -105,18 +103,22 @@ __device__ __forceinline__ void mma_half_f(const unsigned char* __restrict__ As,
     }
 }
 
-// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Everything is stored (padding rows
-// and columns are inside the [128][LDT2] array): no branches.
-__device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restrict__ T, const float* colscale, int lane, int wr, int wc)
+// The result tiles are parked in the FLAT layout of the outputs, T[a + row * P + col] with my columns only (the partner's stay whatever
+// the ring held: the sweep masks them), so that the sweep reads 16-byte LDS vectors that are the 16-byte global vectors (`a`: see
+// park_flat in corr_tile.h).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// Branch-free: padding rows / columns go to a per-lane dummy word behind the tile.
+__device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restrict__ T, int P, int q0, const float* colscale, int lane, int wr,
+                                          int wc)
 {
-    const int col = 32 * wc + (lane & 31);
-    const float sc = colscale[col];
+    const int dummy = TP * LDT - 72 + lane;          // (T may be shifted by up to 3 floats)
+    const int cl = 32 * wc + (lane & 31), col = q0 + cl;
+    const float sc = colscale[cl];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            T[row * LDT2 + col] = acc[mi][r] * sc;
+            T[(row < P && col < P) ? row * P + col : dummy] = acc[mi][r] * sc;
         }
 }
 
@@ -222,8 +224,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     float4* tapw = reinterpret_cast<float4*>(smem + RD_TAPW);
     unsigned char* ring = smem + RD_RING;
     float* Tfd = reinterpret_cast<float*>(smem + RD_RING);   // epilogue aliases of the ring
-    float* Tcd = Tfd + TP * LDT2;
-    float* rsum = Tcd + TP * LDT2;               // [128] my partial row sums of fd
+    float* Tcd = Tfd + TP * LDT;
+    float* rsum = reinterpret_cast<float*>(smem + RD_TAPOF);      // [128] my partial row sums of fd (the tap tables are dead by then)
     typedef P1Layout<NJ, PREC> LY;
     typedef P1Layout<NJ, PREC, true> LYL;
     constexpr int NCH2 = LY::NCH2;
@@ -665,14 +667,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
 
     __syncthreads();                             // E0: the ring is dead, csc / cscc complete
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
-    if (mfma_team) park_half(accf, Tfd, csc, lane, wr, wc);
+    if (mfma_team) park_half(accf, Tfd + a, P, q0, csc, lane, wr, wc);
     __syncthreads();                             // E1: Tfd complete
     if (mfma_team) {
-        park_half(accc, Tcd, cscc, lane, wr, wc);
+        park_half(accc, Tcd + a, P, q0, cscc, lane, wr, wc);
     } else {
         // my partial row sums of fd: four lanes per row over the 8 gather waves, a fixed trip count of independent predicated loads
         const int row = gt >> 2, t = gt & 3;
-        const float* srcr = Tfd + row * LDT2;
+        const float* srcr = Tfd + a + (row < P ? row : 0) * P + q0;
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < HB / 4; i += 2) {
@@ -717,17 +719,18 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             const int g = (E0 >> 2) + gi;
             if (4 * g >= E1) continue;
             const float rm = rowmean[r] + shift;
+            const f32x4 cd4 = *reinterpret_cast<const f32x4*>(Tcd + 4 * g);
+            f32x4 fd4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mode != 0) fd4 = *reinterpret_cast<const f32x4*>(Tfd + 4 * g);
             f32x4 o4;
             bool in[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int E = 4 * g + k;
                 in[k] = E >= E0 && E < E1;
-                const int cl_ = in[k] ? E - E0 : 0;
-                const float cd = Tcd[r * LDT2 + cl_];
+                const float cd = cd4[k];
                 if (mode == 0) { o4[k] = cd; continue; }
-                const float fd = Tfd[r * LDT2 + cl_];
-                const float wv = fd - rm;
+                const float wv = fd4[k] - rm;
                 const float cl = fminf(fmaxf(cd, cmin), cmax);
                 const float lp = -cl * wv;
                 if (mode == 1) {
@@ -751,6 +754,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         }
     };
     sweep(0);                                    // cd needs nobody
+    if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
     // ---- whole-row means: my partner's partial row sums (bounded wait; it zeroes mine after reading them, I zero its)
     if (wave8 >= 4 && wave8 < 6) {
         float other = 0.f;
@@ -778,6 +782,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     __syncthreads();                             // E3: rowmean
     if (stamp_on) ts[8] = __builtin_amdgcn_s_memrealtime();
     sweep(1);
+    if (stamp_on) ts[13] = __builtin_amdgcn_s_memrealtime();
     bool gave_up = false;
     float* omv = red + 8;                        // [0] old_mean, [1] applied
     if (loss_out) {                              // (workgroup-uniform)
@@ -810,9 +815,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             if (lane == 0) { omv[0] = omx; omv[1] = applied; }
         }
         __syncthreads();                         // E4: old_mean
+        if (stamp_on) ts[14] = __builtin_amdgcn_s_memrealtime();
         om = omv[0];
         gave_up = omv[1] == 0.f;
         sweep(2);
+        if (stamp_on) ts[15] = __builtin_amdgcn_s_memrealtime();
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

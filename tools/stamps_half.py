@@ -21,7 +21,7 @@ nt = (2 + n_neg) * B
 cus = torch.cuda.get_device_properties(0).multi_processor_count & ~7
 na = (cus - 2 * nt) & ~7
 grid = na + 2 * nt
-names = {12: "p1: taps known (wave 0)", 13: "p1: gathers landed (wave 0)", 14: "p1: rows staged (team barrier)", 15: "p1: stores landed (wave 0)", 0: "start", 1: "phase 1 done (samplers) / skipped", 6: "item known", 11: "gather head done", 2: "anchor ready", 7: "loop end", 3: "E0",
+names = {12: "cd swept", 13: "w swept", 14: "old_mean known", 15: "loss swept", 0: "start", 1: "phase 1 done (samplers) / skipped", 6: "item known", 11: "gather head done", 2: "anchor ready", 7: "loop end", 3: "E0",
          4: "row sums + sum fd published", 8: "row means (partner read)", 5: "sums published + ticket"}
 DBG = 256 | int(os.environ.get("DBG", 0))
 capi.debug_set("STEGO_DEBUG", DBG)
@@ -50,8 +50,10 @@ heavy = (~anchor) & ~intra
 print("B=%d %s: grid %d = %d anchor workgroups + %d items (us since the first workgroup started; p0 / p50 / p100)" % (B, wl, grid, na, 2 * nt))
 for cname, sel in (("anchor workgroups", anchor), ("self-correlation halves (samplers)", intra), ("gathered items", heavy)):
     print(" %s (%d)" % (cname, int(sel.sum())))
-    for k in (0, 1, 6, 11, 2, 7, 3, 4, 8, 5):
+    for k in (0, 1, 6, 11, 2, 7, 3, 4, 12, 8, 13, 14, 15, 5):
         if cname.startswith("anchor") and k not in (0, 1):
+            continue
+        if cname.startswith("self") and k in (14, 15):
             continue
         if cname.startswith("self") and k == 11:
             continue
