@@ -191,6 +191,49 @@ def _product_path(sets, cfg, args, kernel_step_s, total=False):
     return out
 
 
+def measured_traffic(workload, B, precision, timeout_s=90):
+    """HBM / fabric bytes of ONE forward launch, measured by THIS run (missing 4): two rocprofv3 counter passes
+    (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: one counter group per pass, no other tracing - MI355X_MICROARCH.md) over a child
+    process that launches the same forward 12 times on rotating inputs (tools/exp/fwd_loop.py); 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes
+    (gfx950 tallies 128-byte requests at 64 B: the guide's correction).  None when rocprofv3 is missing or fails - the caller then
+    falls back on the builder's constant and says so."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    env = dict(os.environ, B=str(B), WL=workload, TMPDIR="/tmp")
+    if precision == "f32":
+        env["PREC"] = "f32"
+    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            try:
+                subprocess.run([exe, "--kernel-trace", "--pmc", cnt, "-d", td, "-o", "pmc", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "exp", "fwd_loop.py"), "12"], env=env, cwd="/tmp", timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                dbs = [os.path.join(r, f) for r, _, fs in os.walk(td) for f in fs if f.endswith("_results.db")]
+                db = sqlite3.connect(dbs[0])
+                cur = db.cursor()
+                tabs = [n for (n,) in cur.execute("select name from sqlite_master where type='table'")]
+                pick = lambda pre: next(n for n in tabs if n.startswith(pre))      # noqa: E731
+                q = ("select s.kernel_name, count(*), avg(e.value) from %s e join %s p on e.pmc_id=p.id join %s d on e.event_id=d.event_id "
+                     "join %s s on d.kernel_id=s.id where p.name='%s' group by s.kernel_name"
+                     % (pick("rocpd_pmc_event"), pick("rocpd_info_pmc"), pick("rocpd_kernel_dispatch"), pick("rocpd_info_kernel_symbol"), cnt))
+                rows = [r for r in cur.execute(q) if "corr_fused" in r[0]]
+                db.close()
+                if not rows:
+                    return None
+                vals[cnt] = (rows[0][2], rows[0][1], rows[0][0])
+            except Exception:       # noqa: BLE001
+                return None
+    kb = 2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]
+    return {"bytes": int(kb * 1024), "fetch_kb": vals["FETCH_SIZE"][0], "write_kb": vals["WRITE_SIZE"][0], "samples": vals["FETCH_SIZE"][1],
+            "kernel": vals["FETCH_SIZE"][2].replace("_ZN5stego", "")[:48]}
+
+
 def cpu_baseline(B, C, H, W, K, S, n_neg, cfg, budget_s=20.0):
     """The reference's CPU path, forward+backward, on the host cores of this box; a bounded sample.  BASELINE.md 2: "imported
     unmodified" - when /root/reference is present (the build container) the timed callable IS the reference's own
@@ -262,6 +305,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (B)")
+    ap.add_argument("--traffic", choices=["measure", "static", "none"], default="measure",
+                    help="roofline.traffic: two rocprofv3 counter passes over a child process in this run (default; falls back on the "
+                         "builder's constant of profiles/traffic.json when rocprofv3 is not usable), that constant, or nothing")
     ap.add_argument("--workload", default="vits8_224", choices=sorted(WORKLOADS))
     ap.add_argument("--feature-samples", type=int, default=0,
                     help="cfg.feature_samples (default: the reference's 11); 12 .. 16 run the multi-launch path of csrc/corr_wide.hip")
@@ -648,7 +694,14 @@ def main():
         # constant that the builder's counter passes of this kernel produced, with where it comes from
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and S == 11 and args.traffic == "measure":
+            mt = measured_traffic(args.workload, B, args.precision)
+            if mt is not None:
+                traffic = mt["bytes"]
+                traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes over a child process "
+                                  "(tools/exp/fwd_loop.py, 12 launches, rotating inputs): 2 x %.1f + %.1f KB per launch of %s"
+                                  % (mt["fetch_kb"], mt["write_kb"], mt["kernel"]))
+        if traffic is None and args.traffic != "none" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 # (the constants are counter passes of the feature_samples = 11 single-launch kernel: any other S is a different set of
