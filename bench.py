@@ -617,6 +617,65 @@ def main():
         except Exception as e:       # noqa: BLE001 - a record for the reader, never the reason a bench run fails
             wide = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- the reference's SHIPPED batch size, for the record (src/configs/train_config.yml:11: batch_size 16; BASELINE config 4 names B = 16
+    # too): the same workload at B = 16 - since round 6 the column-half launch (csrc/corr_fused_half.hip) -, four rotating input sets, eager
+    # launches; the forward by HIP events around single launches like the headline's, the full-tile launch of the same library beside it
+    ref16 = None
+    if rank == 0 and not args.no_alt and not dry and S == 11 and B == 32 and not args.fwd_only:
+        try:
+            B16 = 16
+            sets16 = [make_inputs(B16, C, H, W, K, S, n_neg, 5000 + i, dev, args.layout) for i in range(4)]
+            d16b = capi.make_desc(B16, C, K, H, W, S, n_neg, cfg, (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift),
+                                  capi.PREC_F32 if args.precision == "f32" else capi.PREC_F16X3)
+            gi16, ge16 = torch.tensor(cfg.pos_intra_weight, device=dev), torch.tensor(cfg.pos_inter_weight, device=dev)
+            gn16 = torch.full((1,), cfg.neg_inter_weight / (n_neg * B16 * S ** 4), device=dev).expand(n_neg * B16, S, S, S, S)
+
+            def step_b16(i):
+                d = sets16[i % 4]
+                o = capi.corr_fwd(d16b, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]), as_channels_last(d["code"]),
+                                  as_channels_last(d["code_pos"]), d["coords1"], d["coords2"], d["perms"], True)
+                lm, icd, ecd, nl, ncd, saved = o
+                capi.corr_bwd(d16b, d["code"], d["code_pos"], d["coords1"], d["coords2"], d["perms"], saved, icd, ecd, ncd, gi16, ge16, gn16, None, None, None)
+
+            def fwd_b16():
+                acc, n = 0.0, 0
+                for r in range(6):
+                    for d in sets16:
+                        k = capi.corr_fwd_profile(d16b, as_channels_last(d["feats"]), as_channels_last(d["feats_pos"]), as_channels_last(d["code"]),
+                                                  as_channels_last(d["code_pos"]), d["coords1"], d["coords2"], d["perms"], True, 1)
+                        if r > 0:
+                            acc += k[1]
+                            n += 1
+                return acc / n
+
+            for k in range(8):
+                step_b16(k)
+            torch.cuda.synchronize()
+            nb16 = 100
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(nb16):
+                step_b16(k)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_b16 = e0.elapsed_time(e1) / nb16
+            f_half = fwd_b16()
+            capi.debug_set("STEGO_DEBUG", 16384)            # the full-tile launch of the same library (tools only; reset right below)
+            try:
+                f_full = fwd_b16()
+            finally:
+                capi.debug_set("STEGO_DEBUG", 0)
+            ab16 = algorithmic_bytes_fwd(B16, C, H, W, K, S, n_neg)
+            ref16 = {"batch": B16, "ms_per_step": ms_b16, "value": B16 / (ms_b16 * 1e-3), "unit": "image-pairs/s", "steps": nb16, "launch": "eager",
+                     "forward_us": f_half * 1e3, "forward_frac_of_hbm_peak": ab16 / (f_half * 1e-3) / HBM_PEAK,
+                     "forward_us_full_tile_launch": f_full * 1e3,
+                     "what": "src/configs/train_config.yml:11 ships batch_size 16: the same workload at B = 16; forward = corr_fused_half_kernel (one "
+                             "workgroup per 128 x 64 column half, every compute unit busy) - next to it the full-tile launch of the same library "
+                             "(STEGO_DEBUG bit 16384)"}
+            del sets16
+        except Exception as e:       # noqa: BLE001 - a record for the reader, never the reason a bench run fails
+            ref16 = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- dominant kernel: HIP-event duration per launch, rotating input sets (HBM-cold like the timed loop)
     roof = roof_mfma = roof_bwd = None
     fin_us = None
@@ -868,7 +927,7 @@ def main():
                        "shared_device": (args.shared_device == "1" or (args.shared_device == "auto" and dist is not None)) and not dry},
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_bwd": roof_bwd, "forward_backward_split": split,
             "step_us_dist": step_dist,
-            "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt, "feature_samples_16": wide,
+            "product_path": product, "finalize_kernel_us": fin_us, "other_precision": alt, "feature_samples_16": wide, "reference_batch_16": ref16,
             "cpu_baseline": cpu,
         }
         if dry:

@@ -359,7 +359,7 @@ def torchglue():
                 spec = importlib.util.spec_from_file_location("_stego_torchglue", path)
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
-                mod.bind(_build.LIB_PATH)
+                mod.bind(library_path())      # (the SAME file ctypes loaded: with STEGO_LIB_PATH set two copies would each own their globals - ADVICE round 5)
                 _torchglue_mod = mod
             except (ImportError, OSError, RuntimeError) as e:      # e.g. a stale build against another torch: the product runs without it
                 import warnings

@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(256) wide_gather_kernel(const WideGatherParams
                 const unsigned k2 = (unsigned)__builtin_amdgcn_readlane((int)skey, i + u);
                 wi[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sw), i + u));
                 const float* vr = p.V + (size_t)(k2 >> 2) * K;
-                v0[u] = vr[lane];
+                v0[u] = lane < K ? vr[lane] : 0.f;             // (K < 64: the row ends before lane 63)
                 v1[u] = lane + 64 < K ? vr[lane + 64] : 0.f;
             }
 #pragma unroll
@@ -782,7 +782,10 @@ hipError_t launch_wide_bwd(const WideBwdArgs& a, hipStream_t stream)
     p.tiles = p.tiles_out;
     p.tile_bytes = g.tile_bytes;
     const int HW = a.H * a.W;
-    const bool gather = HW <= 4096 && !(knob(KNOB_DEBUG_BWD) & (1 << 20));             // (debug bit 20: the scatter with global atomics)
+    // (debug bit 20: the scatter with global atomics.  ADVICE round 5: the list builder keeps 2 HW + n_neg B + ... words in LDS - beyond the
+    // 160 KB a shape that the forward took must not fail here: it takes the scatter path)
+    const bool gather = HW <= 4096 && (size_t)(2 * HW + 1 + nnb + 2 + 512 / 64 + 4) * 4 <= (size_t)160 * 1024 - 1024 &&
+                        !(knob(KNOB_DEBUG_BWD) & (1 << 20));
     WideGatherParams q{};
     q.d_rows = p.d_rows; q.d_anchor = p.d_anchor; q.cn = cn; q.inv = inv; q.co1 = co1; q.co2 = co2; q.perms = a.perms;
     q.V = reinterpret_cast<float*>(ws + g.b_v);

@@ -354,33 +354,49 @@ class _LossFamily:
     """The three scalar outputs of ONE forward call - pos_intra_loss.mean(), pos_inter_loss.mean(), neg_inter_loss.mean(), as the
     autograd outputs of the loss op - and the device constants a weighted sum of them needs as upstream gradients."""
     _const = {}
+    _pinned = set()
     __slots__ = ("outs", "means")
 
     def __init__(self, o_intra, o_inter, o_neg, means=None):
         self.outs = (o_intra, o_inter, o_neg)
         self.means = means          # the same three scalars as the op's ONE vector output [3] (the C++ autograd function's), or None
 
+    _CONST_MAX = 256                  # cached device constants (per value / triple, device, dtype)
+
+    @classmethod
+    def _put(cls, key, make, like):
+        """A bounded cache of device constants whose tensors are NEVER replaced while alive: at the bound the least recently used entry's
+        VALUE is overwritten in place (copy_) and the entry re-keyed - a captured graph that baked the old tensor's address in as an upstream
+        gradient keeps a valid pointer; entries made or used during a stream capture are pinned (never re-used), as the workspace cache
+        does (_WS_PINNED).  (scheduled loss weights changed the key every step and the cache grew without bound.)"""
+        t = cls._const.get(key)
+        capturing = torch.cuda.is_available() and like.is_cuda and torch.cuda.is_current_stream_capturing()
+        if t is not None:
+            cls._const[key] = cls._const.pop(key)            # most recently used last
+            if capturing:
+                cls._pinned.add(key)
+            return t
+        if capturing:
+            return None                    # (no allocation + fill inside a capture: the caller takes the plain path)
+        if len(cls._const) >= cls._CONST_MAX:
+            victim = next((k for k in cls._const if k not in cls._pinned and k[1:] == key[1:] and
+                           isinstance(k[0], tuple) == isinstance(key[0], tuple)), None)     # (same device, dtype and shape: scalar or [3])
+            if victim is not None:
+                t = cls._const.pop(victim)
+                t.copy_(make().to(t.device))
+                cls._const[key] = t
+                return t
+        t = cls._const[key] = make()
+        return t
+
     @classmethod
     def const(cls, value, like):
-        key = (float(value), like.device, like.dtype)
-        t = cls._const.get(key)
-        if t is None:
-            if torch.cuda.is_available() and like.is_cuda and torch.cuda.is_current_stream_capturing():
-                return None                    # (no allocation + fill inside a capture: the caller takes the plain path)
-            # (never evicted: a cached constant may be baked into a captured graph as an upstream gradient - a training loop uses a handful)
-            t = cls._const[key] = torch.full((), float(value), device=like.device, dtype=like.dtype)
-        return t
+        return cls._put((float(value), like.device, like.dtype), lambda: torch.full((), float(value), device=like.device, dtype=like.dtype), like)
 
     @classmethod
     def const3(cls, coeffs, like):
         """The coefficient vector [3] as a device tensor (cached per value triple): the upstream of the vector output."""
-        key = (coeffs, like.device, like.dtype)
-        t = cls._const.get(key)
-        if t is None:
-            if like.is_cuda and torch.cuda.is_current_stream_capturing():
-                return None
-            t = cls._const[key] = torch.tensor(coeffs, device=like.device, dtype=like.dtype)
-        return t
+        return cls._put((coeffs, like.device, like.dtype), lambda: torch.tensor(coeffs, device=like.device, dtype=like.dtype), like)
 
 
 def _is_number(x):

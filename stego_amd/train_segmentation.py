@@ -98,7 +98,8 @@ class LitUnsupervisedSegmenter(nn.Module):
                               "multi-launch kernels S <= %d with dim <= %d; this configuration runs on ContrastiveCorrelationLoss.generic_forward "
                               "(the same native samplers and correlation kernels composed in Python): same results, slower and host-bound"
                               % (cfg.feature_samples, dim, MAX_FEATURE_SAMPLES, MAX_FEATURE_SAMPLES_WIDE, MAX_CODE_DIM_WIDE))
-            if MAX_CODE_DIM_ANY_PATH < dim <= MAX_CODE_DIM:
+            # (feature_samples 12 .. 16 run on csrc/corr_wide.hip, which takes any layout with dim <= 128: nothing to warn about - ADVICE round 5)
+            if MAX_CODE_DIM_ANY_PATH < dim <= MAX_CODE_DIM and cfg.feature_samples <= MAX_FEATURE_SAMPLES:
                 # 72 < dim <= 128 exists on the single-launch forward only (plan_fwd / fused_supported, csrc/c_api.hip,
                 # csrc/corr_fused.hip); what it does not take runs on generic_forward like dim > 128 does (fused_kernels_cover decides per
                 # call, from the tensors): the same conditions here, with the cfg keys named, as a warning

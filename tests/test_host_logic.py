@@ -441,6 +441,31 @@ def test_default_forward_outputs_are_tensors(monkeypatch):
         assert c.grad is not None and cp.grad is not None
 
 
+def test_cached_upstream_constants_are_bounded_and_never_reallocated():
+    """modules._LossFamily caches the device constants a lazy weighted sum hands to the backward; coefficients that change
+    every step (scheduled loss weights) must not grow it without bound, and a cached tensor is never replaced by a new allocation (a
+    captured graph may hold its address): at the bound the least recently used tensor is overwritten in place and re-keyed."""
+    import torch
+    from stego_amd import modules as M
+    F = M._LossFamily
+    old, F._const, F._pinned = (F._const, F._pinned), {}, set()
+    try:
+        like = torch.zeros((), dtype=torch.float32)
+        first = F.const(0.5, like)
+        ptr = first.data_ptr()
+        seen = {ptr}
+        for i in range(3 * F._CONST_MAX):
+            t = F.const(1.0 + i, like)
+            assert float(t) == 1.0 + i
+            seen.add(t.data_ptr())
+            v = F.const3((float(i), 0.25, 0.5), like)
+            assert v.tolist() == [float(i), 0.25, 0.5] and v.shape == (3,)
+        assert len(F._const) <= F._CONST_MAX and len(seen) <= F._CONST_MAX
+        assert F.const(1.0 + 3 * F._CONST_MAX - 1, like) is F.const(1.0 + 3 * F._CONST_MAX - 1, like)      # a hit returns the same tensor
+    finally:
+        F._const, F._pinned = old
+
+
 def test_the_selected_generator_restatement_is_reported_and_a_fallback_warns_once(caplog):
     """stego_ref_draws / stego_ref_dropout_masks restate ATen's generator arithmetic; the self-check that selects a
     variant (or keeps the torch calls) must say which - a torch upgrade may not silently return the step to dozens of tiny launches."""
