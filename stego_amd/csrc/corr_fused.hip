@@ -962,7 +962,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
 
     // ---- which tile am I: the first gather wave works it out (ballots over perms, ~1.3 us), everybody else picks it up from LDS
     int tile;
-    if (wave8 == 4) {
+    // Round 6: the first 2 nb slots of an XCD hold, by construction of the placement (tile order, preferences b % 8), the self-correlation
+    // and the inter tiles of its nb anchors: those workgroups know their tile from their index - no cold look at perms, no ballots.  It
+    // matters for the INTER tiles: the only readers of their image, every line a cold miss, the last tiles to finish in the skeleton
+    // (profiles/r06_skeleton_B32_C384.txt) - their gather stream starts ~3 us earlier.
+    const int k_slot = me >> 3;
+    const int k_nb = (me & 7) < B ? (B - (me & 7) + 7) >> 3 : 0;
+    const bool known = prm.ps_round * B >= n_tiles && k_slot < 2 * k_nb && !(prm.debug & 16);      // (debug 16: everybody looks it up)
+    if (known) {
+        tile = (k_slot < k_nb ? 0 : B) + (me & 7) + 8 * (k_slot < k_nb ? k_slot : k_slot - k_nb);
+        if ((prm.debug & 256) && tid == 256) ts[6] = __builtin_amdgcn_s_memrealtime();
+    } else if (wave8 == 4) {
         // More tiles than compute units (B = 64 with 5 negatives: 448): ROUNDS of whole pair-sets - the old_mean rendezvous of a
         // pair-set is between workgroups that run at the same time - of ps_round * B tiles each; the workgroups of round r are
         // the r-th window of the grid and start as the compute units of earlier workgroups become free (every workgroup needs a whole

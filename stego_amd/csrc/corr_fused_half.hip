@@ -320,6 +320,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     const int my_nb = (me & 7) < B ? (B - (me & 7) + 7) >> 3 : 0;
     if (my_slot < 2 * my_nb) {
         item = 2 * ((me & 7) + 8 * (my_slot >> 1)) + (my_slot & 1);
+    } else if (my_slot < 4 * my_nb) {            // the next 2 nb slots: the halves of the XCD's inter tiles (pure cold gathers: they start first)
+        item = 2 * (B + (me & 7) + 8 * ((my_slot - 2 * my_nb) >> 1)) + (my_slot & 1);
     } else if (wave8 == 4) {
         int pref0[ASSIGN_NB];
         assign_prefetch<false, 1>(prm, lane, 0, n_items, pref0);
