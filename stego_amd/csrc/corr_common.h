@@ -158,7 +158,9 @@ struct FusedParams {
     int ps_round;                              // pair-sets per round of tiles (all of them unless there are more tiles than CUs)
     int pointwise;
     int debug;                                 // 32 never rendezvous (always repair), 64 owners skip phase 1 (always help), 128 even phase-1 shares,
-                                               // 256 phase stamps
+                                               // 256 phase stamps, 16 every workgroup looks its tile up (round 6: the intra / inter tiles know theirs),
+                                               // 16384 keep the full-tile launch where the column-half launch would be taken, 1 (column-half
+                                               // launch only) no MFMAs - any other bit keeps the full-tile launch
     int timeout_ticks;                         // bound of every spin, 100 MHz ticks
     float cmin, cmax;
     float shift[3];

@@ -374,7 +374,9 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 if (g + NST - 1 < nstage) issue(g + NST - 1);
                 const half_t* bp = reinterpret_cast<const half_t*>(smem + (g % NST) * DC_SIDE) + r * LDH + 8 * half;
                 // (prepared operands: 32-column groups beyond the block's points and waves whose rows are all beyond M have nothing to multiply)
-                const int nlive = APANELS ? ((mi * TP + 32 * wave < prm.M) ? (min(TP, prm.N - nj * TP) + 31) >> 5 : 0) : 4;
+                // (round 6: the map variant too - a 784-pixel map ends 16 pixels into its seventh block: three of that block's four column
+                // groups and three of the last row block's four waves multiplied padding, 20 % of the launch's MFMAs and fragment reads)
+                const int nlive = (mi * TP + 32 * wave < prm.M) ? (min(TP, prm.N - nj * TP) + 31) >> 5 : 0;
                 if (nlive == 4) {                                      // (the full block: nothing predicated between the MFMAs)
 #pragma unroll
                     for (int ks = 0; ks < KC / 16; ++ks) {
