@@ -1609,7 +1609,7 @@ hipError_t launch_fused_half(const FusedParams& prm, int precision, hipStream_t 
 // kernel - its ablation / forced-path bits mean that kernel; bit 16384 has no other meaning: same-process A/B of the two launches.
 static bool half_launch_covers(const FusedParams& prm, bool shared, int all, int* n_anchor_wg)
 {
-    if (shared || (prm.debug & ~(256 | 1)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA)
+    if (shared || (prm.debug & ~(256 | 3)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA; 2: its twelve-wave form)
     if (!(prm.C == 384 || prm.C == 768) || (prm.K & 1) || prm.P <= 64) return false;
     const int n_items = 2 * prm.n_sets * prm.B;
     if (n_items + 8 > all) return false;

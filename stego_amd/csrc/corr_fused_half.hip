@@ -37,23 +37,28 @@ constexpr int HB = 64;                           // B-side points of a work item
 // ------------------------------------------------------------------------------------------ MFMA stages, 128 x 64
 // wave (wr, wc): A rows 64 wr + {0, 32} + r, B rows brow + r (brow = 32 wc in the gathered B side, q0 + 32 wc in the A side of a
 // self-correlation item)
+template <int MB>
 __device__ __forceinline__ void mma_half_h(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow,
-                                           f32x16 (&acc)[2], int lane, int wr)
+                                           f32x16 (&acc)[MB], int lane, int wr)
 {
     const int r = lane & 31, half = lane >> 5;
-    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb = brow + r;
+    const int ra0 = 32 * MB * wr + r, rb = brow + r;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int u = 2 * ks + half;
-        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(As + swz_h(ra0, u)), al0 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra0, u));
-        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(As + swz_h(ra1, u)), al1 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra1, u));
+        f16x8 ah[MB], al[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(As + swz_h(ra0 + 32 * i, u));
+            al[i] = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra0 + 32 * i, u));
+        }
         const f16x8 bh = *reinterpret_cast<const f16x8*>(Bs + swz_h(rb, u)), bl = *reinterpret_cast<const f16x8*>(Bs + 8192 + swz_h(rb, u));
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i], 0, 0, 0);
     }
 }
 
@@ -61,45 +66,48 @@ __device__ __forceinline__ void mma_half_h(const unsigned char* __restrict__ As,
 // kernel can put OTHER work between them: the LDS pipe needs as long for a stage's twelve 1 KB fragment reads as the matrix core for its
 // twelve MFMAs (tools/ubench/mfma_rate.hip: 13.4 ns per MFMA from registers, 27-29 ns with a read per MFMA, one wave per SIMD), and a wave
 // that reads, waits and multiplies in turn pays both.
-struct HFrag { f16x8 ah0, al0, ah1, al1, bh, bl; };
-__device__ __forceinline__ void half_frag_read(HFrag& f, const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow,
+template <int MB> struct HFrag { f16x8 ah[MB], al[MB], bh, bl; };
+template <int MB>
+__device__ __forceinline__ void half_frag_read(HFrag<MB>& f, const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow,
                                                int blo, int ks, int lane, int wr)
 {
     const int r = lane & 31, half = lane >> 5;
-    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb = brow + r;
+    const int ra0 = 32 * MB * wr + r, rb = brow + r;
     const int u = 2 * ks + half;
-    f.al0 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra0, u));
-    f.al1 = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra1, u));
+#pragma unroll
+    for (int i = 0; i < MB; ++i) f.al[i] = *reinterpret_cast<const f16x8*>(As + 8192 + swz_h(ra0 + 32 * i, u));
     f.bh = *reinterpret_cast<const f16x8*>(Bs + swz_h(rb, u));
-    f.ah0 = *reinterpret_cast<const f16x8*>(As + swz_h(ra0, u));
-    f.ah1 = *reinterpret_cast<const f16x8*>(As + swz_h(ra1, u));
+#pragma unroll
+    for (int i = 0; i < MB; ++i) f.ah[i] = *reinterpret_cast<const f16x8*>(As + swz_h(ra0 + 32 * i, u));
     f.bl = *reinterpret_cast<const f16x8*>(Bs + blo + swz_h(rb, u));
 }
-__device__ __forceinline__ void half_frag_mma(const HFrag& f, f32x16 (&acc)[2])
+template <int MB>
+__device__ __forceinline__ void half_frag_mma(const HFrag<MB>& f, f32x16 (&acc)[MB])
 {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al0, f.bh, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al1, f.bh, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah0, f.bl, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah1, f.bl, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah0, f.bh, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah1, f.bh, acc[1], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh, acc[i], 0, 0, 0);
 }
 
+template <int MB>
 __device__ __forceinline__ void mma_half_f(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs, int brow, int kper,
-                                           f32x16 (&acc)[2], int lane, int wr)
+                                           f32x16 (&acc)[MB], int lane, int wr)
 {
     const int r = lane & 31, half = lane >> 5;
-    const int ra0 = 64 * wr + r, ra1 = ra0 + 32, rb = brow + r;
+    const int ra0 = 32 * MB * wr + r, rb = brow + r;
     for (int kk = 0; kk < kper; kk += 8) {
         const int u = (kk >> 2) + half;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + swz_f(ra0, u));
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + swz_f(ra1, u));
+        f32x4 a[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + swz_f(ra0 + 32 * i, u));
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + swz_f(rb, u));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b0[j], acc[i], 0, 0, 0);
     }
 }
 
@@ -107,17 +115,18 @@ __device__ __forceinline__ void mma_half_f(const unsigned char* __restrict__ As,
 // the ring held: the sweep masks them), so that the sweep reads 16-byte LDS vectors that are the 16-byte global vectors (`a`: see
 // park_flat in corr_tile.h).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 // Branch-free: padding rows / columns go to a per-lane dummy word behind the tile.
-__device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restrict__ T, int P, int q0, const float* colscale, int lane, int wr,
+template <int MB>
+__device__ __forceinline__ void park_half(const f32x16 (&acc)[MB], float* __restrict__ T, int P, int q0, const float* colscale, int lane, int wr,
                                           int wc)
 {
     const int dummy = TP * LDT - 72 + lane;          // (T may be shifted by up to 3 floats)
     const int cl = 32 * wc + (lane & 31), col = q0 + cl;
     const float sc = colscale[cl];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = 32 * MB * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             T[(row < P && col < P) ? row * P + col : dummy] = acc[mi][r] * sc;
         }
 }
@@ -125,6 +134,7 @@ __device__ __forceinline__ void park_half(const f32x16 (&acc)[2], float* __restr
 // ------------------------------------------------------------------------------------------ the last workgroup of the launch
 // last_workgroup_tail for 2 B items per pair-set (item = 2 * tile + half): same sums in the same tree order, the repair of an item
 // touches its own columns only.
+template <int NW>
 __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm, float* Tfd, float* timed_out, int tid, int n_items,
                                                          unsigned long long* ts = nullptr)
 {
@@ -138,7 +148,7 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
     bool mine = false;
     {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (int i = tid; i < n_items * 4; i += FUSED_THREADS) {
+        for (int i = tid; i < n_items * 4; i += 64 * NW) {
             const int t = i >> 2, k = i & 3;
             const unsigned long long* src = k == 0 ? prm.gran + t : gst + (size_t)t * 3 + (k - 1);
             unsigned long long x;
@@ -154,7 +164,7 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
         }
     }
     const bool repair = __syncthreads_or(mine) && prm.pointwise;
-    for (int idx = tid >> 6; idx < 3 * prm.n_sets; idx += FUSED_WAVES) {
+    for (int idx = tid >> 6; idx < 3 * prm.n_sets; idx += NW) {
         const int ps = idx / 3, k = idx - 3 * ps, lane = tid & 63;
         const float* st = sst + (size_t)ps * PB * 4 + k;
         float acc = 0.f;
@@ -162,7 +172,7 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
         if (lane == 0) sums3[idx] = acc;
     }
     if (tid >= 64) {
-        constexpr int NZ = FUSED_THREADS - 64;
+        constexpr int NZ = 64 * NW - 64;
         for (int i = tid - 64; i < B; i += NZ)
             __hip_atomic_store(prm.anchor_cnt + (size_t)i * ANCHOR_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid - 64; i < n_items * 4; i += NZ)
@@ -196,7 +206,7 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
             const float omp = som[tile / B];
             float* lossr = prm.neg_loss + (size_t)(tile - 2 * B) * P2;
             const float* cdr = prm.neg_cd + (size_t)(tile - 2 * B) * P2;
-            for (int e = tid; e < P2; e += FUSED_THREADS) {
+            for (int e = tid; e < P2; e += 64 * NW) {
                 const int col = e % P;
                 if (col < c0 || col >= c1) continue;
                 const float cdv = __hip_atomic_load(cdr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,9 +221,19 @@ __device__ __forceinline__ void last_workgroup_tail_half(const FusedParams& prm,
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <int PREC, int NJ, int NKCT>
-__global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const FusedParams prm)
+// NW waves per workgroup: the last eight gather, the first MW = NW - 8 multiply.  NW = 12 is corr_fused_kernel's split (four MFMA waves of
+// 64 x 32).  NW = 16 (C = 384): EIGHT MFMA waves of 32 x 32, two per SIMD - one wave's fragment reads run under the other's MFMAs (the
+// LDS pipe needs as long for a stage's fragments as the matrix core for its MFMAs, tools/ubench/mfma_rate.hip), each issues two of a
+// stage's sixteen anchor copies instead of four - and phase 1 puts ONE row pair on each of sixteen waves instead of two pairs on eight
+// (its arithmetic, ~600 instructions per row pair, is what the anchors wait for).  128 registers per lane then: fine at C = 384, not for
+// the 96 tap registers of a C = 768 row (the launcher keeps NW = 12 there).
+template <int PREC, int NJ, int NKCT, int NW>
+__global__ void __launch_bounds__(64 * NW) corr_fused_half_kernel(const FusedParams prm)
 {
+    constexpr int MW = NW - 8;                   // MFMA waves
+    constexpr int MB = 8 / MW;                   // 32-row blocks per MFMA wave: wave (wr, wc) owns rows 32 MB wr .. x columns 32 wc ..
+    constexpr int PPW = 16 / MW;                 // pieces of a 16 KB anchor stage per MFMA wave
+    constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* rowmean = reinterpret_cast<float*>(smem + RD_ROWMEAN);
     float* red = reinterpret_cast<float*>(smem + RD_RED);
@@ -235,9 +255,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool mfma_team = wave8 < 4;
-    const int wave = wave8 & 3;
-    const int gt = mfma_team ? tid : tid - NTHREADS;
+    const bool mfma_team = wave8 < MW;
+    const int wave = mfma_team ? wave8 : wave8 - MW;      // index inside the team
+    const int gt = mfma_team ? tid : tid - 64 * MW;
     const int wr = wave >> 1, wc = wave & 1;
     const int B = prm.B, P = prm.P;
     const int kper = prm.kper;
@@ -260,8 +280,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     if (tid == 0) { tile_slot[0] = -1; team_cnt[0] = 0u; fin[1] = 0.f; }
     __syncthreads();
 
-    if (!anchor_wg && wave8 >= 5) {              // coords2 into this CU's L1 while the item is worked out (as corr_fused_kernel)
-        const int idx = 32 * ((wave8 - 5) * 64 + lane);
+    if (!anchor_wg && wave8 > MW) {              // coords2 into this CU's L1 while the item is worked out (as corr_fused_kernel)
+        const int idx = 32 * ((wave8 - MW - 1) * 64 + lane);
         if (idx < B * P * 2) { const float x = prm.coords2[idx]; asm volatile("" :: "v"(x)); }
     }
 
@@ -277,25 +297,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         if (r < ns && nb > 0) {
             const int R = nb * TP;
             const int beg = (int)((long long)R * r / ns), end = (int)((long long)R * (r + 1) / ns);
-            const int lr0 = mfma_team ? 2 * LYL::G * wave : LYL::MROWS + 2 * LYL::G * (wave8 - 4);
+            // rows of a pass: NW = 12 as the light workgroups of corr_fused_kernel (2 G rows per wave + the gather waves' second chunk: 64 rows
+            // at C = 384, 24 at 768); NW = 16 one row pair per wave (32 rows)
+            constexpr int PASS_ROWS = NW == 16 ? 2 * NW : LYL::ROWS;
+            const int lr0 = NW == 16 ? 2 * wave8 : (mfma_team ? 2 * LYL::G * wave : LYL::MROWS + 2 * LYL::G * wave);
             unsigned epoch = 0;
             __builtin_amdgcn_s_setprio(3);
-            for (int pb = beg; pb < end; pb += LYL::ROWS) {
-                const int pe = min(end, pb + LYL::ROWS);
-                if (pb + lr0 < pe) p1_sample_rows<NJ, PREC, NKCT, LYL::G, true, false, CH>(prm, x, pb, pe, lr0, lane, ring, nullptr);
-                if constexpr (LYL::XB > 0) {
-                    const int lr1 = LYL::MROWS + 8 * 2 * LYL::G + 2 * (wave8 - 4);
-                    if (!mfma_team && pb + lr1 < pe) p1_sample_rows<NJ, PREC, NKCT, 1, true, false, CH>(prm, x, pb, pe, lr1, lane, ring, nullptr);
+            for (int pb = beg; pb < end; pb += PASS_ROWS) {
+                const int pe = min(end, pb + PASS_ROWS);
+                if constexpr (NW == 16) {
+                    if (pb + lr0 < pe) p1_sample_rows<NJ, PREC, NKCT, 1, true, false, CH>(prm, x, pb, pe, lr0, lane, ring, nullptr);
+                } else {
+                    if (pb + lr0 < pe) p1_sample_rows<NJ, PREC, NKCT, LYL::G, true, false, CH>(prm, x, pb, pe, lr0, lane, ring, nullptr);
+                    if constexpr (LYL::XB > 0) {
+                        const int lr1 = LYL::MROWS + 8 * 2 * LYL::G + 2 * wave;
+                        if (!mfma_team && pb + lr1 < pe) p1_sample_rows<NJ, PREC, NKCT, 1, true, false, CH>(prm, x, pb, pe, lr1, lane, ring, nullptr);
+                    }
                 }
-                epoch += FUSED_WAVES;
+                epoch += NW;
                 team_barrier(team_cnt, epoch, lane);
                 const int nrows = pe - pb;
                 const int to_edge = (((pb >> 7) + 1) << 7) - pb;
                 const int n0 = min(nrows, to_edge);
-                p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, 0, n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
-                if (n0 < nrows) p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, n0, nrows - n0, wave8, FUSED_WAVES, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, 0, n0, wave8, NW, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
+                if (n0 < nrows) p1_copy_out<NJ, PREC, true, CH>(prm, x, pb, n0, nrows - n0, wave8, NW, lane, ring, fs_rsrc, csf_rsrc, cs_rsrc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
-                epoch += FUSED_WAVES;
+                epoch += NW;
                 team_barrier(team_cnt, epoch, lane);
                 if (tid == 0) p1_publish(prm, x, pb, nrows);
             }
@@ -309,7 +336,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
         }
         __syncthreads();
-        if (fin[0] != 0.f) last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
+        if (fin[0] != 0.f) last_workgroup_tail_half<NW>(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
         return;
     }
 
@@ -322,7 +349,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         item = 2 * ((me & 7) + 8 * (my_slot >> 1)) + (my_slot & 1);
     } else if (my_slot < 4 * my_nb) {            // the next 2 nb slots: the halves of the XCD's inter tiles (pure cold gathers: they start first)
         item = 2 * (B + (me & 7) + 8 * ((my_slot - 2 * my_nb) >> 1)) + (my_slot & 1);
-    } else if (wave8 == 4) {
+    } else if (wave8 == MW) {
         int pref0[ASSIGN_NB];
         assign_prefetch<false, 1>(prm, lane, 0, n_items, pref0);
         item = assign_tile<false, 1>(prm, me - NA, lane, 0, n_items, pref0);
@@ -371,7 +398,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     const bool vec_ok = (!loss_out || (int)((reinterpret_cast<uintptr_t>(loss_out) >> 2) & 3) == a) &&
                         (!w_out || (int)((reinterpret_cast<uintptr_t>(w_out) >> 2) & 3) == a);
     const bool rendezvous = loss_out != nullptr && prm.pointwise;
-    f32x16 accf[2], accc[2];
+    f32x16 accf[MB], accc[MB];
     if (mfma_team) {
         // ================================================================= MFMA team
         auto stage_src = [&](int n) { return n < NKC ? csfA + (size_t)n * RS_SIDE : fsA + (size_t)(n - NKC) * RS_SIDE; };
@@ -404,10 +431,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         auto stage_head = [&](int n) {
+            // my pieces of stage n have landed: only what I issued after them may still fly (wave 0 issued the first three stages alone)
             if (wave == 0 && n == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (wave == 0 && n == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if (n + 2 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (n + 1 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (wave == 0 && n == 1) { if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
+            else if (n + 2 < NT) { if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (n + 1 < NT) { if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ring_barrier();                          // B(n)
         };
@@ -416,17 +444,18 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
                 const unsigned char* s3 = stage_src(n + 3);
                 const unsigned dst = ring_addr + ((n + 3) & (RS_NS - 1)) * RS_STAGE;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pc = wave + 4 * i;
+                for (int i = 0; i < PPW; ++i) {
+                    const int pc = wave + MW * i;
                     dma_piece_sc1(s3 + pc * 1024 + lane * 16, dst + pc * 1024);
                 }
             }
         };
+        const int wr = wave >> 1, wc = wave & 1;
         const int brow = sameAB ? q0 + 32 * wc : 32 * wc;
         const bool abl_mfma = prm.debug & 1;         // (timing ablation: the stream without the multiplies)
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accc[i][e] = 0.f; accf[i][e] = 0.f; }
 #pragma unroll
@@ -453,11 +482,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             // then the wave passes B(n + 1) - every LDS read of stage n has landed by then (ring_barrier waits for lgkmcnt(0)), so its slot
             // may be overwritten - issues the A copies and reads k-step 0 of stage n + 1 while k-step 1 of stage n multiplies.  The same
             // 48 fragment registers, the same NT barriers; only the prologue's reads are exposed.
-            auto frag = [&](HFrag& f, int n, int ks) {
+            auto frag = [&](HFrag<MB>& f, int n, int ks) {
                 const unsigned char* As = ring + (n & (RS_NS - 1)) * RS_STAGE;
                 half_frag_read(f, As, sameAB ? As : As + RS_SIDE, brow, 8192, ks, lane, wr);
             };
-            HFrag x0, x1;
+            HFrag<MB> x0, x1;
             stage_head(NKC);
             stage_copy(NKC);
             frag(x0, NKC, 0);
@@ -485,7 +514,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     } else {
         // ================================================================= gather team: one point per lane group (64 points)
         const int g8 = gt & 7, prow = gt >> 3;       // prow = my point inside the half, q0 + prow inside the set
-        const int gwave = wave8 - 4;
+        const int gwave = wave;
         const int q = q0 + prow;
         float ss = 0.f, bsc = 0.f, ssc = 0.f, bscc = 0.f;
         if (lane < 8) {
@@ -632,7 +661,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
             commit(gc, 2);
             commit(ga, 3);
         }
-        if ((prm.debug & 256) && tid == NTHREADS) ts[11] = __builtin_amdgcn_s_memrealtime();
+        if ((prm.debug & 256) && tid == 64 * MW) ts[11] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             ring_barrier();                          // B(n)
@@ -669,10 +698,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
 
     __syncthreads();                             // E0: the ring is dead, csc / cscc complete
     if (stamp_on) ts[3] = __builtin_amdgcn_s_memrealtime();
-    if (mfma_team) park_half(accf, Tfd + a, P, q0, csc, lane, wr, wc);
+    if (mfma_team) park_half<MB>(accf, Tfd + a, P, q0, csc, lane, wave >> 1, wave & 1);
     __syncthreads();                             // E1: Tfd complete
     if (mfma_team) {
-        park_half(accc, Tcd + a, P, q0, cscc, lane, wr, wc);
+        park_half<MB>(accc, Tcd + a, P, q0, cscc, lane, wave >> 1, wave & 1);
     } else {
         // my partial row sums of fd: four lanes per row over the 8 gather waves, a fixed trip count of independent predicated loads
         const int row = gt >> 2, t = gt & 3;
@@ -693,7 +722,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         float ws = t == 0 ? mine : 0.f;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor(ws, m, 64);
-        if (lane == 0) red[40 + (wave8 - 4)] = ws;
+        if (lane == 0) red[40 + wave] = ws;
     }
     __syncthreads();                             // E2: Tcd, rsum, the eight partial sums of fd
     if (tid == 0) {
@@ -701,7 +730,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         __hip_atomic_store(prm.gran + item, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // my row sums for my partner (one 8-byte write-through granule per row)
-    if (prm.pointwise && wave8 >= 4 && wave8 < 6 && gt < P)
+    if (prm.pointwise && !mfma_team && wave < 2 && gt < P)
         __hip_atomic_store(prm.rowg + (size_t)item * TP + gt, (1ull << 32) | __builtin_bit_cast(unsigned, rsum[gt]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
@@ -715,7 +744,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     float om = 0.f;
     // mode 0: cd; 1: w + the two sums; 2: the negative loss
     auto sweep = [&](int mode) {
-        for (int it = tid; it < P * GPR; it += FUSED_THREADS) {
+        for (int it = tid; it < P * GPR; it += NTHR) {
             const int r = it / GPR, gi = it - r * GPR;
             const int E0 = a + r * P + q0, E1 = E0 + ncols;
             const int g = (E0 >> 2) + gi;
@@ -758,7 +787,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     sweep(0);                                    // cd needs nobody
     if (stamp_on) ts[12] = __builtin_amdgcn_s_memrealtime();
     // ---- whole-row means: my partner's partial row sums (bounded wait; it zeroes mine after reading them, I zero its)
-    if (wave8 >= 4 && wave8 < 6) {
+    if (!mfma_team && wave < 2) {
         float other = 0.f;
         bool bad = false;
         if (prm.pointwise && gt < P) {
@@ -828,13 +857,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
         loss_part += __shfl_xor(loss_part, m, 64);
         clamp_part += __shfl_xor(clamp_part, m, 64);
     }
-    if (lane == 0) { red[16 + wave8 * 2] = loss_part; red[16 + wave8 * 2 + 1] = clamp_part; }
+    if (lane == 0) { csc[wave8 * 2] = loss_part; csc[wave8 * 2 + 1] = clamp_part; }      // (csc is dead since the parks; red[16 ..] would reach red[40 ..] with sixteen waves)
     if (gave_up) __threadfence();                // (rare) whoever repairs this item must see its cd / loss
     __syncthreads();
     unsigned long long* gst = prm.gran + n_items;                  // [n_items][3]
     if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
-        for (int w = 0; w < FUSED_WAVES; ++w) { s1 += red[16 + w * 2]; s2 += red[16 + w * 2 + 1]; }
+        for (int w = 0; w < NW; ++w) { s1 += csc[w * 2]; s2 += csc[w * 2 + 1]; }
         if (gave_up) __hip_atomic_fetch_add(prm.done_cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long* g3 = gst + (size_t)item * 3;
         __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -846,32 +875,37 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_half_kernel(const Fu
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (fin[0] == 0.f) return;
-    last_workgroup_tail_half(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
+    last_workgroup_tail_half<NW>(prm, Tfd, fin + 1, tid, n_items, (prm.debug & 256) ? ts : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------ launch
-#define STEGO_HALF_ONE(PR, N, NK)                                                                      \
+#define STEGO_HALF_ONE(PR, N, NK, NWV)                                                                 \
     do {                                                                                               \
-        hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_half_kernel<PR, N, NK>), lds); \
+        hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_fused_half_kernel<PR, N, NK, NWV>), lds); \
         if (e_ != hipSuccess) return e_;                                                               \
-        hipLaunchKernelGGL((corr_fused_half_kernel<PR, N, NK>), grid, block, lds, stream, prm);        \
+        hipLaunchKernelGGL((corr_fused_half_kernel<PR, N, NK, NWV>), grid, dim3(64 * NWV), lds, stream, prm); \
         return hipSuccess;                                                                             \
     } while (0)
-#define STEGO_HALF_NK(PR, N)                                                                           \
+#define STEGO_HALF_NK(PR, N, NWV)                                                                      \
     do {                                                                                               \
-        if (prm.NKC == 1) STEGO_HALF_ONE(PR, N, 1);                                                    \
-        else if (prm.NKC == 2) STEGO_HALF_ONE(PR, N, 2);                                               \
-        else if (prm.NKC == 3) STEGO_HALF_ONE(PR, N, 3);                                               \
-        else STEGO_HALF_ONE(PR, N, 4);                                                                 \
+        if (prm.NKC == 1) STEGO_HALF_ONE(PR, N, 1, NWV);                                               \
+        else if (prm.NKC == 2) STEGO_HALF_ONE(PR, N, 2, NWV);                                          \
+        else if (prm.NKC == 3) STEGO_HALF_ONE(PR, N, 3, NWV);                                          \
+        else STEGO_HALF_ONE(PR, N, 4, NWV);                                                            \
     } while (0)
 // (the caller - launch_corr_fused - has checked half_launch_covers)
 hipError_t launch_fused_half(const FusedParams& prm, int precision, hipStream_t stream)
 {
     const int n_items = 2 * prm.n_sets * prm.B;
-    const dim3 grid(prm.n_anchor_wg + n_items), block(FUSED_THREADS);
+    const dim3 grid(prm.n_anchor_wg + n_items);
     const int lds = RING_LDS_BYTES;
-    if (precision == PREC_F32) { if (prm.C == 384) STEGO_HALF_NK(PREC_F32, 3); else STEGO_HALF_NK(PREC_F32, 6); }
-    else { if (prm.C == 384) STEGO_HALF_NK(PREC_F16X3, 3); else STEGO_HALF_NK(PREC_F16X3, 6); }
+    // C = 384: sixteen waves (eight MFMA waves, one row pair per wave in phase 1); C = 768: twelve (its phase 1 holds 96 tap registers);
+    // STEGO_DEBUG bit 2: twelve everywhere (same-process A/B)
+    if (prm.C == 384 && !(prm.debug & 2)) {
+        if (precision == PREC_F32) STEGO_HALF_NK(PREC_F32, 3, 16); else STEGO_HALF_NK(PREC_F16X3, 3, 16);
+    }
+    if (precision == PREC_F32) { if (prm.C == 384) STEGO_HALF_NK(PREC_F32, 3, 12); else STEGO_HALF_NK(PREC_F32, 6, 12); }
+    else { if (prm.C == 384) STEGO_HALF_NK(PREC_F16X3, 3, 12); else STEGO_HALF_NK(PREC_F16X3, 6, 12); }
 }
 #undef STEGO_HALF_NK
 #undef STEGO_HALF_ONE

@@ -42,12 +42,17 @@ def test_fused_forward_register_budget(tmp_path):
                 kernels[name][m.group(1)] = int(m.group(2))
         per_unit.append(len([k for k in list(kernels)[before:] if "corr_fused_kernel" in k]))
     assert per_unit == [16, 16, 12, 0], per_unit                # even K: 2 precisions x 2 widths x 4 code-chunk counts; odd K: the same; C = 192: 2 x 3 x even / odd
-    # round 6: the column-half kernel of small batches (corr_fused_half.hip): the same 12-wave / 168-register budget, spills only in phase 1
+    # round 6: the column-half kernel of small batches (corr_fused_half.hip): the same 12-wave / 168-register budget, spills only in phase 1;
+    # its sixteen-wave form (C = 384: eight MFMA waves, one row pair per wave in phase 1) lives on 128 registers, four waves per SIMD
     half = {k: v for k, v in kernels.items() if "corr_fused_half_kernel" in k}
-    assert len(half) == 16, sorted(kernels)                     # 2 precisions x 2 widths x 4 code-chunk counts, even K
+    assert len(half) == 24, sorted(kernels)                     # 2 precisions x (2 widths x 12 waves + C = 384 x 16 waves) x 4 code-chunk counts, even K
     for k, v in half.items():
-        assert v["VGPRs"] + v.get("AGPRs", 0) <= 168 and v["Occupancy [waves/SIMD]"] >= 3, (k, v)
-        assert v["VGPRs Spill"] <= 32 and v["ScratchSize [bytes/lane]"] <= 128, (k, v)
+        if k.endswith("Li16EEEvNS_11FusedParamsE"):
+            assert v["VGPRs"] + v.get("AGPRs", 0) <= 128 and v["Occupancy [waves/SIMD]"] >= 4, (k, v)
+            assert v["VGPRs Spill"] <= 48 and v["ScratchSize [bytes/lane]"] <= 192, (k, v)       # (phase 1's taps; none between the ring loop's barriers)
+        else:
+            assert v["VGPRs"] + v.get("AGPRs", 0) <= 168 and v["Occupancy [waves/SIMD]"] >= 3, (k, v)
+            assert v["VGPRs Spill"] <= 32 and v["ScratchSize [bytes/lane]"] <= 128, (k, v)
     fused = {k: v for k, v in kernels.items() if "corr_fused_kernel" in k}
     assert len(fused) == 44, sorted(kernels)                    # 2 precisions x (2 widths x 4 + C = 192 x 3) code-chunk counts x even / odd K
     for k, v in fused.items():
