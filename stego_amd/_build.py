@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libstego_corr.so")
-SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_fused_odd.hip", "corr_fused_c192.hip", "corr_fused_half.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "sample_sets.hip", "loss_pointwise.hip", "corr_wide.hip", "vit_forward.hip", "host_util.hip", "draws.hip", "head_fused.hip", "c_api.hip"]
+SOURCES = ["corr_sample.hip", "corr_fwd.hip", "corr_fused.hip", "corr_fused_odd.hip", "corr_fused_c192.hip", "corr_fused_half.hip", "corr_bwd.hip", "knn_topk.hip", "dense_corr.hip", "dense_stream.hip", "sample_sets.hip", "loss_pointwise.hip", "corr_wide.hip", "vit_forward.hip", "host_util.hip", "draws.hip", "head_fused.hip", "c_api.hip"]
 HEADERS = ["corr_common.h", "corr_tile.h", "host_util.h", "corr_wide.h", "corr_fused.hip", os.path.join("..", "..", "include", "stego_corr.h"), os.path.join("..", "..", "include", "stego_vit.h"),
            os.path.join("..", "..", "include", "stego_head.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

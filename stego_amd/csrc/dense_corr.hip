@@ -19,6 +19,8 @@
 namespace stego {
 
 hipError_t launch_rowsum(const float* x, float* out, long long rows, int P, hipStream_t stream);          // loss_pointwise.hip
+hipError_t launch_dense_stream(const MapV& a, const MapV& b, int B, int C, int H1, int W1, int H2, int W2, int normalize, float* out, void* ws,
+                               hipStream_t stream);                                                    // dense_stream.hip
 
 constexpr int DC_SIDE = 2 * TP * LDH * 2;          // bytes of one chunk image: hi[128][72] + lo[128][72] fp16
 constexpr int DT_PKS = 68;                         // floats per row of a wave's parked 32 x 64 half quadrant (272 B: conflict-free 16-byte reads along a row)
@@ -280,47 +282,76 @@ __global__ void __launch_bounds__(NTHREADS) dense_rowblock_kernel(const DensePar
                 }
             }
     } else {
-    const int pix = mi * TP + 32 * wave + r;
-    const bool rv = pix < prm.M;
-    const int hh = rv ? pix / prm.W1 : 0, ww = rv ? pix - hh * prm.W1 : 0;
-    const float* xrow = prm.a.p + (long long)n * prm.a.sn + (long long)hh * prm.a.sh + (long long)ww * prm.a.sw;
-    float ss = 0.f, mx = 0.f;
+    // (round 6) The block comes in coalesced - lane (q, s) reads 16 bytes of eight rows per 64-channel chunk, four whole 256-byte runs per
+    // wave instruction, every chunk in flight at once, nothing behind a branch -, gets its row statistics by shuffles inside the 16-lane
+    // groups and passes through the (still idle) ring slots in the split-fp16 chunk layout, from which every lane takes its fragments with
+    // conflict-free 16-byte reads.  Before, each lane read its own row in 32-byte pieces, twice, behind a branch and a full wait per
+    // piece: ~25 serialized cold round trips and every line pulled into the L1 four times - 40 of the kernel's 93 us (stamps,
+    // tools/exp/r6_dense_stamps.py on the streaming variant of this kernel).  Rows beyond M read the map's last pixel times zero.
+    const int q4 = lane >> 4, s16 = lane & 15;
+    const float* aimg = prm.a.p + (long long)n * prm.a.sn;
+    f32x4 ar[DR_MAXCH][8];
+    const float* arow[8];
 #pragma unroll
-    for (int c = 0; c < DR_MAXCH; ++c)
+    for (int i = 0; i < 8; ++i) {
+        const int pc = min(mi * TP + 32 * wave + 4 * i + q4, prm.M - 1);
+        const int hh = pc / prm.W1, ww = pc - hh * prm.W1;
+        arow[i] = aimg + (long long)hh * prm.a.sh + (long long)ww * prm.a.sw;
+    }
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-            const int ch = 64 * c + 16 * ks + 8 * half;
-            if (c < NCH && rv && ch < C) {                    // (C % 8 == 0: a group of 8 is inside or outside)
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xrow + ch), v1 = *reinterpret_cast<const f32x4*>(xrow + ch + 4);
+    for (int c = 0; c < DR_MAXCH; ++c) {
+        const int ch = min(64 * c + 4 * s16, C - 4);           // (chunks / channels beyond C: a valid address, masked below)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ss += v0[e] * v0[e] + v1[e] * v1[e];
-                    mx = fmaxf(mx, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-                }
+        for (int i = 0; i < 8; ++i) ar[c][i] = *reinterpret_cast<const f32x4*>(arow[i] + ch);
+    }
+    float ainv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float ss = 0.f, mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < DR_MAXCH; ++c) {
+            const float m = 64 * c + 4 * s16 < C ? 1.f : 0.f;
+            const f32x4 v = ar[c][i];
+            ss += m * ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            mx = fmaxf(mx, m * fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { ss += __shfl_xor(ss, d, 64); mx = fmaxf(mx, __shfl_xor(mx, d, 64)); }
+        float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;        // norm(), modules.py:276
+        const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
+        const int rl = 32 * wave + 4 * i + q4;
+        ainv[i] = mi * TP + rl < prm.M ? inv * rs : 0.f;
+        if (s16 == 0) ra_s[rl] = 1.f / rs;
+    }
+#pragma unroll
+    for (int c = 0; c < DR_MAXCH; ++c) {
+        unsigned char* stage = smem + (c & 1) * DC_SIDE;
+        if (c < NCH) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float sc = 64 * c + 4 * s16 < C ? ainv[i] : 0.f;
+                unsigned h0, l0, h1, l1;
+                split_f16_pair(ar[c][i][0] * sc, ar[c][i][1] * sc, h0, l0);
+                split_f16_pair(ar[c][i][2] * sc, ar[c][i][3] * sc, h1, l1);
+                half_t* dh = reinterpret_cast<half_t*>(stage) + (32 * wave + 4 * i + q4) * LDH + 4 * s16;
+                *reinterpret_cast<u32x2*>(dh) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(dh + TP * LDH) = u32x2{l0, l1};
             }
         }
-    ss += __shfl_xor(ss, 32, 64);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float inv = prm.normalize ? 1.f / fmaxf(sqrtf(ss), 1e-10f) : 1.f;            // norm(), modules.py:276
-    const float rs = mx * inv > 0.f ? __builtin_ldexpf(1.f, -__builtin_amdgcn_frexp_expf(mx * inv)) : 1.f;
-    inv *= rs;
-    if (half == 0) ra_s[32 * wave + r] = 1.f / rs;
-#pragma unroll
-    for (int c = 0; c < DR_MAXCH; ++c)
+        __syncthreads();                             // the chunk is whole (and everybody has read the slot's previous tenant, two chunks back)
+        const half_t* ap = reinterpret_cast<const half_t*>(stage) + (32 * wave + r) * LDH + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
-            const int ch = 64 * c + 16 * ks + 8 * half;
-            f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (c < NCH && rv && ch < C) { v0 = *reinterpret_cast<const f32x4*>(xrow + ch); v1 = *reinterpret_cast<const f32x4*>(xrow + ch + 4); }
-            unsigned h[4], l[4];
-            split_f16_pair(v0[0] * inv, v0[1] * inv, h[0], l[0]);
-            split_f16_pair(v0[2] * inv, v0[3] * inv, h[1], l[1]);
-            split_f16_pair(v1[0] * inv, v1[1] * inv, h[2], l[2]);
-            split_f16_pair(v1[2] * inv, v1[3] * inv, h[3], l[3]);
-            typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
-            Ah[c][ks] = __builtin_bit_cast(f16x8, du32x4{h[0], h[1], h[2], h[3]});
-            Al[c][ks] = __builtin_bit_cast(f16x8, du32x4{l[0], l[1], l[2], l[3]});
+            if (c < NCH) {
+                Ah[c][ks] = *reinterpret_cast<const f16x8*>(ap + 16 * ks);
+                Al[c][ks] = *reinterpret_cast<const f16x8*>(ap + TP * LDH + 16 * ks);
+            } else {
+                Ah[c][ks] = f16x8{};
+                Al[c][ks] = f16x8{};
+            }
         }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();                                       // ra_s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the counted waits below start from zero
@@ -670,6 +701,10 @@ hipError_t launch_dense_corr(const MapV& a, const MapV& b, int B, int C, int H1,
                (reinterpret_cast<uintptr_t>(m.p) % 16) == 0;
     };
     const int vec = cl(a) && cl(b) ? 1 : 0;
+    // round 6: the streaming kernel (dense_stream.hip) - B read as it lies and converted by the multiplying workgroups themselves, one small
+    // statistics launch in front instead of the operand prep (debug bit 21: the row-block kernel below)
+    if (vec && C % 8 == 0 && C > KC && prm.NCH <= DR_MAXCH && b.sh == W2 * b.sw && !(knob(KNOB_DEBUG) & (8192 | (1 << 21))))
+        return launch_dense_stream(a, b, B, C, H1, W1, H2, W2, normalize, out, ws, stream);
     if (vec && C % 8 == 0 && prm.NCH <= DR_MAXCH && !(knob(KNOB_DEBUG) & 8192)) {          // (debug 8192: the tile kernel)
         // row-block kernel: the A map is consumed as it lies, only B is prepared (blocks [nbA, nbA + nbB) of every image)
         DenseParams pb = prm;
