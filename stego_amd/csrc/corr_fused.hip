@@ -713,8 +713,8 @@ __device__ __forceinline__ void last_workgroup_tail(const FusedParams& prm, floa
             for (;;) {
                 x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((x >> 32) == 1ull) break;
-                // A granule that never arrives (its workgroup cannot have finished: every workgroup has taken its ticket) means
-                // the launch is broken, not slow: the scalars become NaN - loudly wrong - instead of folding in a stale value.
+                // A granule that does not arrive within the bound (every workgroup has taken its ticket, i.e. parked its tile: what is left of
+                // it is two sweeps) means the launch is broken, not slow: the scalars become NaN - loudly wrong - instead of folding in a stale value.
                 if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > prm.timeout_ticks) { timed_out[0] = 1.f; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -1428,11 +1428,19 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         if (lane == 0) red[40 + (wave8 - 4)] = ws;
     }
     __syncthreads();                             // E2: Tcd, rowmean, the eight partial sums of fd
+    // The closing ticket is taken HERE, a sweep's length in front of the workgroup's end (round 6): whoever draws the last one finishes the
+    // launch (last_workgroup_tail), and that workgroup POLLS every tile's granules by tag - so the ticket need not say "everything is
+    // published", only "every workgroup is past this point"; the atomic's round trip (~1 us, formerly behind the last store of the
+    // launch's slowest tile) and the first round of the tail's polls now run under the sweeps.  The hand-off words are zeroed by the tail
+    // only after every tile's LAST granules (published behind its last read of any of them) have arrived.  (STEGO_DEBUG bit 4: at the end.)
+    unsigned tick = 0u;
+    const bool early_ticket = !(prm.debug & 4);
     if (tid == 0) {
         const float sfd = ((red[40] + red[41]) + (red[42] + red[43])) + ((red[44] + red[45]) + (red[46] + red[47]));
         // one aligned 8-byte write-through store: {tag, value} (read by the tiles of my pair-set and by the last workgroup)
         __hip_atomic_store(prm.gran + tile, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        if (early_ticket) tick = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (stamp_on) ts[4] = __builtin_amdgcn_s_memrealtime();
 
@@ -1559,8 +1567,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) corr_fused_kernel(const FusedPa
         __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, gave_up ? 0.f : 1.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
+        if (!early_ticket) tick = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin[0] = tick == gridDim.x - 1 ? 1.f : 0.f;
     }
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
@@ -1609,7 +1617,7 @@ hipError_t launch_fused_half(const FusedParams& prm, int precision, hipStream_t 
 // kernel - its ablation / forced-path bits mean that kernel; bit 16384 has no other meaning: same-process A/B of the two launches.
 static bool half_launch_covers(const FusedParams& prm, bool shared, int all, int* n_anchor_wg)
 {
-    if (shared || (prm.debug & ~(256 | 3)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA; 2: its twelve-wave form)
+    if (shared || (prm.debug & ~(256 | 7)) != 0 || !prm.rowg) return false;       // (1: timing ablation of the half kernel - no MFMA; 2: its twelve-wave form; 4: the closing ticket at the end)
     if (!(prm.C == 384 || prm.C == 768) || (prm.K & 1) || prm.P <= 64) return false;
     const int n_items = 2 * prm.n_sets * prm.B;
     if (n_items + 8 > all) return false;

@@ -725,9 +725,12 @@ __global__ void __launch_bounds__(64 * NW) corr_fused_half_kernel(const FusedPar
         if (lane == 0) red[40 + wave] = ws;
     }
     __syncthreads();                             // E2: Tcd, rsum, the eight partial sums of fd
+    unsigned tick = 0u;                          // (the closing ticket, taken here and not at the end: see corr_fused_kernel)
+    const bool early_ticket = !(prm.debug & 4);
     if (tid == 0) {
         const float sfd = ((red[40] + red[41]) + (red[42] + red[43])) + ((red[44] + red[45]) + (red[46] + red[47]));
         __hip_atomic_store(prm.gran + item, (1ull << 32) | __builtin_bit_cast(unsigned, sfd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (early_ticket) tick = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // my row sums for my partner (one 8-byte write-through granule per row)
     if (prm.pointwise && !mfma_team && wave < 2 && gt < P)
@@ -869,8 +872,8 @@ __global__ void __launch_bounds__(64 * NW) corr_fused_half_kernel(const FusedPar
         __hip_atomic_store(g3 + 0, (1ull << 32) | __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 1, (1ull << 32) | __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g3 + 2, (1ull << 32) | __builtin_bit_cast(unsigned, gave_up ? 0.f : 1.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned t = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fin[0] = t == gridDim.x - 1 ? 1.f : 0.f;
+        if (!early_ticket) tick = __hip_atomic_fetch_add(prm.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin[0] = tick == gridDim.x - 1 ? 1.f : 0.f;
     }
     if (stamp_on) ts[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
