@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-6 evidence run on the GPU box: bench records (cfg-2 with the in-run counter passes and the skeleton; B = 16 / 8 / 64; cfg-4 B = 32 / 16;
 # F32), kernel stats of the bench command at B = 32 and B = 16, PMC passes of forward + backward, the traffic skeleton at four shapes, the
-# MFMA-rate micro-benchmark, stamps of the full-tile and the column-half kernels, half vs full launch of one library.
+# MFMA-rate micro-benchmark, stamps of the full-tile and the column-half kernels, half vs full launch of one library, the dense correspondence
+# (bench + stamps of dense_stream_kernel), KNN at 100 k, same-process A/Bs of the early closing ticket (bit 4) and the twelve-wave half kernel (bit 2).
 # usage: tools/gpu_round6.sh <tag>   (writes gpurun_out/<tag>/...)
 export TMPDIR=/tmp
 TAG=${1:-r06}
@@ -36,6 +37,10 @@ for shp in "32 384 28" "16 384 28" "32 768 40" "16 768 40"; do
 done
 SKEL_MODES=1 stego_amd/lib/fused_skeleton.bin 32 384 28 30 > $OUT/skeleton_B32_hot_cold.txt 2>&1
 tools/ubench/bin/mfma_rate > $OUT/ubench_mfma_rate.txt 2>&1
+python tools/bench_dense.py > $OUT/dense_corr.json 2>> $OUT/bench.err
+python tools/bench_knn.py > $OUT/knn_100k.json 2>> $OUT/bench.err
+python tools/exp/r6_dense_stamps.py > $OUT/stamps_dense_stream.txt 2>&1
+(python tools/exp/r6_ab_debug.py vits8_224 32 0 4; python tools/exp/r6_ab_debug.py vits8_224 16 0 4 2) 2>&1 | grep -v amdgpu.ids > $OUT/ab_ticket_and_waves.txt
 find $OUT -name "*.db" -delete
 rm -rf $OUT/ks32 $OUT/ks16; find $OUT/pmc $OUT/pmc16 -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + 2>/dev/null
 python - <<PY
