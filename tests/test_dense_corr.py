@@ -59,6 +59,46 @@ def test_dense_corr_matches_float64_einsum(shape, layout):
         np.testing.assert_allclose(self_sim, self_sim.transpose(0, 2, 1), atol=1e-6)              # symmetric
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [
+    (3, 192, 14, 14, 14, 14, True),      # three chunks (an odd count), one whole block of B + a tail of 68 pixels
+    (2, 136, 9, 13, 7, 11, False),       # the last chunk holds 8 channels; 117 rows (a partial row block), 77 columns: a tail only, N % 4 = 1 (scalar stores)
+    (9, 328, 12, 12, 20, 20, True),      # two groups of images; 144 rows (a block + 16), 400 columns (three blocks + 16), five chunks + 8 channels
+    (1, 72, 16, 16, 16, 16, True),       # two chunks, exactly two blocks, no tail
+    (2, 256, 3, 50, 50, 3, False),       # 150 x 150, N % 4 = 2
+])
+def test_dense_stream_kernel_shapes(shape):
+    """csrc/dense_stream.hip (channels-last maps, 64 < C <= 384, C % 8 == 0) on the shapes its special cases exist for, against fp64."""
+    from stego_amd import capi
+    B, C, H1, W1, H2, W2, normalize = shape
+    rng = np.random.default_rng(B * C + H1 + 7)
+    a = (rng.standard_normal((B, C, H1, W1)) * rng.uniform(0.2, 5.0, (B, 1, H1, W1))).astype(np.float32)      # pixel norms vary
+    b = (rng.standard_normal((B, C, H2, W2)) * rng.uniform(0.2, 5.0, (B, 1, H2, W2))).astype(np.float32)
+    ta = torch.from_numpy(a).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    tb = torch.from_numpy(b).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = capi.dense_corr(ta, tb, normalize=normalize).cpu().numpy()
+    ref = _ref(a, b, normalize)
+    scale = np.abs(ref).mean()
+    np.testing.assert_allclose(out, ref, rtol=1e-3, atol=2e-5 * max(scale, 1e-3) + 1e-6)
+    err = np.abs(out - ref).max() / max(np.abs(ref).max(), 1e-30)
+    assert err < 2e-6, err                                                                      # fp32 class, not just the north-star bar
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-7, 1.0, 1e6])
+def test_dense_stream_raw_products_any_magnitude(scale):
+    """The streaming kernel's fp16 staging (a power of two per pixel from dense_stats_kernel) on tiny and huge raw maps."""
+    from stego_amd import capi
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((2, 96, 6, 7)) * scale).astype(np.float32)
+    b = (rng.standard_normal((2, 96, 5, 4)) * scale).astype(np.float32)
+    ta = torch.from_numpy(a).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    tb = torch.from_numpy(b).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = capi.dense_corr(ta, tb).cpu().numpy()
+    ref = _ref(a, b, False)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).mean())
+
+
 @pytest.mark.parametrize("scale", [1e-7, 1.0, 1e6])
 def test_dense_corr_raw_products_any_magnitude(scale):
     """Without norm() the products are raw: the fp16 staging must not lose tiny maps or overflow on huge ones."""
