@@ -4,19 +4,24 @@
 //              callers are plot_dino_correspondence.py:39-58 / plot_pr_curves.py:108-121.  SURVEY.md 8(f) rank 3.
 //
 // dense_corr.hip's row-block kernel (round 4 / 5) reads B operands that a prep launch wrote (read 38.5 MB, write 43 MB: 28 us at
-// [32,784,784] C = 384), streams them with LDS-DMA behind one barrier per chunk with every wave reading its fragments and multiplying in
-// lockstep (2.2 us per 64-channel chunk for 1 us of MFMA time), and drains its stores after every block: 93 us.  This kernel keeps its
-// decomposition - one workgroup per (image, 128-pixel block of A), the A block as split-fp16 MFMA fragments in registers (192 VGPRs),
-// wave w owns rows 32 w .. 32 w + 31 against all 128 columns of a B block - and changes the stream:
-//   * B is read as it lies (fp32, channels-last), two chunks ahead into registers, scaled by its row's 1 / ||b|| x power of two (the only
-//     thing a small launch in front computes: dense_stats_kernel, two floats per pixel), split into fp16 hi / lo and written into one of
-//     TWO LDS stages by the waves themselves, a quarter chunk after each k-step's MFMAs: the conversion's VALU work and LDS stores run in
-//     the shadow of the matrix core (~100 of the ~1300 issue slots a chunk's 48 MFMAs leave free).  No operand image in memory at all.
-//   * fragment reads are software-pipelined by one k-step (two fragment sets), so that the LDS pipe works under the MFMAs;
+// [32,784,784] C = 384), streams them with LDS-DMA behind one barrier per chunk, every wave reading its fragments and multiplying in
+// lockstep, and drains its stores after every block: 93 us.  This kernel keeps its decomposition - one workgroup of four 512-register
+// waves per (image, 128-pixel block of A), the A block as split-fp16 MFMA fragments in registers (192 VGPRs), wave w owns rows
+// 32 w .. 32 w + 31 against all 128 columns of a B block - and changes the stream:
+//   * B is read as it lies (fp32, channels-last): lane (q, s) holds 16 bytes of eight rows of the chunk on its way, scales them by the
+//     row's 1 / ||b|| x power of two (the only thing a small launch in front computes: dense_stats_kernel, two floats per pixel), splits
+//     into fp16 hi / lo, stores a row pair into one of TWO LDS stages behind each k-step's MFMAs and reloads its registers with the chunk
+//     after next at once (one register set, a whole chunk of latency).  No operand image in memory at all.
+//   * the A block comes in the same way, every chunk in flight at once, branch-free, and passes through the two stages into fragments;
+//   * ONE set of B fragments (32 registers) is reloaded as it dies, the order pinned by sched_barrier (the scheduler, short of registers,
+//     otherwise sinks every read to just in front of its MFMA; two sets in flight spill inside the loop);
+//   * the whole-block chunk is ONE basic block (what varies is compile-time; the stream runs one chunk past its end on clamped addresses);
 //   * the 32 x 128 slab of a wave is parked in a region of its own right after the block's last MFMA and leaves in sixteen 16-byte
 //     stores per lane DURING the next block's first chunk (two whole 512-byte rows per instruction); nothing waits for a store.
 // Same arithmetic as the row-block kernel: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate, the rows' power-of-two
-// staging scales divided out at the park.
+// staging scales divided out at the park.  Measured 122 -> 98 us; where a chunk's 1.7 us go, and the four other forms that were built
+// and measured no faster: DESIGN.md 4.6c, profiles/r06_dense_attempts.txt (the conversion's ~150 VALU instructions per chunk do NOT
+// hide behind the MFMAs: a SIMD has room for ~4 plain / 2 packed VALU instructions per MFMA, tools/ubench/mfma_beside.hip).
 #include "corr_common.h"
 #include "host_util.h"
 #include <type_traits>
